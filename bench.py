@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""bench.py -- novel-view frames/sec @512x512 (4-view in, 2DGS fwd+bwd) on MI355X.
+
+One *step* = one pass of the raster hot path over one training batch as LaRa's step issues it
+(lightning/network.py:473-497): B = 4 scenes x 8 target views (4 input + 4 novel,
+dataLoader/gobjverse.py:46-47), each view = one GaussianRasterizer forward over the scene's
+P = 524 288 surfels at 512x512 (configs/base.yaml:13,23,34) + its backward.  A *frame* is one such
+forward + backward.  `value` = frames of all ranks / max-over-ranks wall time of the timed steps,
+with scenes, cameras and incoming gradients already resident in HBM.  Data is synthetic (no
+dataset / checkpoint in this environment): SURVEY.md section 8d, lara_amd/synthetic.py.
+
+Multi-GPU: per-scene data parallel, one process per GPU (torch.distributed, backend nccl = RCCL);
+the raster itself is per view and is NOT sharded (BASELINE.json north_star) -> weak scaling, every
+rank renders its own B scenes.  The only exchange step of LaRa's training step is DDP's gradient
+all-reduce of the encoder parameters (train_lightning.py:72); the encoder is outside this path, so
+ranks all-reduce a stand-in fp32 buffer of the encoder's size (126.3 M parameters, SURVEY.md
+section 2 #12) in 25 MB buckets on a side stream, overlapped with the raster backward.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed, algorithmic bytes
+from DESIGN.md / SURVEY.md section 8d) and "cpu_baseline" (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+ENCODER_PARAMS = 126_300_000  # VolTransformer 39.45 M + Decoder + ViT-B/16 ~86 M
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scenes", type=int, default=4, help="scenes per rank per step (config 3: 4)")
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--grid", type=int, default=64, help="surfels = grid^3 * 2 (64 -> 524288)")
+    ap.add_argument("--regime", default="init", choices=["init", "trained"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-res", type=int, default=512)
+    return ap.parse_args()
+
+
+def build_batch(args, device, rank):
+    from lara_amd import cameras, synthetic, GaussianRasterizationSettings
+    scenes = []
+    for i in range(args.scenes):
+        sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=1000 * rank + i, device=device)
+        scenes.append({k: v.requires_grad_(True) for k, v in sc.items()})
+    cams = cameras.make_cameras(cameras.turntable_c2w(args.views), args.res, args.res, 0.75, 0.75,
+                                1.906 - 0.8, 1.906 + 0.8, device=device)
+    # background: 1 for the input views, {0, 0.5, 1} for the novel ones (gobjverse.py:103-106)
+    bgs = [1.0] * (args.views // 2) + [(0.0, 0.5, 1.0)[j % 3] for j in range(args.views - args.views // 2)]
+    settings = []
+    for cam, b in zip(cams, bgs):
+        settings.append(GaussianRasterizationSettings(
+            image_height=args.res, image_width=args.res, tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.full((3,), b, device=device), scale_modifier=1.0,
+            viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(),
+            sh_degree=1, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False))
+    g = torch.Generator(device="cpu").manual_seed(7 + rank)
+    gc = (torch.randn(3, args.res, args.res, generator=g) / (args.res * args.res)).to(device)
+    ga = (torch.randn(7, args.res, args.res, generator=g) / (args.res * args.res) * 0.1).to(device)
+    return scenes, settings, gc, ga
+
+
+def step(scenes, settings, gc, ga):
+    """All forwards of the batch, then one backward through every view (as loss.backward() does)."""
+    from lara_amd import GaussianRasterizer
+    outs, grads = [], []
+    for sc in scenes:
+        for rs in settings:
+            # the reference's activations, applied per view (renderer_2dgs.py:181-189)
+            opac = torch.sigmoid(sc["opacity"])
+            scales = torch.exp(sc["scales"])
+            rots = torch.nn.functional.normalize(sc["rotations"])
+            means2D = torch.zeros_like(sc["centers"], requires_grad=True)
+            color, radii, allmap = GaussianRasterizer(rs)(
+                means3D=sc["centers"], means2D=means2D, shs=sc["shs"], opacities=opac,
+                scales=scales, rotations=rots, cov3D_precomp=None)
+            outs += [color, allmap]
+            grads += [gc, ga]
+    torch.autograd.backward(outs, grads)
+    for sc in scenes:
+        for v in sc.values():
+            v.grad = None
+
+
+def measure_roofline(scenes, settings, gc, ga, args):
+    """Per-kernel HIP-event times over one step; returns (roofline dict, per-kernel table, D)."""
+    from lara_amd import rasterizer
+    rasterizer.profile_enable(True)
+    step(scenes, settings, gc, ga)
+    torch.cuda.synchronize()
+    rec = rasterizer.profile_collect()
+    rasterizer.profile_enable(False)
+    agg = {}
+    for name, ms in rec:
+        a = agg.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += ms
+    # D (pairs per frame) of one representative view
+    from lara_amd import synthetic
+    act = synthetic.activate({k: v.detach() for k, v in scenes[0].items()})
+    r = rasterizer.forward_with_state(settings[0], act["means3D"], act["opacities"], shs=act["shs"],
+                                      scales=act["scales"], rotations=act["rotations"])
+    torch.cuda.synchronize()
+    D = int(r["views"]["header"][0].item())
+    P = scenes[0]["centers"].shape[0]
+    HW = args.res * args.res
+    # ALGORITHMIC bytes per launch (DESIGN.md section "kernels and roofs")
+    alg = {
+        "preprocess_fwd": 88 * P + 92 * P,
+        "tile_scan": 12 * (HW // 256),
+        "scatter": 12 * P + 8 * D,
+        "tile_sort_small": 12 * D,
+        "tile_sort_large": 0,
+        "composite_fwd": 84 * D + 60 * HW,
+        "composite_bwd": 84 * D + 100 * HW + 144 * D,
+        "preprocess_bwd": (88 + 80 + 80) * P + 88 * P,
+    }
+    table = {k: {"launches": n, "avg_us": 1e3 * t / n, "alg_bytes": alg.get(k, 0),
+                 "alg_GBs": (alg.get(k, 0) / (1e-3 * t / n) / 1e9) if t > 0 else 0.0}
+             for k, (n, t) in agg.items()}
+    dom = max(table, key=lambda k: table[k]["avg_us"] * table[k]["launches"])
+    t = table[dom]
+    roof = {"kernel": dom, "bound": "hbm", "achieved": round(t["alg_GBs"], 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(t["alg_GBs"] / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_us": round(t["avg_us"], 2), "alg_bytes_per_launch": t["alg_bytes"],
+            "pairs_per_frame_D": D}
+    return roof, table, D
+
+
+def cpu_baseline(args):
+    """The CPU oracle (fp32 restatement, OpenMP over tiles) on a bounded sample: ONE frame
+    (forward + backward of view 0 of scene 0) of the same workload."""
+    import numpy as np
+    import oracle
+    from lara_amd import cameras, synthetic
+    sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=0)
+    act = {k: v.numpy() for k, v in synthetic.activate(sc).items()}
+    res = args.cpu_sample_res
+    cam = cameras.make_cameras(cameras.turntable_c2w(args.views)[:1], res, res, 0.75, 0.75,
+                               1.906 - 0.8, 1.906 + 0.8)[0]
+    view = oracle.View(res, res, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0,
+                       cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 1,
+                       cam.camera_center.numpy())
+    oracle.build()
+    g = np.random.default_rng(0)
+    dc = g.normal(size=(3, res, res)).astype(np.float32)
+    da = g.normal(size=(7, res, res)).astype(np.float32)
+    t0 = time.perf_counter()
+    r = oracle.forward(view, act["means3D"], act["opacities"], shs=act["shs"], scales=act["scales"],
+                       rotations=act["rotations"])
+    oracle.backward(r, dc, da)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame (fwd+bwd, view 0 of scene 0, {res}x{res}, P={act['means3D'].shape[0]}, "
+                      f"D={r.num_rendered}) with the OpenMP fp32 oracle; {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from lara_amd import rasterizer
+    rasterizer.load_library()
+    scenes, settings, gc, ga = build_batch(args, device, rank)
+
+    comm_stream = torch.cuda.Stream(device) if world > 1 else None
+    grad_buf = torch.zeros(ENCODER_PARAMS, device=device) if world > 1 else None
+    BUCKET = 25 * 1024 * 1024 // 4
+
+    def full_step():
+        if world > 1:  # DDP-style bucketed all-reduce, overlapped with the raster work on a side stream
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                for o in range(0, grad_buf.numel(), BUCKET):
+                    dist.all_reduce(grad_buf[o:o + BUCKET])
+        step(scenes, settings, gc, ga)
+        if world > 1:
+            torch.cuda.current_stream().wait_stream(comm_stream)
+
+    for _ in range(args.warmup):
+        full_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rasterizer.check_pending(block=True)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_per_step = args.scenes * args.views * world
+    out = {
+        "metric": "novel-view frames/sec @512x512 (4-view in, 2DGS fwd+bwd)",
+        "value": round(frames_per_step * args.steps / dt, 3),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[2]: training-step raster fwd+bwd, {args.scenes} scenes/GPU x {args.views} "
+                        f"views @{args.res}x{args.res}, P={scenes[0]['centers'].shape[0]} surfels/scene, "
+                        f"SH degree 1, regime={args.regime}",
+            "frames_per_step": frames_per_step,
+            "parallelism": f"dp{world} (per-scene; raster not sharded)",
+            "grad_allreduce": (f"{ENCODER_PARAMS * 4 / 1e6:.0f} MB fp32 stand-in for the encoder's DDP "
+                               "gradient, 25 MB buckets, RCCL, overlapped") if world > 1 else None,
+        },
+    }
+    if rank == 0 and not args.no_roofline:
+        roof, table, D = measure_roofline(scenes, settings, gc, ga, args)
+        out["roofline"] = roof
+        out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
+                              "alg_GBs": round(v["alg_GBs"], 1)} for k, v in table.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+/*
+ * lara2dgs.h -- C ABI of the MI355X-native 2D-Gaussian-surfel rasteriser (liblara2dgs.so).
+ *
+ * This is the drop-in boundary for the one hot path of autonomousvision/LaRa that is native code:
+ * the `diff_surfel_rasterization._C` extension that `lightning/renderer_2dgs.py:7-10` imports and
+ * `renderer_2dgs.py:209-218` calls through `GaussianRasterizer`.  The reference's native module
+ * (pybind, torch::Tensor signatures; sources absent from the snapshot, .gitmodules:1-3) exposes
+ * three entry points; each function below names the one it replaces.  Signatures are plain
+ * pointers and sizes -- no torch types -- so the library is bindable from ctypes / cffi / any FFI
+ * (see INTEGRATION.md for the binding a LaRa maintainer adds).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated otherwise; all float data is fp32,
+ *     contiguous, 16-byte aligned (a torch allocation is);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the calls return
+ *     without synchronising: there is NO host sync on the fast path (the reference blocks on a
+ *     D2H copy of `num_rendered` once per view);
+ *   - the caller owns every allocation: outputs, the `state` buffer that forward hands to
+ *     backward (the reference's geomBuffer/binningBuffer/imgBuffer), and a transient `scratch`;
+ *   - the library keeps no global state and is re-entrant across streams;
+ *   - functions return 0 on success or a negative LARA2DGS_E_* code; nothing throws.
+ *   - binning capacity: the number of (tile, surfel) pairs is data dependent and only known on the
+ *     device.  The caller passes `capacity`; if a view needs more, the kernels raise the
+ *     `overflow` word of the state header AND poison the outputs with NaN (loud in the data); the
+ *     Python operator checks the header lazily and raises.  See DESIGN.md "binning without a
+ *     host sync".
+ */
+#ifndef LARA2DGS_H
+#define LARA2DGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LARA2DGS_ABI_VERSION 1
+
+#define LARA2DGS_OK 0
+#define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
+#define LARA2DGS_E_LAUNCH (-2)    /* a HIP launch / API call failed; see lara2dgs_last_hip_error() */
+#define LARA2DGS_E_UNSUPPORTED (-3)
+
+/* The 12 fields of GaussianRasterizationSettings (renderer_2dgs.py:124-137) plus sizes.
+ * bg / viewmatrix / projmatrix / campos stay DEVICE tensors exactly as the reference passes them
+ * (viewmatrix = w2c^T, projmatrix = w2c^T P^T, campos = -c2w[:3,3]; lightning/utils.py:39-48). */
+typedef struct lara2dgs_view {
+    int32_t P;              /* number of surfels */
+    int32_t sh_degree;      /* active degree 0..3 */
+    int32_t sh_coeffs;      /* coefficients stored per surfel = shs.shape[1] (0 with colors_precomp) */
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t debug;
+    int64_t capacity;       /* max (tile, surfel) pairs the state/scratch buffers were sized for */
+    const float *bg;         /* [3]  */
+    const float *viewmatrix; /* [16] */
+    const float *projmatrix; /* [16] */
+    const float *campos;     /* [3]  */
+} lara2dgs_view;
+
+/* Byte offsets of the sections of the `state` buffer (for tests, debugging and tooling; the
+ * integer sections are the bit-exact parity surface: SURVEY.md section 8a R2-R7). */
+typedef struct lara2dgs_state_layout {
+    int64_t header;      /* uint32[16]: [0]=num_rendered, [1]=overflow flag, [2]=max tile list length */
+    int64_t geom;        /* float[P][20]: Tu(3) Tv(3) Tw(3) xy(2) opacity normal(3) depth rgb(3) clamp-bits */
+    int64_t point_list;  /* uint32[capacity]: surfel ids, per tile, sorted by (depth bits, id) */
+    int64_t ranges;      /* uint32[tiles][2]: [start, end) per 16x16 tile, (0,0) when empty */
+    int64_t final_T;     /* float[3][H][W]: T, M1, M2 */
+    int64_t n_contrib;   /* uint32[2][H][W]: last contributor, median contributor */
+    int64_t total;
+} lara2dgs_state_layout;
+
+int lara2dgs_abi_version(void);
+const char *lara2dgs_error_string(int code);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none). */
+int lara2dgs_last_hip_error(void);
+
+/* Sizes of the two caller-owned buffers.  Replaces the resize-callback scheme of the reference's
+ * `rasterize_gaussians` (geomBuffer / binningBuffer / imgBuffer). */
+int64_t lara2dgs_state_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity);
+int64_t lara2dgs_scratch_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity);
+int lara2dgs_get_state_layout(int32_t P, int32_t H, int32_t W, int64_t capacity,
+                              lara2dgs_state_layout *out);
+
+/* Replaces `_C.rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations,
+ * scale_modifier, transMat_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, H, W, sh, degree,
+ * campos, prefiltered, debug)` as called from GaussianRasterizer.forward
+ * (renderer_2dgs.py:209-218).
+ *   means3D [P,3]; exactly one of shs [P,M,3] / colors_precomp [P,3]; opacities [P];
+ *   either scales [P,2] + rotations [P,4] (w,x,y,z) or transmat_precomp [P,9]; unused = NULL.
+ *   out_color [3,H,W]; out_allmap [7,H,W] (depth-sum, alpha, normal xyz, median depth,
+ *   distortion: renderer_2dgs.py:226-242); out_radii int32 [P]. */
+int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const float *shs,
+                     const float *colors_precomp, const float *opacities, const float *scales,
+                     const float *rotations, const float *transmat_precomp, float *out_color,
+                     float *out_allmap, int32_t *out_radii, void *state, void *scratch,
+                     void *stream);
+
+/* Replaces `_C.rasterize_gaussians_backward(...)`.  `state` is the buffer forward filled.
+ * Gradient outputs (any may be NULL when the corresponding input was NULL):
+ *   dL_dmeans3D [P,3], dL_dmeans2D [P,3], dL_dshs [P,M,3], dL_dcolors [P,3], dL_dopacities [P],
+ *   dL_dscales [P,2], dL_drotations [P,4], dL_dtransmat [P,9].  They are fully overwritten. */
+int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const float *shs,
+                      const float *colors_precomp, const float *scales, const float *rotations,
+                      const float *transmat_precomp, const int32_t *radii, const float *dL_dcolor,
+                      const float *dL_dallmap, const void *state, void *scratch,
+                      float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs, float *dL_dcolors,
+                      float *dL_dopacities, float *dL_dscales, float *dL_drotations,
+                      float *dL_dtransmat, void *stream);
+
+/* Replaces `_C.mark_visible(means3D, viewmatrix, projmatrix)` (GaussianRasterizer.markVisible).
+ * present: uint8 [P]. */
+int lara2dgs_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
+                          const float *projmatrix, uint8_t *present, void *stream);
+
+/* Optional per-kernel timing (bench.py's roofline leg; not part of the reference surface).
+ * When enabled on the calling thread, every kernel the library launches is bracketed by HIP
+ * events recorded on the launch stream.  lara2dgs_profile_collect synchronises those events,
+ * writes up to `max_entries` records (kernel name -> `names`, NUL-separated, at most `names_len`
+ * bytes; duration in milliseconds -> `ms`), clears the log and returns the number written. */
+int lara2dgs_profile_enable(int on);
+int lara2dgs_profile_collect(char *names, int names_len, float *ms, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LARA2DGS_H */

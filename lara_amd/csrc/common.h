@@ -1,0 +1,108 @@
+// common.h -- shared declarations of the gfx950 surfel rasteriser kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lara2dgs.h"
+
+#define TILE 16            // tile edge in pixels: the binning contract (tile ids / ranges are bit-exact)
+#define NEAR_N 0.2f
+#define FAR_N 100.0f
+#define FILTER_SIZE 0.707106f
+#define FILTER_INV_SQUARE 2.0f
+#define CUTOFF 3.0f
+#define GEOM_F 20          // floats per surfel record in the state buffer
+#define GRAD_F 20          // floats per surfel in the backward accumulator (18 used)
+
+// Everything a kernel needs to know about the view, passed by value (lands in SGPRs / kernarg).
+struct ViewDev {
+    int P, deg, M, H, W, gx, gy, tiles;
+    float scale_modifier;
+    unsigned cap;  // capacity in (tile, surfel) pairs
+    const float *bg, *viewmatrix, *projmatrix, *campos;
+};
+
+struct StateView {  // typed pointers into the caller's `state` buffer
+    uint32_t *header;
+    float4 *geom;         // [P][5] float4
+    uint32_t *point_list; // [cap]
+    uint2 *ranges;        // [tiles]
+    float *final_T;       // [3][HW]
+    uint32_t *n_contrib;  // [2][HW]
+};
+
+struct ScratchView {
+    uint32_t *tile_count;  // [tiles]
+    uint32_t *tile_fill;   // [tiles]
+    ushort4 *rect;         // [P]
+    uint64_t *keys;        // [cap]  (depth bits << 32) | surfel id, grouped per tile, unsorted
+    float *grad;           // [P][GRAD_F] backward accumulators (aliases keys/rect region)
+};
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state_layout *L) {
+    const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const int64_t HW = (int64_t)H * W;
+    int64_t o = 0;
+    L->header = o;      o = align_up(o + 64, 256);
+    L->geom = o;        o = align_up(o + (int64_t)P * GEOM_F * 4, 256);
+    L->point_list = o;  o = align_up(o + cap * 4, 256);
+    L->ranges = o;      o = align_up(o + tiles * 8, 256);
+    L->final_T = o;     o = align_up(o + 3 * HW * 4, 256);
+    L->n_contrib = o;   o = align_up(o + 2 * HW * 4, 256);
+    L->total = o;
+}
+
+struct ScratchLayout { int64_t tile_count, tile_fill, rect, keys, grad, total; };
+static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayout *L) {
+    const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    int64_t o = 0;
+    L->tile_count = o;  o = align_up(o + tiles * 4, 256);
+    L->tile_fill = o;   o = align_up(o + tiles * 4, 256);
+    const int64_t fwd0 = o;
+    L->rect = o;        o = align_up(o + (int64_t)P * 8, 256);
+    L->keys = o;        o = align_up(o + cap * 8, 256);
+    const int64_t fwd_end = o;
+    L->grad = fwd0;     // backward reuses the forward-only region
+    const int64_t bwd_end = align_up(fwd0 + (int64_t)P * GRAD_F * 4, 256);
+    L->total = fwd_end > bwd_end ? fwd_end : bwd_end;
+}
+
+// ---- launchers (one per .hip translation unit) -------------------------------------------------
+int launch_preprocess_fwd(const ViewDev &v, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          const float *rotations, const float *transmat_precomp, StateView st,
+                          ScratchView sc, int32_t *radii, hipStream_t s);
+int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s);
+int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float *out_allmap,
+                         hipStream_t s);
+int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const float *dL_dcolor,
+                         const float *dL_dallmap, hipStream_t s);
+int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *scales, const float *rotations,
+                          const float *transmat_precomp, const int32_t *radii, StateView st,
+                          ScratchView sc, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
+                          float *dL_dcolors, float *dL_dopacities, float *dL_dscales,
+                          float *dL_drotations, float *dL_dtransmat, hipStream_t s);
+int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present,
+                        hipStream_t s);
+
+void l2d_set_hip_error(hipError_t e);
+
+// optional event bracketing of a launch (see lara2dgs_profile_enable)
+struct L2dProfScope {
+    int slot;
+    hipStream_t s;
+    L2dProfScope(const char *name, hipStream_t stream);
+    ~L2dProfScope();
+};
+#define L2D_PROF(name, stream) L2dProfScope prof_scope__(name, stream)
+#define L2D_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) {                            \
+            l2d_set_hip_error(e__);                         \
+            return LARA2DGS_E_LAUNCH;                       \
+        }                                                   \
+    } while (0)

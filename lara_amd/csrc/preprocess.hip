@@ -1,0 +1,487 @@
+// preprocess.hip -- per-surfel stages of the 2DGS rasteriser for gfx950 (forward + backward).
+//
+// Compiled with -ffp-contract=off: the INTEGER results of this stage (radius, tile rectangle,
+// tiles touched, depth key bits) must be bit-identical to the CPU oracle's, so the fp32 operation
+// order below is part of the contract and no FMA contraction is allowed.  The stage is a pure
+// stream over P surfels (88 B in, 80 B + 12 B out per surfel) -> HBM-bound.
+//
+// Replaces the reference's (absent) `preprocessCUDA` forward/backward; behaviour restated from the
+// published 2DGS rasteriser, call-site contract at lightning/renderer_2dgs.py:209-218.
+#include "common.h"
+
+namespace {
+
+__device__ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f,
+                                           0.31539156525252005f, -1.0925484305920792f,
+                                           0.5462742152960396f};
+__device__ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
+                                           -0.4570457994644658f, 0.3731763325901154f,
+                                           -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f};
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+struct Pm43 { float m[4][3]; };
+
+// projmatrix (row-vector convention) times ndc->pixel:  pixel = ((ndc + 1) * W - 1) / 2
+__device__ __forceinline__ Pm43 build_Pm(const ViewDev &v) {
+    Pm43 r;
+    const float hw = (float)v.W / 2.0f, hh = (float)v.H / 2.0f;
+    const float cw = (float)(v.W - 1) / 2.0f, ch = (float)(v.H - 1) / 2.0f;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const float r0 = v.projmatrix[4 * a + 0], r1 = v.projmatrix[4 * a + 1], r3 = v.projmatrix[4 * a + 3];
+        r.m[a][0] = r0 * hw + r3 * cw;
+        r.m[a][1] = r1 * hh + r3 * ch;
+        r.m[a][2] = r3;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void point4x3(const float *m, const float p[3], float o[3]) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void vec4x3(const float *m, const float p[3], float o[3]) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2];
+}
+__device__ __forceinline__ void vec4x3T(const float *m, const float p[3], float o[3]) {
+    o[0] = m[0] * p[0] + m[1] * p[1] + m[2] * p[2];
+    o[1] = m[4] * p[0] + m[5] * p[1] + m[6] * p[2];
+    o[2] = m[8] * p[0] + m[9] * p[1] + m[10] * p[2];
+}
+
+// R[r][c] from quaternion (w,x,y,z)
+__device__ __forceinline__ void quat_to_rotmat(const float4 q, float R[3][3], float n[4]) {
+    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const float s = 1.0f / sqrtf(n2);
+    const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
+    n[0] = w; n[1] = x; n[2] = y; n[3] = z;
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[1][0] = 2.f * (x * y + w * z);
+    R[2][0] = 2.f * (x * z - w * y);
+    R[0][1] = 2.f * (x * y - w * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[2][1] = 2.f * (y * z + w * x);
+    R[0][2] = 2.f * (x * z + w * y);
+    R[1][2] = 2.f * (y * z - w * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// T(i,j) = sum_a Mrow_i[a] Pm[a][j];  rows: u axis, v axis, centre;  cols: x*w, y*w, w
+__device__ __forceinline__ void compute_transmat(const ViewDev &v, const Pm43 &Pm, const float p[3],
+                                                 const float2 scale, const float4 rot,
+                                                 float Tm[3][3], float normal[3], float R[3][3],
+                                                 float qn[4]) {
+    quat_to_rotmat(rot, R, qn);
+    const float sx = v.scale_modifier * scale.x, sy = v.scale_modifier * scale.y;
+    const float L0[3] = {R[0][0] * sx, R[1][0] * sx, R[2][0] * sx};
+    const float L1[3] = {R[0][1] * sy, R[1][1] * sy, R[2][1] * sy};
+    const float L2[3] = {R[0][2], R[1][2], R[2][2]};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        Tm[0][j] = L0[0] * Pm.m[0][j] + L0[1] * Pm.m[1][j] + L0[2] * Pm.m[2][j];
+        Tm[1][j] = L1[0] * Pm.m[0][j] + L1[1] * Pm.m[1][j] + L1[2] * Pm.m[2][j];
+        Tm[2][j] = p[0] * Pm.m[0][j] + p[1] * Pm.m[1][j] + p[2] * Pm.m[2][j] + Pm.m[3][j];
+    }
+    vec4x3(v.viewmatrix, L2, normal);
+}
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+template <int DEG>
+__device__ __forceinline__ float sh_channel(const float *s, float x, float y, float z) {
+    // s[k] = coefficient k of this channel
+    float r = SH_C0 * s[0];
+    if (DEG > 0) {
+        r = r - SH_C1 * y * s[1] + SH_C1 * z * s[2] - SH_C1 * x * s[3];
+        if (DEG > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            r = r + kSH_C2[0] * xy * s[4] + kSH_C2[1] * yz * s[5] +
+                kSH_C2[2] * (2.0f * zz - xx - yy) * s[6] + kSH_C2[3] * xz * s[7] +
+                kSH_C2[4] * (xx - yy) * s[8];
+            if (DEG > 2) {
+                r = r + kSH_C3[0] * y * (3.0f * xx - yy) * s[9] + kSH_C3[1] * xy * z * s[10] +
+                    kSH_C3[2] * y * (4.0f * zz - xx - yy) * s[11] +
+                    kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s[12] +
+                    kSH_C3[4] * x * (4.0f * zz - xx - yy) * s[13] +
+                    kSH_C3[5] * z * (xx - yy) * s[14] + kSH_C3[6] * x * (xx - 3.0f * yy) * s[15];
+            }
+        }
+    }
+    return r + 0.5f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: one thread per surfel
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
+                      const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
+                      const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
+                      const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
+                      ushort4 *__restrict__ rect_out, uint32_t *__restrict__ tile_count,
+                      int32_t *__restrict__ radii) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= v.P) return;
+    radii[idx] = 0;
+    rect_out[idx] = make_ushort4(0, 0, 0, 0);
+
+    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    float p_view[3];
+    point4x3(v.viewmatrix, p, p_view);
+    if (p_view[2] <= 0.2f) return;
+
+    const Pm43 Pm = build_Pm(v);
+    float Tm[3][3], normal[3];
+    if (transmat_precomp == nullptr) {
+        float R[3][3], qn[4];
+        compute_transmat(v, Pm, p, scales[idx], rotations[idx], Tm, normal, R, qn);
+    } else {
+        const float *tp = transmat_precomp + 9 * (size_t)idx;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) Tm[i][j] = tp[3 * j + i];
+        normal[0] = 0.f; normal[1] = 0.f; normal[2] = 1.f;
+    }
+    const float T0[3] = {Tm[0][0], Tm[1][0], Tm[2][0]};
+    const float T1[3] = {Tm[0][1], Tm[1][1], Tm[2][1]};
+    const float T3[3] = {Tm[0][2], Tm[1][2], Tm[2][2]};
+    const float cosv = -(p_view[0] * normal[0] + p_view[1] * normal[1] + p_view[2] * normal[2]);
+    if (cosv == 0.0f) return;
+    const float mult = cosv > 0.0f ? 1.0f : -1.0f;
+    normal[0] *= mult; normal[1] *= mult; normal[2] *= mult;
+
+    // 3-sigma bounding box of the projected surfel
+    const float t[3] = {CUTOFF * CUTOFF, CUTOFF * CUTOFF, -1.0f};
+    const float distance = T3[0] * T3[0] * t[0] + T3[1] * T3[1] * t[1] + T3[2] * T3[2] * t[2];
+    if (distance == 0.0f) return;
+    const float inv = 1.0f / distance;
+    const float f[3] = {inv * t[0], inv * t[1], inv * t[2]};
+    const float ptx = f[0] * T0[0] * T3[0] + f[1] * T0[1] * T3[1] + f[2] * T0[2] * T3[2];
+    const float pty = f[0] * T1[0] * T3[0] + f[1] * T1[1] * T3[1] + f[2] * T1[2] * T3[2];
+    const float t0 = f[0] * T0[0] * T0[0] + f[1] * T0[1] * T0[1] + f[2] * T0[2] * T0[2];
+    const float t1 = f[0] * T1[0] * T1[0] + f[1] * T1[1] * T1[1] + f[2] * T1[2] * T1[2];
+    const float h0 = ptx * ptx - t0, h1 = pty * pty - t1;
+    const float ext0 = sqrtf(fmaxf(1e-4f, h0)), ext1 = sqrtf(fmaxf(1e-4f, h1));
+    const float radius = ceilf(fmaxf(fmaxf(ext0, ext1), CUTOFF * FILTER_SIZE));
+    const int max_radius = (int)radius;  // v_cvt_i32_f32: saturating, NaN -> 0 (as the oracle)
+    const int rx0 = imin(v.gx, imax(0, (int)((ptx - max_radius) / TILE)));
+    const int ry0 = imin(v.gy, imax(0, (int)((pty - max_radius) / TILE)));
+    const int rx1 = imin(v.gx, imax(0, (int)((ptx + max_radius + TILE - 1) / TILE)));
+    const int ry1 = imin(v.gy, imax(0, (int)((pty + max_radius + TILE - 1) / TILE)));
+    if ((uint32_t)(rx1 - rx0) * (uint32_t)(ry1 - ry0) == 0) return;
+
+    float rgb[3];
+    uint32_t clamp_bits = 0;
+    if (colors_precomp == nullptr) {
+        float dir[3] = {p[0] - v.campos[0], p[1] - v.campos[1], p[2] - v.campos[2]};
+        const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        const float x = dir[0] / len, y = dir[1] / len, z = dir[2] / len;
+        const float *sh = shs + (size_t)idx * v.M * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float s[(DEG + 1) * (DEG + 1)];
+#pragma unroll
+            for (int k = 0; k < (DEG + 1) * (DEG + 1); k++) s[k] = sh[3 * k + ch];
+            const float r = sh_channel<DEG>(s, x, y, z);
+            if (r < 0.0f) clamp_bits |= 1u << ch;
+            rgb[ch] = fmaxf(r, 0.0f);
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) rgb[ch] = colors_precomp[3 * (size_t)idx + ch];
+    }
+
+    float4 *g = geom + (size_t)idx * 5;
+    g[0] = make_float4(T0[0], T0[1], T0[2], T1[0]);
+    g[1] = make_float4(T1[1], T1[2], T3[0], T3[1]);
+    g[2] = make_float4(T3[2], ptx, pty, opacities[idx]);
+    g[3] = make_float4(normal[0], normal[1], normal[2], p_view[2]);
+    g[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
+    radii[idx] = max_radius;
+    rect_out[idx] = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
+                                 (unsigned short)ry1);
+    // per-tile population count (binning pass 1); relaxed device-scope adds, no return value
+    for (int y = ry0; y < ry1; y++)
+        for (int x = rx0; x < rx1; x++)
+            __hip_atomic_fetch_add(&tile_count[y * v.gx + x], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float *__restrict__ means3D, const float *__restrict__ viewmatrix,
+                    uint8_t *__restrict__ present) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    float pv[3];
+    point4x3(viewmatrix, p, pv);
+    present[idx] = pv[2] > 0.2f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: one thread per surfel; reads the tile-reduced accumulators of the composite backward
+//   grad[idx][0..8]  dL/dT (Tu,Tv,Tw)   [9..10] dL/dmean2D   [11..13] dL/dnormal
+//   grad[idx][14]    dL/dopacity        [15..17] dL/drgb
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
+                      const float *__restrict__ colors_precomp, const float2 *__restrict__ scales,
+                      const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
+                      const int32_t *__restrict__ radii, const float4 *__restrict__ geom,
+                      const float4 *__restrict__ grad, float *__restrict__ dL_dmeans3D,
+                      float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
+                      float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
+                      float2 *__restrict__ dL_dscales, float4 *__restrict__ dL_drots,
+                      float *__restrict__ dL_dtransmat) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= v.P) return;
+    const bool visible = radii[idx] > 0;
+
+    float gacc[GRAD_F];
+    if (visible) {
+#pragma unroll
+        for (int k = 0; k < GRAD_F / 4; k++) {
+            const float4 q = grad[(size_t)idx * (GRAD_F / 4) + k];
+            gacc[4 * k] = q.x; gacc[4 * k + 1] = q.y; gacc[4 * k + 2] = q.z; gacc[4 * k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < GRAD_F; k++) gacc[k] = 0.f;
+    }
+    dL_dopacities[idx] = gacc[14];
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float2 dscale = make_float2(0.f, 0.f);
+    float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dT[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) dT[k] = gacc[k];
+    float m2out[3] = {0.f, 0.f, 0.f};
+
+    if (visible) {
+        const float4 *g = geom + (size_t)idx * 5;
+        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g4 = g[4];
+        const float T0[3] = {g0.x, g0.y, g0.z};
+        const float T1[3] = {g0.w, g1.x, g1.y};
+        const float T3[3] = {g1.z, g1.w, g2.x};
+        const float m2x = gacc[9], m2y = gacc[10];
+        if (m2x != 0.0f || m2y != 0.0f) {
+            // through the box-centre formula: centre = sum(f * T0 * T3), f = t / dot(t, T3*T3)
+            const float t[3] = {9.0f, 9.0f, -1.0f};
+            const float d = t[0] * T3[0] * T3[0] + t[1] * T3[1] * T3[1] + t[2] * T3[2] * T3[2];
+            const float f[3] = {t[0] * (1.0f / d), t[1] * (1.0f / d), t[2] * (1.0f / d)};
+            float dL_dT3[3], dL_df[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                dT[0 + k] += m2x * f[k] * T3[k];
+                dT[3 + k] += m2y * f[k] * T3[k];
+                dL_dT3[k] = m2x * f[k] * T0[k] + m2y * f[k] * T1[k];
+                dL_df[k] = m2x * T0[k] * T3[k] + m2y * T1[k] * T3[k];
+            }
+            const float dL_dd = (dL_df[0] * f[0] + dL_df[1] * f[1] + dL_df[2] * f[2]) * (-1.0f / d);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                dL_dT3[k] += dL_dd * (t[k] * T3[k] * 2.0f);
+                dT[6 + k] += dL_dT3[k];
+            }
+        }
+        const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        if (transmat_precomp == nullptr) {
+            const Pm43 Pm = build_Pm(v);
+            float Tm[3][3], normal[3], R[3][3], qn[4];
+            const float2 sc = scales[idx];
+            compute_transmat(v, Pm, p, sc, rotations[idx], Tm, normal, R, qn);
+            float dM[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+                    dM[i][a] = dT[0 + i] * Pm.m[a][0] + dT[3 + i] * Pm.m[a][1] + dT[6 + i] * Pm.m[a][2];
+            const float dn[3] = {gacc[11], gacc[12], gacc[13]};
+            float dtn[3];
+            vec4x3T(v.viewmatrix, dn, dtn);
+            float p_view[3];
+            point4x3(v.viewmatrix, p, p_view);
+            const float cosv = -(p_view[0] * normal[0] + p_view[1] * normal[1] + p_view[2] * normal[2]);
+            const float mult = cosv > 0.0f ? 1.0f : -1.0f;
+            dtn[0] *= mult; dtn[1] *= mult; dtn[2] *= mult;
+            const float sx = v.scale_modifier * sc.x, sy = v.scale_modifier * sc.y;
+            float V[3][3];  // V[r][c] = dL/dR(r,c)
+#pragma unroll
+            for (int r = 0; r < 3; r++) { V[r][0] = dM[0][r] * sx; V[r][1] = dM[1][r] * sy; V[r][2] = dtn[r]; }
+            dscale.x = v.scale_modifier * (dM[0][0] * R[0][0] + dM[0][1] * R[1][0] + dM[0][2] * R[2][0]);
+            dscale.y = v.scale_modifier * (dM[1][0] * R[0][1] + dM[1][1] * R[1][1] + dM[1][2] * R[2][1]);
+            const float w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+            drot.x = 2.f * (x * (V[2][1] - V[1][2]) + y * (V[0][2] - V[2][0]) + z * (V[1][0] - V[0][1]));
+            drot.y = 2.f * (-2.f * x * (V[1][1] + V[2][2]) + y * (V[1][0] + V[0][1]) + z * (V[2][0] + V[0][2]) + w * (V[2][1] - V[1][2]));
+            drot.z = 2.f * (x * (V[1][0] + V[0][1]) - 2.f * y * (V[0][0] + V[2][2]) + z * (V[2][1] + V[1][2]) + w * (V[0][2] - V[2][0]));
+            drot.w = 2.f * (x * (V[2][0] + V[0][2]) + y * (V[2][1] + V[1][2]) - 2.f * z * (V[0][0] + V[1][1]) + w * (V[1][0] - V[0][1]));
+            dmean[0] = dM[2][0]; dmean[1] = dM[2][1]; dmean[2] = dM[2][2];
+        }
+
+        if (colors_precomp == nullptr) {
+            const float *sh = shs + (size_t)idx * v.M * 3;
+            float *dsh = dL_dshs + (size_t)idx * v.M * 3;
+            const float dir_o[3] = {p[0] - v.campos[0], p[1] - v.campos[1], p[2] - v.campos[2]};
+            const float len = sqrtf(dir_o[0] * dir_o[0] + dir_o[1] * dir_o[1] + dir_o[2] * dir_o[2]);
+            const float x = dir_o[0] / len, y = dir_o[1] / len, z = dir_o[2] / len;
+            const uint32_t clamp_bits = __float_as_uint(g4.w);
+            float ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float gg = gacc[15 + ch] * ((clamp_bits >> ch) & 1u ? 0.0f : 1.0f);
+                float dx = 0.f, dy = 0.f, dz = 0.f;
+                dsh[0 * 3 + ch] = SH_C0 * gg;
+                if (DEG > 0) {
+                    const float s1 = sh[1 * 3 + ch], s2 = sh[2 * 3 + ch], s3 = sh[3 * 3 + ch];
+                    dsh[1 * 3 + ch] = -SH_C1 * y * gg;
+                    dsh[2 * 3 + ch] = SH_C1 * z * gg;
+                    dsh[3 * 3 + ch] = -SH_C1 * x * gg;
+                    dx = -SH_C1 * s3; dy = -SH_C1 * s1; dz = SH_C1 * s2;
+                    if (DEG > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        const float s4 = sh[4 * 3 + ch], s5 = sh[5 * 3 + ch], s6 = sh[6 * 3 + ch],
+                                    s7 = sh[7 * 3 + ch], s8 = sh[8 * 3 + ch];
+                        dsh[4 * 3 + ch] = kSH_C2[0] * xy * gg;
+                        dsh[5 * 3 + ch] = kSH_C2[1] * yz * gg;
+                        dsh[6 * 3 + ch] = kSH_C2[2] * (2.f * zz - xx - yy) * gg;
+                        dsh[7 * 3 + ch] = kSH_C2[3] * xz * gg;
+                        dsh[8 * 3 + ch] = kSH_C2[4] * (xx - yy) * gg;
+                        dx += kSH_C2[0] * y * s4 + kSH_C2[2] * 2.f * -x * s6 + kSH_C2[3] * z * s7 + kSH_C2[4] * 2.f * x * s8;
+                        dy += kSH_C2[0] * x * s4 + kSH_C2[1] * z * s5 + kSH_C2[2] * 2.f * -y * s6 + kSH_C2[4] * 2.f * -y * s8;
+                        dz += kSH_C2[1] * y * s5 + kSH_C2[2] * 2.f * 2.f * z * s6 + kSH_C2[3] * x * s7;
+                        if (DEG > 2) {
+                            const float s9 = sh[9 * 3 + ch], s10 = sh[10 * 3 + ch], s11 = sh[11 * 3 + ch],
+                                        s12 = sh[12 * 3 + ch], s13 = sh[13 * 3 + ch], s14 = sh[14 * 3 + ch],
+                                        s15 = sh[15 * 3 + ch];
+                            dsh[9 * 3 + ch] = kSH_C3[0] * y * (3.f * xx - yy) * gg;
+                            dsh[10 * 3 + ch] = kSH_C3[1] * xy * z * gg;
+                            dsh[11 * 3 + ch] = kSH_C3[2] * y * (4.f * zz - xx - yy) * gg;
+                            dsh[12 * 3 + ch] = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gg;
+                            dsh[13 * 3 + ch] = kSH_C3[4] * x * (4.f * zz - xx - yy) * gg;
+                            dsh[14 * 3 + ch] = kSH_C3[5] * z * (xx - yy) * gg;
+                            dsh[15 * 3 + ch] = kSH_C3[6] * x * (xx - 3.f * yy) * gg;
+                            dx += kSH_C3[0] * s9 * 3.f * 2.f * xy + kSH_C3[1] * s10 * yz +
+                                  kSH_C3[2] * s11 * -2.f * xy + kSH_C3[3] * s12 * -3.f * 2.f * xz +
+                                  kSH_C3[4] * s13 * (-3.f * xx + 4.f * zz - yy) +
+                                  kSH_C3[5] * s14 * 2.f * xz + kSH_C3[6] * s15 * 3.f * (xx - yy);
+                            dy += kSH_C3[0] * s9 * 3.f * (xx - yy) + kSH_C3[1] * s10 * xz +
+                                  kSH_C3[2] * s11 * (-3.f * yy + 4.f * zz - xx) +
+                                  kSH_C3[3] * s12 * -3.f * 2.f * yz + kSH_C3[4] * s13 * -2.f * xy +
+                                  kSH_C3[5] * s14 * -2.f * yz + kSH_C3[6] * s15 * -3.f * 2.f * xy;
+                            dz += kSH_C3[1] * s10 * xy + kSH_C3[2] * s11 * 4.f * 2.f * yz +
+                                  kSH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) +
+                                  kSH_C3[4] * s13 * 4.f * 2.f * xz + kSH_C3[5] * s14 * (xx - yy);
+                        }
+                    }
+                }
+                // coefficients above the active degree get zero gradient
+                for (int k = (DEG + 1) * (DEG + 1); k < v.M; k++) dsh[k * 3 + ch] = 0.f;
+                ddir[0] += dx * gg; ddir[1] += dy * gg; ddir[2] += dz * gg;
+            }
+            const float sum2 = dir_o[0] * dir_o[0] + dir_o[1] * dir_o[1] + dir_o[2] * dir_o[2];
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((sum2 - dir_o[0] * dir_o[0]) * ddir[0] - dir_o[1] * dir_o[0] * ddir[1] - dir_o[2] * dir_o[0] * ddir[2]) * invsum32;
+            dmean[1] += (-dir_o[0] * dir_o[1] * ddir[0] + (sum2 - dir_o[1] * dir_o[1]) * ddir[1] - dir_o[2] * dir_o[1] * ddir[2]) * invsum32;
+            dmean[2] += (-dir_o[0] * dir_o[2] * ddir[0] - dir_o[1] * dir_o[2] * ddir[1] + (sum2 - dir_o[2] * dir_o[2]) * ddir[2]) * invsum32;
+        }
+        // screen-space gradient handed back for densification heuristics (published behaviour)
+        const float depth = g2.x;
+        m2out[0] = gacc[2] * depth * 0.5f * (float)v.W;
+        m2out[1] = gacc[5] * depth * 0.5f * (float)v.H;
+    } else if (colors_precomp == nullptr) {
+        float *dsh = dL_dshs + (size_t)idx * v.M * 3;
+        for (int k = 0; k < v.M * 3; k++) dsh[k] = 0.f;
+    }
+
+    dL_dmeans3D[3 * idx + 0] = dmean[0];
+    dL_dmeans3D[3 * idx + 1] = dmean[1];
+    dL_dmeans3D[3 * idx + 2] = dmean[2];
+    dL_dmeans2D[3 * idx + 0] = m2out[0];
+    dL_dmeans2D[3 * idx + 1] = m2out[1];
+    dL_dmeans2D[3 * idx + 2] = 0.f;
+    if (transmat_precomp == nullptr) {
+        dL_dscales[idx] = dscale;
+        dL_drots[idx] = drot;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) dL_dtransmat[9 * (size_t)idx + k] = visible ? dT[k] : 0.f;
+    }
+    if (colors_precomp != nullptr) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * (size_t)idx + ch] = gacc[15 + ch];
+    }
+}
+
+}  // namespace
+
+int launch_preprocess_fwd(const ViewDev &v, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          const float *rotations, const float *transmat_precomp, StateView st,
+                          ScratchView sc, int32_t *radii, hipStream_t s) {
+    if (v.P == 0) return LARA2DGS_OK;
+    const dim3 grid((v.P + 255) / 256), block(256);
+#define L2D_PRE(DEG)                                                                             \
+    hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, v, means3D, shs,           \
+                       colors_precomp, opacities, (const float2 *)scales,                        \
+                       (const float4 *)rotations, transmat_precomp, st.geom, sc.rect,            \
+                       sc.tile_count, radii)
+    {
+        L2D_PROF("preprocess_fwd", s);
+        switch (colors_precomp ? 0 : v.deg) {
+        case 0: L2D_PRE(0); break;
+        case 1: L2D_PRE(1); break;
+        case 2: L2D_PRE(2); break;
+        default: L2D_PRE(3); break;
+        }
+    }
+#undef L2D_PRE
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *scales, const float *rotations,
+                          const float *transmat_precomp, const int32_t *radii, StateView st,
+                          ScratchView sc, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
+                          float *dL_dcolors, float *dL_dopacities, float *dL_dscales,
+                          float *dL_drotations, float *dL_dtransmat, hipStream_t s) {
+    if (v.P == 0) return LARA2DGS_OK;
+    const dim3 grid((v.P + 255) / 256), block(256);
+#define L2D_PREB(DEG)                                                                            \
+    hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, v, means3D, shs,           \
+                       colors_precomp, (const float2 *)scales, (const float4 *)rotations,        \
+                       transmat_precomp, radii, (const float4 *)st.geom, (const float4 *)sc.grad, \
+                       dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities,             \
+                       (float2 *)dL_dscales, (float4 *)dL_drotations, dL_dtransmat)
+    {
+        L2D_PROF("preprocess_bwd", s);
+        switch (colors_precomp ? 0 : v.deg) {
+        case 0: L2D_PREB(0); break;
+        case 1: L2D_PREB(1); break;
+        case 2: L2D_PREB(2); break;
+        default: L2D_PREB(3); break;
+        }
+    }
+#undef L2D_PREB
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present,
+                        hipStream_t s) {
+    if (P == 0) return LARA2DGS_OK;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D,
+                       viewmatrix, present);
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}

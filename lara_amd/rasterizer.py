@@ -1,0 +1,429 @@
+"""The reference's rasteriser operator API, backed by hand-written gfx950 kernels.
+
+Drop-in for the Python surface of ``diff_surfel_rasterization`` that LaRa imports
+(lightning/renderer_2dgs.py:7-10) and calls (renderer_2dgs.py:124-139, 209-218):
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg,
+                                  scale_modifier, viewmatrix, projmatrix, sh_degree, campos,
+                                  prefiltered, debug)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None,
+                                        colors_precomp=None, scales=None, rotations=None,
+                                        cov3D_precomp=None) -> (color[3,H,W], radii[P], allmap[7,H,W])
+
+Same names, argument meaning, return arity and error behaviour; differentiable w.r.t.
+means3D / shs (or colors_precomp) / opacities / scales / rotations (or cov3D_precomp, which in the
+2DGS rasteriser is the precomputed 3x3 splat-to-pixel matrix), and hands a gradient to ``means2D``.
+
+The host side is a thin ctypes binding of the C ABI in ``include/lara2dgs.h``: PyTorch only owns
+memory and the stream.  There is no CPU path and no fallback: without ``liblara2dgs.so`` or with
+non-GPU tensors the operator raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
+ABI_VERSION = 1
+
+
+class _View(ctypes.Structure):
+    _fields_ = [
+        ("P", ctypes.c_int32), ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
+        ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+        ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+        ("capacity", ctypes.c_int64),
+        ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+        ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p),
+    ]
+
+
+class StateLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ("header", "geom", "point_list", "ranges", "final_T", "n_contrib", "total")]
+
+
+_lib = None
+
+
+def load_library():
+    """Load liblara2dgs.so (built by ``__graft_entry__.build()`` / ``make -C lara_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"lara_amd: HIP library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C lara_amd/csrc`. "
+            "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    lib.lara2dgs_abi_version.restype = ctypes.c_int
+    lib.lara2dgs_error_string.restype = ctypes.c_char_p
+    lib.lara2dgs_error_string.argtypes = [ctypes.c_int]
+    lib.lara2dgs_last_hip_error.restype = ctypes.c_int
+    lib.lara2dgs_state_bytes.restype = i64
+    lib.lara2dgs_state_bytes.argtypes = [i32, i32, i32, i64]
+    lib.lara2dgs_scratch_bytes.restype = i64
+    lib.lara2dgs_scratch_bytes.argtypes = [i32, i32, i32, i64]
+    lib.lara2dgs_get_state_layout.restype = ctypes.c_int
+    lib.lara2dgs_get_state_layout.argtypes = [i32, i32, i32, i64, ctypes.POINTER(StateLayout)]
+    lib.lara2dgs_forward.restype = ctypes.c_int
+    lib.lara2dgs_forward.argtypes = [ctypes.POINTER(_View)] + [vp] * 13
+    lib.lara2dgs_backward.restype = ctypes.c_int
+    lib.lara2dgs_backward.argtypes = [ctypes.POINTER(_View)] + [vp] * 20
+    lib.lara2dgs_mark_visible.restype = ctypes.c_int
+    lib.lara2dgs_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.lara2dgs_profile_enable.restype = ctypes.c_int
+    lib.lara2dgs_profile_enable.argtypes = [ctypes.c_int]
+    lib.lara2dgs_profile_collect.restype = ctypes.c_int
+    lib.lara2dgs_profile_collect.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    if lib.lara2dgs_abi_version() != ABI_VERSION:
+        raise RuntimeError("lara_amd: liblara2dgs.so ABI version mismatch; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        lib = load_library()
+        raise RuntimeError(f"lara_amd: {what} failed: {lib.lara2dgs_error_string(rc).decode()} "
+                           f"(hipError {lib.lara2dgs_last_hip_error()})")
+
+
+# ---------------------------------------------------------------------------------------------
+# workspace policy
+# ---------------------------------------------------------------------------------------------
+def _dup_factor() -> int:
+    return int(os.environ.get("LARA2DGS_DUP_FACTOR", "16"))
+
+
+def binning_capacity(P: int) -> int:
+    """(tile, surfel) pairs the buffers are sized for.  The real count is data dependent and
+    stays on the device (no host sync per view); LaRa's init distribution needs ~3 P, a 288 GB
+    part can afford 16 P (~36 B per pair) without thinking about it.  Override with
+    LARA2DGS_DUP_FACTOR."""
+    return min(max(P * _dup_factor(), 1 << 16), 0xFFFFFFFF)
+
+
+_scratch = {}   # (device index, stream id) -> uint8 tensor
+_pending = []   # [(event, pinned header, capacity)] of forwards not yet checked for overflow
+
+
+def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def _raise_overflow(hdr, cap):
+    raise RuntimeError(
+        f"lara_amd: binning capacity exceeded: the view produced {int(hdr[0])} (tile, surfel) pairs "
+        f"but buffers were sized for {cap}; its outputs were poisoned with NaN. Raise "
+        "LARA2DGS_DUP_FACTOR (pairs per surfel, default 16).")
+
+
+def check_pending(block: bool = False):
+    """Overflow check of earlier forwards, without stalling the stream unless ``block``."""
+    global _pending
+    keep = []
+    for ev, hdr, cap in _pending:
+        if block:
+            ev.synchronize()
+        if block or ev.query():
+            if int(hdr[1]) != 0:
+                _pending = []
+                _raise_overflow(hdr, cap)
+        else:
+            keep.append((ev, hdr, cap))
+    _pending = keep
+
+
+def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError(f"lara_amd: `{name}` is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"lara_amd: `{name}` must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """The 12-field settings record built at lightning/renderer_2dgs.py:124-137."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _make_view(rs: GaussianRasterizationSettings, P: int, M: int, cap: int, device):
+    bg = _prep(rs.bg, "bg", device)
+    vm = _prep(rs.viewmatrix, "viewmatrix", device)
+    pm = _prep(rs.projmatrix, "projmatrix", device)
+    cp = _prep(rs.campos, "campos", device)
+    if bg is None or vm is None or pm is None or cp is None:
+        raise RuntimeError("lara_amd: bg / viewmatrix / projmatrix / campos must be non-empty tensors")
+    if bg.numel() != 3 or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
+        raise RuntimeError("lara_amd: bg[3], viewmatrix[4,4], projmatrix[4,4], campos[3] expected")
+    v = _View(P, int(rs.sh_degree), M, int(rs.image_height), int(rs.image_width),
+              float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
+              int(bool(rs.prefiltered)), int(bool(rs.debug)), cap,
+              bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
+    return v, (bg, vm, pm, cp)
+
+
+def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+    """Validate, allocate, enqueue the forward.  Returns everything backward / the tests need."""
+    lib = load_library()
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+    device = means3D.device
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    means3D_c = _prep(means3D, "means3D", device)
+    sh_c = _prep(sh, "shs", device)
+    col_c = _prep(colors_precomp, "colors_precomp", device)
+    opa_c = _prep(opacities, "opacities", device)
+    sc_c = _prep(scales, "scales", device)
+    rot_c = _prep(rotations, "rotations", device)
+    tm_c = _prep(cov3Ds_precomp, "cov3D_precomp", device)
+    M = 0
+    if sh_c is not None:
+        if sh_c.dim() != 3 or sh_c.shape[0] != P or sh_c.shape[2] != 3:
+            raise RuntimeError("shs must have dimensions (num_points, num_coeffs, 3)")
+        M = sh_c.shape[1]
+        if M < (int(rs.sh_degree) + 1) ** 2:
+            raise RuntimeError("shs holds fewer coefficients than sh_degree needs")
+    for t, n, k in ((opa_c, "opacities", 1), (sc_c, "scales", 2), (rot_c, "rotations", 4),
+                    (tm_c, "cov3D_precomp", 9), (col_c, "colors_precomp", 3)):
+        if t is not None and t.numel() != P * k:
+            raise RuntimeError(f"{n} must hold {k} value(s) per point")
+
+    check_pending()
+    cap = binning_capacity(P)
+    with torch.cuda.device(device):
+        view, keep = _make_view(rs, P, M, cap, device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((P,), dtype=torch.int32, device=device)
+        state = torch.empty((lib.lara2dgs_state_bytes(P, H, W, cap),), dtype=torch.uint8, device=device)
+        scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(P, H, W, cap))
+        rc = lib.lara2dgs_forward(ctypes.byref(view), _ptr(means3D_c), _ptr(sh_c), _ptr(col_c),
+                                  _ptr(opa_c), _ptr(sc_c), _ptr(rot_c), _ptr(tm_c),
+                                  color.data_ptr(), allmap.data_ptr(), radii.data_ptr(),
+                                  state.data_ptr(), scratch.data_ptr(), stream)
+        _check(rc, "lara2dgs_forward")
+        # lazy overflow check: 64-byte header -> pinned host memory, no stall
+        hdr = torch.empty((16,), dtype=torch.int32, pin_memory=True)
+        hdr.copy_(state[:64].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if rs.debug:
+            ev.synchronize()
+            if int(hdr[1]) != 0:
+                _raise_overflow(hdr, cap)
+        else:
+            _pending.append((ev, hdr, cap))
+    return dict(color=color, radii=radii, allmap=allmap, state=state, cap=cap, M=M, ev=ev, hdr=hdr,
+                keep=keep, inputs=(means3D_c, sh_c, col_c, sc_c, rot_c, tm_c))
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        r = _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs)
+        color, radii, allmap, state, cap, M = r["color"], r["radii"], r["allmap"], r["state"], r["cap"], r["M"]
+        ev, hdr, keep = r["ev"], r["hdr"], r["keep"]
+        means3D_c, sh_c, col_c, sc_c, rot_c, tm_c = r["inputs"]
+
+        ctx.raster_settings = rs
+        ctx.cap = cap
+        ctx.M = M
+        ctx.hdr = (ev, hdr)
+        ctx.flags = (sh_c is not None, col_c is not None, sc_c is not None, tm_c is not None)
+        ctx.shapes = (sh.shape if sh_c is not None else None, opacities.shape)
+        empty = means3D_c.new_empty(0)
+        ctx.save_for_backward(means3D_c,
+                              sh_c if sh_c is not None else empty,
+                              col_c if col_c is not None else empty,
+                              sc_c if sc_c is not None else empty,
+                              rot_c if rot_c is not None else empty,
+                              tm_c if tm_c is not None else empty,
+                              radii, state, *keep)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, allmap
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_allmap):
+        lib = load_library()
+        (means3D, sh, col, sc, rot, tm, radii, state, bg, vm, pm, cp) = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_tm = ctx.flags
+        rs = ctx.raster_settings
+        device = means3D.device
+        P = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        ev, hdr = ctx.hdr
+        ev.synchronize()  # long done by the time autograd gets here
+        if int(hdr[1]) != 0:
+            _raise_overflow(hdr, ctx.cap)
+        with torch.cuda.device(device):
+            if grad_color is None:
+                grad_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
+            if grad_allmap is None:
+                grad_allmap = torch.zeros((7, H, W), dtype=torch.float32, device=device)
+            grad_color = _prep(grad_color, "grad_color", device)
+            grad_allmap = _prep(grad_allmap, "grad_allmap", device)
+            view = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
+                         float(rs.scale_modifier), int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                         ctx.cap, bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
+            new = lambda *s: torch.empty(s, dtype=torch.float32, device=device)
+            g_means3D = new(P, 3)
+            g_means2D = new(P, 3)
+            g_opac = new(P, 1)
+            g_sh = new(P, ctx.M, 3) if has_sh else None
+            g_col = new(P, 3) if has_col else None
+            g_sc = new(P, 2) if has_sr else None
+            g_rot = new(P, 4) if has_sr else None
+            g_tm = new(P, 9) if has_tm else None
+            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(P, H, W, ctx.cap))
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = lib.lara2dgs_backward(
+                ctypes.byref(view), _ptr(means3D), _ptr(sh if has_sh else None),
+                _ptr(col if has_col else None), _ptr(sc if has_sr else None),
+                _ptr(rot if has_sr else None), _ptr(tm if has_tm else None), radii.data_ptr(),
+                grad_color.data_ptr(), grad_allmap.data_ptr(), state.data_ptr(), scratch.data_ptr(),
+                g_means3D.data_ptr(), g_means2D.data_ptr(), _ptr(g_sh), _ptr(g_col),
+                g_opac.data_ptr(), _ptr(g_sc), _ptr(g_rot), _ptr(g_tm), stream)
+            _check(rc, "lara2dgs_backward")
+        if has_sh and ctx.shapes[0] is not None:
+            g_sh = g_sh.view(ctx.shapes[0])
+        g_opac = g_opac.view(ctx.shapes[1])
+        # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
+        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_sc, g_rot, g_tm, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """Callable built at lightning/renderer_2dgs.py:139 and invoked at :209-218."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Boolean mask of points in front of the near plane (view-space z > 0.2)."""
+        lib = load_library()
+        rs = self.raster_settings
+        with torch.no_grad():
+            if not positions.is_cuda:
+                raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device")
+            device = positions.device
+            pos = _prep(positions, "positions", device)
+            P = positions.shape[0]
+            present = torch.zeros((P,), dtype=torch.uint8, device=device)
+            vm = _prep(rs.viewmatrix, "viewmatrix", device)
+            pm = _prep(rs.projmatrix, "projmatrix", device)
+            with torch.cuda.device(device):
+                rc = lib.lara2dgs_mark_visible(P, _ptr(pos), vm.data_ptr(), pm.data_ptr(),
+                                               present.data_ptr(),
+                                               torch.cuda.current_stream(device).cuda_stream)
+            _check(rc, "lara2dgs_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                   rotations, cov3D_precomp, raster_settings)
+
+
+# ---------------------------------------------------------------------------------------------
+# introspection used by the parity tests and by bench.py (not part of the reference surface)
+# ---------------------------------------------------------------------------------------------
+def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
+    """Typed views into a forward's ``state`` buffer (the integer parity surface)."""
+    lib = load_library()
+    L = StateLayout()
+    _check(lib.lara2dgs_get_state_layout(P, H, W, cap, ctypes.byref(L)), "lara2dgs_get_state_layout")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def sec(off, nbytes, dtype, shape):
+        return state[off:off + nbytes].view(dtype).view(shape)
+
+    hdr = sec(L.header, 64, torch.int32, (16,))
+    return dict(
+        header=hdr,
+        geom=sec(L.geom, P * 80, torch.float32, (P, 20)),
+        point_list=sec(L.point_list, cap * 4, torch.int32, (cap,)),
+        ranges=sec(L.ranges, tiles * 8, torch.int32, (tiles, 2)),
+        final_T=sec(L.final_T, 3 * H * W * 4, torch.float32, (3, H, W)),
+        n_contrib=sec(L.n_contrib, 2 * H * W * 4, torch.int32, (2, H, W)),
+    )
+
+
+def forward_with_state(raster_settings, means3D, opacities, shs=None, colors_precomp=None,
+                       scales=None, rotations=None, cov3D_precomp=None) -> dict:
+    """Forward only, returning the saved ``state`` too: ``dict(color, radii, allmap, views, ...)``."""
+    with torch.no_grad():
+        r = _forward_impl(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                          raster_settings)
+    P = means3D.shape[0]
+    r["views"] = state_views(r["state"], P, int(raster_settings.image_height),
+                             int(raster_settings.image_width), r["cap"])
+    return r
+
+
+def profile_enable(on: bool = True):
+    """Bracket every kernel launch of this thread with HIP events (bench.py's roofline leg)."""
+    load_library().lara2dgs_profile_enable(int(on))
+
+
+def profile_collect(max_entries: int = 65536) -> list:
+    """[(kernel name, milliseconds)] since the last collect; synchronises the recorded events."""
+    lib = load_library()
+    names = ctypes.create_string_buffer(max_entries * 24)
+    ms = (ctypes.c_float * max_entries)()
+    n = lib.lara2dgs_profile_collect(names, len(names), ms, max_entries)
+    parts = names.raw.split(b"\0")
+    return [(parts[i].decode(), float(ms[i])) for i in range(n)]

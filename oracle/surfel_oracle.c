@@ -97,6 +97,15 @@ typedef struct {
 
 /* ---- small helpers ------------------------------------------------------- */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+/* float -> int as GPUs do it (cvt.rzi.s32 / v_cvt_i32_f32): saturating, NaN -> 0.  A plain C cast
+ * is undefined out of range (x86 yields INT_MIN), which would change tile rectangles of surfels
+ * whose projection blows up. */
+static inline int f2i_sat(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int)f;
+}
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 
@@ -182,10 +191,10 @@ static int compute_aabb(const float T0[3], const float T1[3], const float T3[3],
 }
 
 static void get_rect(const float p[2], int max_radius, int gx, int gy, uint32_t r[4]) {
-    r[0] = (uint32_t)imin(gx, imax(0, (int)((p[0] - max_radius) / BLOCK_X)));
-    r[1] = (uint32_t)imin(gy, imax(0, (int)((p[1] - max_radius) / BLOCK_Y)));
-    r[2] = (uint32_t)imin(gx, imax(0, (int)((p[0] + max_radius + BLOCK_X - 1) / BLOCK_X)));
-    r[3] = (uint32_t)imin(gy, imax(0, (int)((p[1] + max_radius + BLOCK_Y - 1) / BLOCK_Y)));
+    r[0] = (uint32_t)imin(gx, imax(0, f2i_sat((p[0] - max_radius) / BLOCK_X)));
+    r[1] = (uint32_t)imin(gy, imax(0, f2i_sat((p[1] - max_radius) / BLOCK_Y)));
+    r[2] = (uint32_t)imin(gx, imax(0, f2i_sat((p[0] + max_radius + BLOCK_X - 1) / BLOCK_X)));
+    r[3] = (uint32_t)imin(gy, imax(0, f2i_sat((p[1] + max_radius + BLOCK_Y - 1) / BLOCK_Y)));
 }
 
 static void sh_to_rgb(const OracleCfg *c, const float *pos, const float *sh, float rgb[3],
@@ -343,7 +352,7 @@ OracleState *oracle_forward(const OracleCfg *c, const float *means3D, const floa
         if (!compute_aabb(T0, T1, T3, CUTOFF, pt, ext)) continue;
         float radius = ceilf(fmaxf(fmaxf(ext[0], ext[1]), CUTOFF * FILTER_SIZE));
         uint32_t r[4];
-        get_rect(pt, (int)radius, gx, gy, r);
+        get_rect(pt, f2i_sat(radius), gx, gy, r);
         if ((r[2] - r[0]) * (r[3] - r[1]) == 0) continue;
 
         /* transMats are stored only for visible surfels that reach this point (upstream stores
@@ -359,7 +368,7 @@ OracleState *oracle_forward(const OracleCfg *c, const float *means3D, const floa
             for (int ch = 0; ch < 3; ch++) s->rgb[3 * idx + ch] = colors_precomp[3 * idx + ch];
         }
         s->depths[idx] = p_view[2];
-        s->radii[idx] = (int)radius;
+        s->radii[idx] = f2i_sat(radius);
         s->means2D[2 * idx] = pt[0]; s->means2D[2 * idx + 1] = pt[1];
         s->normal_opacity[4 * idx + 0] = normal[0];
         s->normal_opacity[4 * idx + 1] = normal[1];

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """liblara2dgs.so built in-tree (hipcc cross-compiles for gfx950 without a GPU)."""
+    import __graft_entry__ as g
+    from lara_amd import rasterizer
+    if not os.path.exists(rasterizer.LIB_PATH):
+        g.build()
+    return rasterizer.load_library()

@@ -1,0 +1,71 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol that
+include/lara2dgs.h declares.  No compute calls here (no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from lara_amd import rasterizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "lara2dgs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lara2dgs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_three_reference_entry_points():
+    names = declared_functions()
+    for must in ("lara2dgs_forward", "lara2dgs_backward", "lara2dgs_mark_visible"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for name in declared_functions():
+        assert hasattr(hip_lib, name), f"{name} declared in lara2dgs.h but not exported"
+    assert hip_lib.lara2dgs_abi_version() == rasterizer.ABI_VERSION
+
+
+def test_sizes_and_layout_are_consistent(hip_lib):
+    P, H, W = 524288, 512, 512
+    cap = rasterizer.binning_capacity(P)
+    L = rasterizer.StateLayout()
+    assert hip_lib.lara2dgs_get_state_layout(P, H, W, cap, ctypes.byref(L)) == 0
+    assert L.total == hip_lib.lara2dgs_state_bytes(P, H, W, cap)
+    offs = [L.header, L.geom, L.point_list, L.ranges, L.final_T, L.n_contrib, L.total]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert L.point_list - L.geom >= P * 80 and L.ranges - L.point_list >= cap * 4
+    assert hip_lib.lara2dgs_scratch_bytes(P, H, W, cap) >= cap * 8
+    assert hip_lib.lara2dgs_state_bytes(-1, H, W, cap) < 0
+
+
+def test_invalid_arguments_return_error_codes_not_crashes(hip_lib):
+    v = rasterizer._View()
+    v.P, v.image_height, v.image_width, v.sh_degree = 8, 16, 16, 7   # bad degree, null matrices
+    rc = hip_lib.lara2dgs_forward(ctypes.byref(v), *([None] * 13))
+    assert rc == -1 and hip_lib.lara2dgs_error_string(rc) == b"invalid argument"
+    assert hip_lib.lara2dgs_mark_visible(4, None, None, None, None, None) == -1
+
+
+def test_operator_refuses_cpu_tensors_and_has_no_fallback(hip_lib):
+    import torch
+    from tests.helpers import small_scene, raster_settings
+    from lara_amd import GaussianRasterizer
+    act, cams = small_scene(grid=4, size=32)
+    rs = raster_settings(cams[0], (1, 1, 1), device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        GaussianRasterizer(rs)(means3D=act["means3D"], means2D=None, opacities=act["opacities"],
+                               shs=act["shs"], scales=act["scales"], rotations=act["rotations"])
+
+
+def test_product_path_never_imports_the_oracle():
+    for pkg in ("lara_amd", "diff_surfel_rasterization"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                    assert "surfel_oracle" not in src, f

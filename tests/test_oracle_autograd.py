@@ -1,0 +1,67 @@
+"""The C oracle's forward and hand-derived backward against an independent fp64 autograd
+restatement (oracle/autograd_ref.py).  Small scenes; a few seconds each."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import autograd_ref
+from tests.helpers import oracle_view, run_oracle, small_scene, to_numpy
+
+
+def _compare(act, cam, bg, sh_degree=1, quirk_free=True, tol=2e-4):
+    v = oracle_view(cam, bg, sh_degree=sh_degree)
+    res = run_oracle(v, to_numpy(act))
+    inp = {k: torch.tensor(val.numpy(), dtype=torch.float64, requires_grad=True) for k, val in act.items()}
+    c, a = autograd_ref.render(v, inp["means3D"], inp["opacities"], inp["shs"], inp["scales"],
+                               inp["rotations"], res.ranges, res.point_list)
+    assert np.abs(c.detach().numpy() - res.color).max() < 2e-5
+    assert np.abs(a.detach().numpy() - res.allmap).max() < 5e-5
+    H, W = res.color.shape[1:]
+    g = torch.Generator().manual_seed(5)
+    dc = torch.randn(3, H, W, generator=g, dtype=torch.float64)
+    da = torch.randn(7, H, W, generator=g, dtype=torch.float64) * 0.3
+    ((c * dc).sum() + (a * da).sum()).backward()
+    gr = oracle.backward(res, dc.numpy(), da.numpy(), lowpass_depth_quirk=not quirk_free)
+    errs = {}
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        ref = inp[k].grad.numpy().reshape(gr[k].shape)
+        errs[k] = np.abs(ref - gr[k]).max() / (np.abs(ref).max() + 1e-30)
+        assert errs[k] < tol, f"{k}: {errs[k]:.2e}"
+    return res, errs
+
+
+def test_forward_and_backward_large_splats():
+    act, cams = small_scene(grid=8, size=64, seed=1, scale_boost=3.0, opacity_boost=2.0)
+    res, _ = _compare(act, cams[1], (1.0, 0.5, 0.2))
+    assert res.n_contrib[0].max() > 20
+
+
+def test_backward_with_low_pass_branch_and_sh3():
+    # sub-pixel surfels: most hits take the screen-space low-pass branch (mean2D gradient path)
+    act, cams = small_scene(grid=8, size=48, seed=2, scale_boost=0.2, opacity_boost=3.0, sh_coeffs=16)
+    _compare(act, cams[0], (0.1, 0.2, 0.3), sh_degree=3)
+
+
+def test_alpha_clamp_is_straight_through():
+    # opacities > 0.99 make min(0.99, o*G) active; published backward passes the gradient through
+    act, cams = small_scene(grid=6, size=48, seed=3, scale_boost=3.0, opacity_boost=12.0)
+    assert float(act["opacities"].max()) > 0.99
+    _compare(act, cams[2], (0.0, 0.0, 0.0))
+
+
+def test_published_low_pass_depth_quirk_differs_only_in_that_branch():
+    act, cams = small_scene(grid=8, size=48, seed=2, scale_boost=0.2, opacity_boost=3.0)
+    v = oracle_view(cams[0], (1, 1, 1))
+    res = run_oracle(v, to_numpy(act))
+    g = np.random.default_rng(0)
+    dc = g.normal(size=(3, 48, 48)); da = g.normal(size=(7, 48, 48))
+    a = oracle.backward(res, dc, da, lowpass_depth_quirk=True)
+    b = oracle.backward(res, dc, da, lowpass_depth_quirk=False)
+    # the quirk adds dL_dz * (s.x, s.y) to dL/dTw.xy only: colours, opacities and centres never see
+    # it (centres depend on the z column of dL/dT); tangent axes (scales, rotations) do
+    np.testing.assert_array_equal(a["shs"], b["shs"])
+    np.testing.assert_array_equal(a["opacities"], b["opacities"])
+    np.testing.assert_array_equal(a["means3D"], b["means3D"])
+    assert np.abs(a["scales"] - b["scales"]).max() > 0
+    assert np.abs(a["rotations"] - b["rotations"]).max() > 0
