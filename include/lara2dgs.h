@@ -17,7 +17,8 @@
  *     D2H copy of `num_rendered` once per view);
  *   - the caller owns every allocation: outputs, the `state` buffer that forward hands to
  *     backward (the reference's geomBuffer/binningBuffer/imgBuffer), and a transient `scratch`;
- *   - the library keeps no global state and is re-entrant across streams;
+ *   - the library keeps no global state (bar the optional profiling log) and is re-entrant
+ *     across streams;
  *   - functions return 0 on success or a negative LARA2DGS_E_* code; nothing throws.
  *   - binning capacity: the number of (tile, surfel) pairs is data dependent and only known on the
  *     device.  The caller passes `capacity`; if a view needs more, the kernels raise the
@@ -119,7 +120,7 @@ int lara2dgs_mark_visible(int32_t P, const float *means3D, const float *viewmatr
                           const float *projmatrix, uint8_t *present, void *stream);
 
 /* Optional per-kernel timing (bench.py's roofline leg; not part of the reference surface).
- * When enabled on the calling thread, every kernel the library launches is bracketed by HIP
+ * When enabled (process-wide), every kernel the library launches is bracketed by HIP
  * events recorded on the launch stream.  lara2dgs_profile_collect synchronises those events,
  * writes up to `max_entries` records (kernel name -> `names`, NUL-separated, at most `names_len`
  * bytes; duration in milliseconds -> `ms`), clears the log and returns the number written. */

@@ -7,13 +7,17 @@ static thread_local int g_last_hip_error = 0;
 void l2d_set_hip_error(hipError_t e) { g_last_hip_error = (int)e; }
 
 // ---- optional per-kernel timing --------------------------------------------------------------
+#include <atomic>
+#include <mutex>
 #include <vector>
 namespace {
+// Process-wide (PyTorch runs backward on its autograd thread, not on the caller's).
 struct ProfRec { const char *name; hipEvent_t a, b; };
-thread_local bool g_prof_on = false;
-thread_local std::vector<ProfRec> g_prof_log;
-thread_local std::vector<hipEvent_t> g_prof_pool;
-hipEvent_t prof_event() {
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_log;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {  // call with g_prof_mu held
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
@@ -22,14 +26,17 @@ hipEvent_t prof_event() {
 }  // namespace
 
 L2dProfScope::L2dProfScope(const char *name, hipStream_t stream) : slot(-1), s(stream) {
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{name, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, s);
     g_prof_log.push_back(r);
     slot = (int)g_prof_log.size() - 1;
 }
 L2dProfScope::~L2dProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof_log[slot].b, s);
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof_log.size()) (void)hipEventRecord(g_prof_log[slot].b, s);
 }
 
 namespace {
@@ -194,11 +201,12 @@ int lara2dgs_mark_visible(int32_t P, const float *means3D, const float *viewmatr
 }
 
 int lara2dgs_profile_enable(int on) {
-    g_prof_on = on != 0;
+    g_prof_on.store(on != 0);
     return LARA2DGS_OK;
 }
 
 int lara2dgs_profile_collect(char *names, int names_len, float *ms, int max_entries) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0, pos = 0;
     for (size_t i = 0; i < g_prof_log.size(); i++) {
         ProfRec &r = g_prof_log[i];

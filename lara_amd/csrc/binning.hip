@@ -73,23 +73,50 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__re
 }
 
 // ---- 3. scatter (depth bits, id) into the tile segments ----------------------------------------
+// Two-level slot reservation: the workgroup counts its pairs per tile in LDS, reserves one
+// contiguous run per touched tile with ONE returning device-scope atomic, then hands out slots
+// inside the run with LDS atomics.  (Order inside a tile segment is arbitrary by design.)
 __global__ void __launch_bounds__(256)
 scatter_kernel(ViewDev v, const ushort4 *__restrict__ rect,
                const float4 *__restrict__ geom, const uint2 *__restrict__ ranges,
-               uint32_t *__restrict__ tile_fill, uint64_t *__restrict__ keys) {
+               uint32_t *__restrict__ tile_fill, uint64_t *__restrict__ keys, const int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= v.P) return;
-    const ushort4 r = rect[idx];
-    if (r.z <= r.x || r.w <= r.y) return;
-    const float depth = geom[(size_t)idx * 5 + 3].w;
-    const uint64_t word = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
-    for (int y = r.y; y < r.w; y++)
-        for (int x = r.x; x < r.z; x++) {
-            const int t = y * v.gx + x;
-            const uint32_t slot = ranges[t].x + __hip_atomic_fetch_add(&tile_fill[t], 1u, __ATOMIC_RELAXED,
-                                                                        __HIP_MEMORY_SCOPE_AGENT);
-            if (slot < v.cap) keys[slot] = word;
+    ushort4 r = make_ushort4(0, 0, 0, 0);
+    uint64_t word = 0;
+    if (idx < v.P) {
+        r = rect[idx];
+        if (r.z > r.x && r.w > r.y) {
+            const float depth = geom[(size_t)idx * 5 + 3].w;
+            word = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
         }
+    }
+    if (use_lds) {
+        for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) hist[t] = 0;
+        __syncthreads();
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) atomicAdd(&hist[y * v.gx + x], 1u);
+        __syncthreads();
+        for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) {
+            const uint32_t c = hist[t];
+            if (c) hist[t] = ranges[t].x + __hip_atomic_fetch_add(&tile_fill[t], c, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) {
+                const uint32_t slot = atomicAdd(&hist[y * v.gx + x], 1u);
+                if (slot < v.cap) keys[slot] = word;
+            }
+    } else {
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) {
+                const int t = y * v.gx + x;
+                const uint32_t slot = ranges[t].x + __hip_atomic_fetch_add(&tile_fill[t], 1u, __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < v.cap) keys[slot] = word;
+            }
+    }
 }
 
 // ---- 4. per-tile sort ----------------------------------------------------------------------------
@@ -155,8 +182,10 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
     if (v.P == 0) return LARA2DGS_OK;
     {
         L2D_PROF("scatter", s);
-        hipLaunchKernelGGL(scatter_kernel, dim3((v.P + 255) / 256), dim3(256), 0, s, v, sc.rect,
-                           (const float4 *)st.geom, st.ranges, sc.tile_fill, sc.keys);
+        const int use_lds = v.tiles <= L2D_LDS_HIST_TILES;
+        hipLaunchKernelGGL(scatter_kernel, dim3((v.P + 255) / 256), dim3(256),
+                           use_lds ? (size_t)v.tiles * 4 : 0, s, v, sc.rect, (const float4 *)st.geom,
+                           st.ranges, sc.tile_fill, sc.keys, use_lds);
     }
     L2D_CHECK_LAUNCH();
     {

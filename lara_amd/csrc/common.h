@@ -12,6 +12,7 @@
 #define FILTER_INV_SQUARE 2.0f
 #define CUTOFF 3.0f
 #define GEOM_F 20          // floats per surfel record in the state buffer
+#define L2D_LDS_HIST_TILES 8192  // per-workgroup LDS tile histogram up to this many tiles (32 KB)
 #define GRAD_F 20          // floats per surfel in the backward accumulator (18 used)
 
 // Everything a kernel needs to know about the view, passed by value (lands in SGPRs / kernarg).

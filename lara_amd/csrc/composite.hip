@@ -47,7 +47,7 @@ __device__ __forceinline__ bool eval_splat(const Splat &s, float pxf, float pyf,
     const float pz = h.k[0] * h.l[1] - h.k[1] * h.l[0];
     if (pz == 0.0f) return false;
     h.pz = pz;
-    const float rz = 1.0f / pz;
+    const float rz = __builtin_amdgcn_rcpf(pz);  // v_rcp_f32 (1 ulp); parity is tolerance-based here
     h.sx = px * rz; h.sy = py * rz;
     h.rho3d = h.sx * h.sx + h.sy * h.sy;
     h.dx = s.xy[0] - pxf; h.dy = s.xy[1] - pyf;
@@ -126,7 +126,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             if (test_T < 0.0001f) { done = true; continue; }
             const float w = h.alpha * T;
             const float A = 1.0f - T;
-            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / h.depth);
+            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N * __builtin_amdgcn_rcpf(h.depth));
             distortion += (m * m * A + M2 - 2.0f * m * M1) * w;
             Dd += h.depth * w;
             M1 += m * w;
@@ -259,7 +259,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             for (int k = 0; k < 18; k++) g[k] = 0.f;
             if (active) {
                 const float alpha = h.alpha, G = h.G, c_d = h.depth;
-                T = T / (1.f - alpha);
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * inv_1ma;
                 const float w = alpha * T;
                 float dL_dalpha = 0.0f;
 #pragma unroll
@@ -271,8 +272,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     g[15 + ch] = w * dpix[ch];
                 }
                 float dL_dz = 0.0f, dL_dweight = 0.0f;
-                const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N / c_d);
-                const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
+                const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
+                const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
                 if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
                 dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
                 dL_dalpha += dL_dweight - last_dL_dT;
@@ -294,7 +296,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 }
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
 
                 const float dL_dG = s.opa * dL_dalpha;
                 dL_dz += alpha * T * dL_ddepth;
@@ -302,7 +304,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 if (h.rho3d <= h.rho2d) {
                     const float dL_dsx = dL_dG * -G * h.sx + dL_dz * s.Tw[0];
                     const float dL_dsy = dL_dG * -G * h.sy + dL_dz * s.Tw[1];
-                    const float dsx_pz = dL_dsx / h.pz, dsy_pz = dL_dsy / h.pz;
+                    const float inv_pz = __builtin_amdgcn_rcpf(h.pz);
+                    const float dsx_pz = dL_dsx * inv_pz, dsy_pz = dL_dsy * inv_pz;
                     const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * h.sx + dsy_pz * h.sy);
                     const float dkx = h.l[1] * dpz - h.l[2] * dpy;
                     const float dky = h.l[2] * dpx - h.l[0] * dpz;

@@ -119,23 +119,21 @@ __device__ __forceinline__ float sh_channel(const float *s, float x, float y, fl
 // ------------------------------------------------------------------------------------------------
 // forward: one thread per surfel
 // ------------------------------------------------------------------------------------------------
+// Returns the surfel's tile rectangle (empty = culled); writes its record, radius.
 template <int DEG>
-__global__ void __launch_bounds__(256)
-preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
-                      const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
-                      const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
-                      const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
-                      ushort4 *__restrict__ rect_out, uint32_t *__restrict__ tile_count,
-                      int32_t *__restrict__ radii) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= v.P) return;
+__device__ __forceinline__ ushort4
+surfel_forward(const ViewDev &v, const int idx, const float *__restrict__ means3D,
+               const float *__restrict__ shs, const float *__restrict__ colors_precomp,
+               const float *__restrict__ opacities, const float2 *__restrict__ scales,
+               const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
+               float4 *__restrict__ geom, int32_t *__restrict__ radii) {
+    const ushort4 culled = make_ushort4(0, 0, 0, 0);
     radii[idx] = 0;
-    rect_out[idx] = make_ushort4(0, 0, 0, 0);
 
     const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     float p_view[3];
     point4x3(v.viewmatrix, p, p_view);
-    if (p_view[2] <= 0.2f) return;
+    if (p_view[2] <= 0.2f) return culled;
 
     const Pm43 Pm = build_Pm(v);
     float Tm[3][3], normal[3];
@@ -154,14 +152,14 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     const float T1[3] = {Tm[0][1], Tm[1][1], Tm[2][1]};
     const float T3[3] = {Tm[0][2], Tm[1][2], Tm[2][2]};
     const float cosv = -(p_view[0] * normal[0] + p_view[1] * normal[1] + p_view[2] * normal[2]);
-    if (cosv == 0.0f) return;
+    if (cosv == 0.0f) return culled;
     const float mult = cosv > 0.0f ? 1.0f : -1.0f;
     normal[0] *= mult; normal[1] *= mult; normal[2] *= mult;
 
     // 3-sigma bounding box of the projected surfel
     const float t[3] = {CUTOFF * CUTOFF, CUTOFF * CUTOFF, -1.0f};
     const float distance = T3[0] * T3[0] * t[0] + T3[1] * T3[1] * t[1] + T3[2] * T3[2] * t[2];
-    if (distance == 0.0f) return;
+    if (distance == 0.0f) return culled;
     const float inv = 1.0f / distance;
     const float f[3] = {inv * t[0], inv * t[1], inv * t[2]};
     const float ptx = f[0] * T0[0] * T3[0] + f[1] * T0[1] * T3[1] + f[2] * T0[2] * T3[2];
@@ -176,7 +174,7 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     const int ry0 = imin(v.gy, imax(0, (int)((pty - max_radius) / TILE)));
     const int rx1 = imin(v.gx, imax(0, (int)((ptx + max_radius + TILE - 1) / TILE)));
     const int ry1 = imin(v.gy, imax(0, (int)((pty + max_radius + TILE - 1) / TILE)));
-    if ((uint32_t)(rx1 - rx0) * (uint32_t)(ry1 - ry0) == 0) return;
+    if ((uint32_t)(rx1 - rx0) * (uint32_t)(ry1 - ry0) == 0) return culled;
 
     float rgb[3];
     uint32_t clamp_bits = 0;
@@ -206,13 +204,46 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     g[3] = make_float4(normal[0], normal[1], normal[2], p_view[2]);
     g[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
     radii[idx] = max_radius;
-    rect_out[idx] = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
-                                 (unsigned short)ry1);
-    // per-tile population count (binning pass 1); relaxed device-scope adds, no return value
-    for (int y = ry0; y < ry1; y++)
-        for (int x = rx0; x < rx1; x++)
-            __hip_atomic_fetch_add(&tile_count[y * v.gx + x], 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+    return make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
+                        (unsigned short)ry1);
+}
+
+// forward kernel: one thread per surfel + binning pass 1 (per-tile population count).  Consecutive
+// surfel ids are spatially coherent in LaRa (voxel-grid order), so a workgroup's 256 surfels hit
+// only a few dozen distinct tiles: counts are aggregated in an LDS histogram and flushed with one
+// device-scope atomic per touched tile instead of one per (surfel, tile) pair.
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
+                      const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
+                      const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
+                      const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
+                      ushort4 *__restrict__ rect_out, uint32_t *__restrict__ tile_count,
+                      int32_t *__restrict__ radii, const int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (use_lds) {
+        for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) hist[t] = 0;
+        __syncthreads();
+    }
+    ushort4 r = make_ushort4(0, 0, 0, 0);
+    if (idx < v.P) {
+        r = surfel_forward<DEG>(v, idx, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                transmat_precomp, geom, radii);
+        rect_out[idx] = r;
+    }
+    for (int y = r.y; y < r.w; y++)
+        for (int x = r.x; x < r.z; x++) {
+            if (use_lds) atomicAdd(&hist[y * v.gx + x], 1u);
+            else __hip_atomic_fetch_add(&tile_count[y * v.gx + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    if (use_lds) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) {
+            const uint32_t c = hist[t];
+            if (c) __hip_atomic_fetch_add(&tile_count[t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -430,11 +461,13 @@ int launch_preprocess_fwd(const ViewDev &v, const float *means3D, const float *s
                           ScratchView sc, int32_t *radii, hipStream_t s) {
     if (v.P == 0) return LARA2DGS_OK;
     const dim3 grid((v.P + 255) / 256), block(256);
+    const int use_lds = v.tiles <= L2D_LDS_HIST_TILES;
+    const size_t lds_bytes = use_lds ? (size_t)v.tiles * 4 : 0;
 #define L2D_PRE(DEG)                                                                             \
-    hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, v, means3D, shs,           \
+    hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds_bytes, s, v, means3D, shs,   \
                        colors_precomp, opacities, (const float2 *)scales,                        \
                        (const float4 *)rotations, transmat_precomp, st.geom, sc.rect,            \
-                       sc.tile_count, radii)
+                       sc.tile_count, radii, use_lds)
     {
         L2D_PROF("preprocess_fwd", s);
         switch (colors_precomp ? 0 : v.deg) {

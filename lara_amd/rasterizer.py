@@ -109,7 +109,7 @@ def binning_capacity(P: int) -> int:
     stays on the device (no host sync per view); LaRa's init distribution needs ~3 P, a 288 GB
     part can afford 16 P (~36 B per pair) without thinking about it.  Override with
     LARA2DGS_DUP_FACTOR."""
-    return min(max(P * _dup_factor(), 1 << 16), 0xFFFFFFFF)
+    return min(max(P * _dup_factor(), 1 << 20), 0xFFFFFFFF)
 
 
 _scratch = {}   # (device index, stream id) -> uint8 tensor
@@ -209,6 +209,8 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     P = means3D.shape[0]
     H, W = int(rs.image_height), int(rs.image_width)
     means3D_c = _prep(means3D, "means3D", device)
+    if means3D_c is None:  # P == 0: keep a (dataless) tensor for the autograd bookkeeping
+        means3D_c = means3D.contiguous()
     sh_c = _prep(sh, "shs", device)
     col_c = _prep(colors_precomp, "colors_precomp", device)
     opa_c = _prep(opacities, "opacities", device)
