@@ -69,6 +69,8 @@ typedef struct lara2dgs_view {
 typedef struct lara2dgs_state_layout {
     int64_t header;      /* uint32[16]: [0]=num_rendered, [1]=overflow flag, [2]=max tile list length */
     int64_t geom;        /* float[P][20]: Tu(3) Tv(3) Tw(3) xy(2) opacity normal(3) depth rgb(3) clamp-bits */
+    int64_t cullbox;     /* float[P][4]: min x, max x, min y, max y of the pixels a surfel can reach with
+                          * alpha >= 1/255 (conservative; lets the composite skip 8x8 quadrants) */
     int64_t point_list;  /* uint32[capacity]: surfel ids, per tile, sorted by (depth bits, id) */
     int64_t ranges;      /* uint32[tiles][2]: [start, end) per 16x16 tile, (0,0) when empty */
     int64_t final_T;     /* float[3][H][W]: T, M1, M2 */
@@ -125,6 +127,10 @@ int lara2dgs_mark_visible(int32_t P, const float *means3D, const float *viewmatr
  * writes up to `max_entries` records (kernel name -> `names`, NUL-separated, at most `names_len`
  * bytes; duration in milliseconds -> `ms`), clears the log and returns the number written. */
 int lara2dgs_profile_enable(int on);
+/* Device self-tests of building blocks whose correctness rests on gfx950 lane semantics.
+ * which = 0: packed butterfly reduction; in = float[64][21] (lane major), out = float[22] zeroed
+ * by the caller: out[k] = sum over lanes of in[.][k], out[21] = 21 (number of writer lanes). */
+int lara2dgs_selftest(int which, const float *in, float *out, void *stream);
 int lara2dgs_profile_collect(char *names, int names_len, float *ms, int max_entries);
 
 #ifdef __cplusplus

@@ -72,6 +72,7 @@ StateView carve_state(const ViewDev &v, void *state) {
     StateView s;
     s.header = (uint32_t *)(b + L.header);
     s.geom = (float4 *)(b + L.geom);
+    s.cullbox = (float4 *)(b + L.cullbox);
     s.point_list = (uint32_t *)(b + L.point_list);
     s.ranges = (uint2 *)(b + L.ranges);
     s.final_T = (float *)(b + L.final_T);
@@ -198,6 +199,11 @@ int lara2dgs_mark_visible(int32_t P, const float *means3D, const float *viewmatr
     (void)projmatrix;  // kept for signature parity with the reference; the test only needs view z
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return LARA2DGS_E_INVALID;
     return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+int lara2dgs_selftest(int which, const float *in, float *out, void *stream) {
+    if (which != 0 || !in || !out) return LARA2DGS_E_INVALID;
+    return launch_selftest_butterfly(in, out, (hipStream_t)stream);
 }
 
 int lara2dgs_profile_enable(int on) {

@@ -26,6 +26,7 @@ struct ViewDev {
 struct StateView {  // typed pointers into the caller's `state` buffer
     uint32_t *header;
     float4 *geom;         // [P][5] float4
+    float4 *cullbox;      // [P] minx,maxx,miny,maxy: conservative box of {alpha >= 1/255}
     uint32_t *point_list; // [cap]
     uint2 *ranges;        // [tiles]
     float *final_T;       // [3][HW]
@@ -48,6 +49,7 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     int64_t o = 0;
     L->header = o;      o = align_up(o + 64, 256);
     L->geom = o;        o = align_up(o + (int64_t)P * GEOM_F * 4, 256);
+    L->cullbox = o;     o = align_up(o + (int64_t)P * 16, 256);
     L->point_list = o;  o = align_up(o + cap * 4, 256);
     L->ranges = o;      o = align_up(o + tiles * 8, 256);
     L->final_T = o;     o = align_up(o + 3 * HW * 4, 256);
@@ -86,6 +88,7 @@ int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *s
                           ScratchView sc, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
                           float *dL_dcolors, float *dL_dopacities, float *dL_dscales,
                           float *dL_drotations, float *dL_dtransmat, hipStream_t s);
+int launch_selftest_butterfly(const float *in, float *out, hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present,
                         hipStream_t s);
 

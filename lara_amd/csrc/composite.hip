@@ -6,73 +6,105 @@
 // (colour = C + T*bg; allmap = [sum w*depth, 1-T, sum w*normal (view space), median depth,
 // distortion]).
 //
-// Mapping: one 256-thread workgroup per 16x16 tile; each of its 4 wave64s owns an 8x8 pixel
-// quadrant (lane = pixel), which keeps a wave's footprint compact for wave-level early-out.
-// A tile's splat records (20 floats, gathered through the sorted id list) are staged through LDS
-// 256 at a time as five float4 planes; every lane then reads the same record (LDS broadcast).
+// Structure (both directions).  One 256-thread workgroup per 16x16 tile; each of its four wave64s
+// owns an 8x8 pixel quadrant (lane = pixel).  A tile's list is consumed 256 entries at a time in
+// two phases:
+//   phase S  (thread = list entry)  gather the surfel record through the sorted id list, turn it
+//            into TILE-RELATIVE coefficients -- the ray/surfel intersection p = k x l is affine in
+//            the pixel offset: p(lx,ly) = A + lx*B + ly*C with A = k0 x l0, B = Tw x l0,
+//            C = k0 x Tw, k0/l0 = the reference's k/l at the tile origin -- test the surfel's
+//            conservative alpha>=1/255 bounding box against the four quadrants (4-bit mask), and
+//            park everything in LDS.  All of this costs 1/64 of a wave-instruction per entry.
+//   phase P  (lane = pixel)  each wave ballots the quadrant bits of 64 entries into a mask and
+//            walks only the set bits; every lane reads the same LDS record (broadcast).  Entries a
+//            quadrant cannot see cost nothing; the reference evaluates every pixel of the tile
+//            against every entry.  Skipping is exact: an entry is skipped only if the reference
+//            would have skipped it for all 64 pixels (alpha < 1/255), and list positions
+//            (`contributor` numbering) are kept.
+// Backward adds: per entry, 21 per-pixel partial derivatives (in coefficient space) are reduced
+// across the wave with a packed butterfly (v_permlane32_swap / v_permlane16_swap / DPP: ~55 VALU
+// ops instead of 126 for 21 separate wave reductions), accumulated per tile in LDS, transformed to
+// dL/dT etc. by the entry's own thread (phase S2) and only then added to HBM: one atomic per
+// (tile, surfel, component) instead of one per (pixel, surfel, component).
 #include "common.h"
 
 namespace {
 
 constexpr int CHUNK = 256;
+constexpr int REC4 = 6;        // float4 planes per staged entry (see stage_entry)
+constexpr int ACC_STRIDE = 23; // 21 sums + touch counter, odd stride -> conflict-free LDS banks
 
-struct Splat {
-    float Tu[3], Tv[3], Tw[3], xy[2], opa, nrm[3], rgb[3];
-};
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
 
-__device__ __forceinline__ Splat load_splat(const float4 *s0, const float4 *s1, const float4 *s2,
-                                            const float4 *s3, const float4 *s4, int j) {
-    const float4 a = s0[j], b = s1[j], c = s2[j], d = s3[j], e = s4[j];
-    Splat s;
-    s.Tu[0] = a.x; s.Tu[1] = a.y; s.Tu[2] = a.z;
-    s.Tv[0] = a.w; s.Tv[1] = b.x; s.Tv[2] = b.y;
-    s.Tw[0] = b.z; s.Tw[1] = b.w; s.Tw[2] = c.x;
-    s.xy[0] = c.y; s.xy[1] = c.z; s.opa = c.w;
-    s.nrm[0] = d.x; s.nrm[1] = d.y; s.nrm[2] = d.z;
-    s.rgb[0] = e.x; s.rgb[1] = e.y; s.rgb[2] = e.z;
-    return s;
+// phase S: thread `e` stages list entry `pos` (if valid) as tile-relative coefficients
+//   plane 0: A.xyz B.x   plane 1: B.yz C.xy   plane 2: C.z dx0 dy0 Tw.x
+//   plane 3: Tw.yz opacity qmask   plane 4: normal.xyz r   plane 5: g b - -
+__device__ __forceinline__ void stage_entry(const uint32_t *__restrict__ point_list,
+                                            const float4 *__restrict__ geom,
+                                            const float4 *__restrict__ cullbox, const uint32_t pos,
+                                            const bool valid, const float X0, const float Y0,
+                                            float4 *rec, uint32_t *ids) {
+    const int e = threadIdx.x;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
+    uint32_t qmask = 0, id = 0;
+    if (valid) {
+        id = point_list[pos];
+        const float4 *g = geom + (size_t)id * 5;
+        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
+        const float4 cb = cullbox[id];  // minx, maxx, miny, maxy of {alpha >= 1/255}, conservative
+        const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
+        const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
+        const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
+        float A[3], B[3], C[3];
+        cross3(k0, l0, A);
+        cross3(Tw, l0, B);
+        cross3(k0, Tw, C);
+        const bool xl = cb.x <= X0 + 7.f && cb.y >= X0, xr = cb.x <= X0 + 15.f && cb.y >= X0 + 8.f;
+        const bool yt = cb.z <= Y0 + 7.f && cb.w >= Y0, yb = cb.z <= Y0 + 15.f && cb.w >= Y0 + 8.f;
+        qmask = (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) |
+                ((uint32_t)(xr && yb) << 3);
+        r0 = make_float4(A[0], A[1], A[2], B[0]);
+        r1 = make_float4(B[1], B[2], C[0], C[1]);
+        r2 = make_float4(C[2], g2.y - X0, g2.z - Y0, Tw[0]);
+        r3 = make_float4(Tw[1], Tw[2], g2.w, __uint_as_float(qmask));
+        r4 = make_float4(g3.x, g3.y, g3.z, g4.x);
+        r5 = make_float4(g4.y, g4.z, 0.f, 0.f);
+    }
+    rec[0 * CHUNK + e] = r0; rec[1 * CHUNK + e] = r1; rec[2 * CHUNK + e] = r2;
+    rec[3 * CHUNK + e] = r3; rec[4 * CHUNK + e] = r4; rec[5 * CHUNK + e] = r5;
+    if (ids) ids[e] = id;
 }
 
 struct Hit {
-    float sx, sy, rho3d, rho2d, dx, dy, depth, G, alpha, pz;
-    float k[3], l[3];
+    float sx, sy, rz, depth, G, alpha, ddx, ddy;
+    bool use3d;
 };
 
-// Ray / surfel evaluation for one pixel.  Returns false when this list entry is skipped.
-__device__ __forceinline__ bool eval_splat(const Splat &s, float pxf, float pyf, Hit &h) {
-    h.k[0] = pxf * s.Tw[0] - s.Tu[0]; h.k[1] = pxf * s.Tw[1] - s.Tu[1]; h.k[2] = pxf * s.Tw[2] - s.Tu[2];
-    h.l[0] = pyf * s.Tw[0] - s.Tv[0]; h.l[1] = pyf * s.Tw[1] - s.Tv[1]; h.l[2] = pyf * s.Tw[2] - s.Tv[2];
-    const float px = h.k[1] * h.l[2] - h.k[2] * h.l[1];
-    const float py = h.k[2] * h.l[0] - h.k[0] * h.l[2];
-    const float pz = h.k[0] * h.l[1] - h.k[1] * h.l[0];
-    if (pz == 0.0f) return false;
-    h.pz = pz;
-    const float rz = __builtin_amdgcn_rcpf(pz);  // v_rcp_f32 (1 ulp); parity is tolerance-based here
-    h.sx = px * rz; h.sy = py * rz;
-    h.rho3d = h.sx * h.sx + h.sy * h.sy;
-    h.dx = s.xy[0] - pxf; h.dy = s.xy[1] - pyf;
-    h.rho2d = FILTER_INV_SQUARE * (h.dx * h.dx + h.dy * h.dy);
-    const float rho = fminf(h.rho3d, h.rho2d);
-    h.depth = (h.rho3d <= h.rho2d) ? (h.sx * s.Tw[0] + h.sy * s.Tw[1]) + s.Tw[2] : s.Tw[2];
-    if (h.depth < NEAR_N) return false;
+// phase P: evaluate staged entry j for this lane's pixel (lx, ly = offsets inside the tile)
+__device__ __forceinline__ bool eval_entry(const float4 *rec, const int j, const float lx,
+                                           const float ly, Hit &h, float Tw[3], float &opa) {
+    const float4 r0 = rec[0 * CHUNK + j], r1 = rec[1 * CHUNK + j], r2 = rec[2 * CHUNK + j],
+                 r3 = rec[3 * CHUNK + j];
+    const float px = r0.x + lx * r0.w + ly * r1.z;
+    const float py = r0.y + lx * r1.x + ly * r1.w;
+    const float pz = r0.z + lx * r1.y + ly * r2.x;
+    Tw[0] = r2.w; Tw[1] = r3.x; Tw[2] = r3.y; opa = r3.z;
+    h.rz = __builtin_amdgcn_rcpf(pz);  // v_rcp_f32 (1 ulp); parity here is tolerance based
+    h.sx = px * h.rz; h.sy = py * h.rz;
+    const float rho3d = h.sx * h.sx + h.sy * h.sy;
+    h.ddx = r2.y - lx; h.ddy = r2.z - ly;
+    const float rho2d = FILTER_INV_SQUARE * (h.ddx * h.ddx + h.ddy * h.ddy);
+    h.use3d = rho3d <= rho2d;
+    const float rho = fminf(rho3d, rho2d);
+    h.depth = h.use3d ? (h.sx * Tw[0] + h.sy * Tw[1]) + Tw[2] : Tw[2];
     const float power = -0.5f * rho;
-    if (power > 0.0f) return false;
     h.G = __expf(power);
-    h.alpha = fminf(0.99f, s.opa * h.G);
-    if (h.alpha < 1.0f / 255.0f) return false;
-    return true;
-}
-
-__device__ __forceinline__ void stage_chunk(const uint32_t *__restrict__ point_list,
-                                            const float4 *__restrict__ geom, uint32_t pos,
-                                            bool valid, float4 *s0, float4 *s1, float4 *s2,
-                                            float4 *s3, float4 *s4) {
-    if (valid) {
-        const uint32_t id = point_list[pos];
-        const float4 *g = geom + (size_t)id * 5;
-        const int t = threadIdx.x;
-        s0[t] = g[0]; s1[t] = g[1]; s2[t] = g[2]; s3[t] = g[3]; s4[t] = g[4];
-    }
+    h.alpha = fminf(0.99f, opa * h.G);
+    return (pz != 0.0f) & (h.depth >= NEAR_N) & !(power > 0.0f) & !(h.alpha < 1.0f / 255.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -81,18 +113,20 @@ __device__ __forceinline__ void stage_chunk(const uint32_t *__restrict__ point_l
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
-                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                     float *__restrict__ out_color, float *__restrict__ out_allmap) {
-    __shared__ float4 s0[CHUNK], s1[CHUNK], s2[CHUNK], s3[CHUNK], s4[CHUNK];
+                     const float4 *__restrict__ cullbox, float *__restrict__ final_T,
+                     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
+                     float *__restrict__ out_allmap) {
+    __shared__ float4 rec[REC4 * CHUNK];
     const int tile = blockIdx.x;
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int pyi = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int lxi = (wave & 1) * 8 + (lane & 7), lyi = (wave >> 1) * 8 + (lane >> 3);
+    const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
     const bool inside = pxi < v.W && pyi < v.H;
     const size_t HW = (size_t)v.H * v.W;
     const size_t pix = (size_t)pyi * v.W + pxi;
-    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float lx = (float)lxi, ly = (float)lyi;
+    const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
 
     if (header[1]) {  // binning capacity exceeded: make the failure loud in the data
         if (inside) {
@@ -114,28 +148,44 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 
     for (int base = 0; base < total; base += CHUNK) {
         if (__syncthreads_count(done) == 256) break;
-        stage_chunk(point_list, geom, range.x + base + threadIdx.x, base + (int)threadIdx.x < total,
-                    s0, s1, s2, s3, s4);
+        stage_entry(point_list, geom, cullbox, range.x + base + threadIdx.x,
+                    base + (int)threadIdx.x < total, X0, Y0, rec, nullptr);
         __syncthreads();
-        const int cnt = min(CHUNK, total - base);
-        for (int j = 0; j < cnt && !done; j++) {
-            const Splat s = load_splat(s0, s1, s2, s3, s4, j);
-            Hit h;
-            if (!eval_splat(s, pxf, pyf, h)) continue;
-            const float test_T = T * (1.0f - h.alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float w = h.alpha * T;
-            const float A = 1.0f - T;
-            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N * __builtin_amdgcn_rcpf(h.depth));
-            distortion += (m * m * A + M2 - 2.0f * m * M1) * w;
-            Dd += h.depth * w;
-            M1 += m * w;
-            M2 += m * m * w;
-            if (T > 0.5f) { median_depth = h.depth; median_contributor = (uint32_t)(base + j + 1); }
-            N0 += s.nrm[0] * w; N1 += s.nrm[1] * w; N2 += s.nrm[2] * w;
-            C0 += s.rgb[0] * w; C1 += s.rgb[1] * w; C2 += s.rgb[2] * w;
-            T = test_T;
-            last_contributor = (uint32_t)(base + j + 1);
+        if (__ballot(!done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
+#pragma unroll 1
+        for (int sub = 0; sub < CHUNK; sub += 64) {
+            if (base + sub >= total) break;
+            const uint32_t qm = __float_as_uint(rec[3 * CHUNK + sub + lane].w);
+            unsigned long long m = __ballot((qm >> wave) & 1u);
+            while (m) {
+                const int j = sub + __builtin_ctzll(m);
+                m &= m - 1;
+                Hit h;
+                float Tw[3], opa;
+                bool valid = eval_entry(rec, j, lx, ly, h, Tw, opa) && !done;
+                const float test_T = T * (1.0f - h.alpha);
+                const bool kill = valid && test_T < 0.0001f;
+                done = done || kill;
+                valid = valid && !kill;
+                if (__ballot(valid) == 0ull) continue;
+                const float4 r4 = rec[4 * CHUNK + j], r5 = rec[5 * CHUNK + j];
+                const float a = valid ? h.alpha : 0.f;
+                const float depth = valid ? h.depth : 1.0f;
+                const float w = a * T;
+                const float A = 1.0f - T;
+                const float mm = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N * __builtin_amdgcn_rcpf(depth));
+                distortion += (mm * mm * A + M2 - 2.0f * mm * M1) * w;
+                Dd += depth * w;
+                M1 += mm * w;
+                M2 += mm * mm * w;
+                const bool med = valid && T > 0.5f;
+                median_depth = med ? depth : median_depth;
+                median_contributor = med ? (uint32_t)(base + j + 1) : median_contributor;
+                N0 += r4.x * w; N1 += r4.y * w; N2 += r4.z * w;
+                C0 += r4.w * w; C1 += r5.x * w; C2 += r5.y * w;
+                T = valid ? test_T : T;
+                last_contributor = valid ? (uint32_t)(base + j + 1) : last_contributor;
+            }
         }
     }
 
@@ -159,49 +209,100 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward
+// packed butterfly reduction of 21 per-lane values over the 64 lanes of a wave
 // ------------------------------------------------------------------------------------------------
-// wave64 sum via DPP: row_shr 1,2,4,8 inside each row of 16, then row_bcast15 / row_bcast31; the
-// total lands in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_step(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __int_as_float(moved);
+__device__ __forceinline__ float f_of(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned u_of(float f) { return __float_as_uint(f); }
+
+// lanes 0..31 <- a[l] + a[l+32] ; lanes 32..63 <- b[l-32] + b[l]
+__device__ __forceinline__ float pair32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(u_of(a), u_of(b), false, false);
+    return f_of(r[0]) + f_of(r[1]);
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_step<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_step<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_step<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_step<0x118, 0xf>(v);  // row_shr:8
-    v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-    v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
-    return v;
+// rows 0,2 <- a summed over (row, row+1) ; rows 1,3 <- b summed over (row-1, row)
+__device__ __forceinline__ float pair16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(u_of(a), u_of(b), false, false);
+    return f_of(r[0]) + f_of(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_full(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// lanes with bit3 clear <- a[l] + a[l^8] ; bit3 set <- b[l] + b[l^8]
+__device__ __forceinline__ float pair8(float a, float b, bool bit3) {
+    const float t = a + dpp_full<0x128>(a), u = b + dpp_full<0x128>(b);  // row_ror:8
+    return bit3 ? u : t;
+}
+// lanes with bit2 clear <- a[l] + a[l+4] ; bit2 set <- b[l] + b[l-4]
+__device__ __forceinline__ float pair4(float a, float b, bool bit2) {
+    int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0,2
+    y = __builtin_amdgcn_update_dpp(y, __float_as_int(b), 0x114, 0xf, 0xa, false);      // row_shr:4 -> banks 1,3
+    return (bit2 ? b : a) + __int_as_float(y);
+}
+// lanes with bit1 clear <- a[l] + a[l^2] ; bit1 set <- b[l] + b[l^2]
+__device__ __forceinline__ float pair2(float a, float b, bool bit1) {
+    const float t = a + dpp_full<0x4E>(a), u = b + dpp_full<0x4E>(b);  // quad_perm [2,3,0,1]
+    return bit1 ? u : t;
+}
+__device__ __forceinline__ float fold1(float a) { return a + dpp_full<0xB1>(a); }  // quad_perm [1,0,3,2]
+
+// After the call, lane l holds the full 64-lane sum of value slot_of_lane(l) (see below).
+__device__ __forceinline__ float butterfly21(const float v[21], const int lane) {
+    float r[11];
+#pragma unroll
+    for (int i = 0; i < 10; i++) r[i] = pair32(v[2 * i], v[2 * i + 1]);
+    r[10] = pair32(v[20], v[20]);
+    float q[6];
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = pair16(r[2 * i], r[2 * i + 1]);
+    q[5] = pair16(r[10], r[10]);
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    const float o0 = pair8(q[0], q[1], b3), o1 = pair8(q[2], q[3], b3), o2 = pair8(q[4], q[5], b3);
+    const float n0 = pair4(o0, o1, b2), n1 = pair4(o2, o2, b2);
+    return fold1(pair2(n0, n1, b1));
+}
+// which of the 21 values lane l ends up with (-1: duplicate holder, must not write)
+__device__ __forceinline__ int slot_of_lane(const int l) {
+    if (l & 1) return -1;
+    const int b1 = (l >> 1) & 1, b2 = (l >> 2) & 1, b3 = (l >> 3) & 1, b4 = (l >> 4) & 1, b5 = (l >> 5) & 1;
+    int o;  // index among o0..o2
+    if (b1) { if (b2) return -1; o = 2; } else o = b2;
+    const int q = 2 * o + b3;  // index among q0..q5
+    if (q == 5) return (b4 | b5) ? -1 : 20;
+    const int r = 2 * q + b4;  // index among r0..r9
+    return 2 * r + b5;
 }
 
 __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
     __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
-                     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                     const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
-                     float *__restrict__ grad) {
-    __shared__ float4 s0[CHUNK], s1[CHUNK], s2[CHUNK], s3[CHUNK], s4[CHUNK];
+                     const float4 *__restrict__ cullbox, const float *__restrict__ final_T,
+                     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
+                     const float *__restrict__ dL_dallmap, float *__restrict__ grad) {
+    __shared__ float4 rec[REC4 * CHUNK];
+    __shared__ float acc[CHUNK * ACC_STRIDE];  // [entry][slot]
     __shared__ uint32_t s_id[CHUNK];
     __shared__ uint32_t s_maxc;
     if (header[1]) return;
     const int tile = blockIdx.x;
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int pyi = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int lxi = (wave & 1) * 8 + (lane & 7), lyi = (wave >> 1) * 8 + (lane >> 3);
+    const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
     const bool inside = pxi < v.W && pyi < v.H;
     const size_t HW = (size_t)v.H * v.W;
     const size_t pix = inside ? (size_t)pyi * v.W + pxi : 0;
-    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float lx = (float)lxi, ly = (float)lyi;
+    const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
     const uint2 range = ranges[tile];
+    const int slot = slot_of_lane(lane);
 
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
@@ -235,108 +336,149 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __syncthreads();
     const int total = (int)s_maxc;
 
-    // back to front, CHUNK entries at a time: chunk c covers list positions [hi - CHUNK, hi)
-    for (int hi = total; hi > 0; hi -= CHUNK) {
-        const int lo = max(0, hi - CHUNK);
-        const int cnt = hi - lo;
+    // back to front, CHUNK entries at a time: chunk c covers list positions [lo, lo + cnt)
+    const int nchunks = (total + CHUNK - 1) / CHUNK;
+    for (int c = nchunks - 1; c >= 0; c--) {
+        const int lo = c * CHUNK;
+        const int cnt = min(CHUNK, total - lo);
+        __syncthreads();  // previous chunk's phase S2 is done with rec / acc / s_id
+        stage_entry(point_list, geom, cullbox, range.x + lo + threadIdx.x, (int)threadIdx.x < cnt,
+                    X0, Y0, rec, s_id);
+#pragma unroll
+        for (int k = 0; k < ACC_STRIDE; k++) acc[threadIdx.x * ACC_STRIDE + k] = 0.f;
         __syncthreads();
-        if ((int)threadIdx.x < cnt) {
-            const uint32_t id = point_list[range.x + lo + threadIdx.x];
-            s_id[threadIdx.x] = id;
+
+#pragma unroll 1
+        for (int sub = ((cnt - 1) >> 6) << 6; sub >= 0; sub -= 64) {
+            const uint32_t qm = __float_as_uint(rec[3 * CHUNK + sub + lane].w);
+            unsigned long long m = __ballot((qm >> wave) & 1u);
+            while (m) {
+                const int b = 63 - __builtin_clzll(m);
+                m &= ~(1ull << b);
+                const int j = sub + b;
+                const uint32_t contributor = (uint32_t)(lo + j);  // 0-based list position
+                Hit h;
+                float Tw[3], opa;
+                const bool active = eval_entry(rec, j, lx, ly, h, Tw, opa) && contributor < last_contributor;
+                if (__ballot(active) == 0ull) continue;
+
+                float g[21];
+#pragma unroll
+                for (int k = 0; k < 21; k++) g[k] = 0.f;
+                if (active) {
+                    const float4 r4 = rec[4 * CHUNK + j], r5 = rec[5 * CHUNK + j];
+                    const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
+                    const float alpha = h.alpha, G = h.G, c_d = h.depth;
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * inv_1ma;
+                    const float w = alpha * T;
+                    float dL_dalpha = 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = rgb[ch];
+                        dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
+                        g[18 + ch] = w * dpix[ch];
+                    }
+                    float dL_dz = 0.0f, dL_dweight = 0.0f;
+                    const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
+                    const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
+                    if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
+                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                    dL_dz += dL_dmd * dmd_dd;
+
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = c_d;
+                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                        last_normal[ch] = nrm[ch];
+                        dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
+                        g[14 + ch] = w * dnrm[ch];
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+
+                    const float dL_dG = opa * dL_dalpha;
+                    dL_dz += w * dL_ddepth;
+                    // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
+                    g[9] = dL_dz * h.sx; g[10] = dL_dz * h.sy; g[11] = dL_dz;
+                    if (h.use3d) {
+                        const float dL_dsx = dL_dG * -G * h.sx + dL_dz * Tw[0];
+                        const float dL_dsy = dL_dG * -G * h.sy + dL_dz * Tw[1];
+                        const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
+                        const float dpz = -(dpx * h.sx + dpy * h.sy);
+                        g[0] = dpx; g[1] = dpy; g[2] = dpz;
+                        g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
+                        g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
+                    } else {
+                        g[12] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddx);
+                        g[13] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddy);
+                    }
+                    g[17] = G * dL_dalpha;
+                }
+                const float s = butterfly21(g, lane);
+                if (slot >= 0) atomicAdd(&acc[j * ACC_STRIDE + slot], s);     // ds_add_f32, 21 lanes
+                if (lane == 1) atomicAdd(&acc[j * ACC_STRIDE + 21], 1.0f);    // touched marker
+            }
         }
-        stage_chunk(point_list, geom, range.x + lo + threadIdx.x, (int)threadIdx.x < cnt, s0, s1, s2, s3, s4);
         __syncthreads();
-        for (int j = cnt - 1; j >= 0; j--) {
-            const uint32_t contributor = (uint32_t)(lo + j);  // 0-based position in the list
-            const bool in_range = contributor < last_contributor;
-            const Splat s = load_splat(s0, s1, s2, s3, s4, j);
-            Hit h;
-            const bool active = in_range && eval_splat(s, pxf, pyf, h);
-            if (__ballot(active) == 0ull) continue;  // wave-uniform skip
 
-            float g[18];
+        // phase S2: thread e turns its entry's 21 coefficient-space sums into dL/d(Tu,Tv,Tw,...)
+        const int e = threadIdx.x;
+        if (e < cnt && acc[e * ACC_STRIDE + 21] > 0.f) {
+            float sacc[21];
 #pragma unroll
-            for (int k = 0; k < 18; k++) g[k] = 0.f;
-            if (active) {
-                const float alpha = h.alpha, G = h.G, c_d = h.depth;
-                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = T * inv_1ma;
-                const float w = alpha * T;
-                float dL_dalpha = 0.0f;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    const float c = s.rgb[ch];
-                    accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                    last_color[ch] = c;
-                    dL_dalpha += (c - accum_rec[ch]) * dpix[ch];
-                    g[15 + ch] = w * dpix[ch];
-                }
-                float dL_dz = 0.0f, dL_dweight = 0.0f;
-                const float inv_cd = __builtin_amdgcn_rcpf(c_d);
-                const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
-                const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
-                if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
-                dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
-                dL_dalpha += dL_dweight - last_dL_dT;
-                last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                dL_dz += dL_dmd * dmd_dd;
-
-                accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                last_depth = c_d;
-                dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
-                    last_normal[ch] = s.nrm[ch];
-                    dL_dalpha += (s.nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
-                    g[11 + ch] = alpha * T * dnrm[ch];
-                }
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-
-                const float dL_dG = s.opa * dL_dalpha;
-                dL_dz += alpha * T * dL_ddepth;
-
-                if (h.rho3d <= h.rho2d) {
-                    const float dL_dsx = dL_dG * -G * h.sx + dL_dz * s.Tw[0];
-                    const float dL_dsy = dL_dG * -G * h.sy + dL_dz * s.Tw[1];
-                    const float inv_pz = __builtin_amdgcn_rcpf(h.pz);
-                    const float dsx_pz = dL_dsx * inv_pz, dsy_pz = dL_dsy * inv_pz;
-                    const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * h.sx + dsy_pz * h.sy);
-                    const float dkx = h.l[1] * dpz - h.l[2] * dpy;
-                    const float dky = h.l[2] * dpx - h.l[0] * dpz;
-                    const float dkz = h.l[0] * dpy - h.l[1] * dpx;
-                    const float dlx = dpy * h.k[2] - dpz * h.k[1];
-                    const float dly = dpz * h.k[0] - dpx * h.k[2];
-                    const float dlz = dpx * h.k[1] - dpy * h.k[0];
-                    g[0] = -dkx; g[1] = -dky; g[2] = -dkz;
-                    g[3] = -dlx; g[4] = -dly; g[5] = -dlz;
-                    g[6] = pxf * dkx + pyf * dlx + dL_dz * h.sx;
-                    g[7] = pxf * dky + pyf * dly + dL_dz * h.sy;
-                    g[8] = pxf * dkz + pyf * dlz + dL_dz;
-                } else {
-                    g[9] = dL_dG * (-G * FILTER_INV_SQUARE * h.dx);
-                    g[10] = dL_dG * (-G * FILTER_INV_SQUARE * h.dy);
-                    g[6] = h.sx * dL_dz;
-                    g[7] = h.sy * dL_dz;
-                    g[8] = dL_dz;
-                }
-                g[14] = G * dL_dalpha;
+            for (int k = 0; k < 21; k++) sacc[k] = acc[e * ACC_STRIDE + k];
+            const uint32_t id = s_id[e];
+            const float4 *gm = geom + (size_t)id * 5;
+            const float4 g0 = gm[0], g1 = gm[1], g2 = gm[2];
+            const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
+            const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
+            const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
+            const float a[3] = {sacc[0], sacc[1], sacc[2]}, b[3] = {sacc[3], sacc[4], sacc[5]},
+                        cc[3] = {sacc[6], sacc[7], sacc[8]};
+            // A = k0 x l0, B = Tw x l0, C = k0 x Tw ; for y = u x v: dL/du = v x dL/dy, dL/dv = dL/dy x u
+            float t1[3], t2[3], dk0[3], dl0[3], dTw[3];
+            cross3(l0, a, t1); cross3(Tw, cc, t2);
+            for (int i = 0; i < 3; i++) dk0[i] = t1[i] + t2[i];
+            cross3(a, k0, t1); cross3(b, Tw, t2);
+            for (int i = 0; i < 3; i++) dl0[i] = t1[i] + t2[i];
+            cross3(l0, b, t1); cross3(cc, k0, t2);
+            for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + sacc[9 + i];
+            float *dst = grad + (size_t)id * GRAD_F;
+            for (int i = 0; i < 3; i++) {
+                atomic_add_f32(dst + 0 + i, -dk0[i]);
+                atomic_add_f32(dst + 3 + i, -dl0[i]);
+                atomic_add_f32(dst + 6 + i, dTw[i]);
             }
-            // wave reduction over the 64 pixels of this quadrant, then one atomic per component
-#pragma unroll
-            for (int k = 0; k < 18; k++) g[k] = wave_sum_to_lane63(g[k]);
-            if (lane == 63) {
-                float *dst = grad + (size_t)s_id[j] * GRAD_F;
-#pragma unroll
-                for (int k = 0; k < 18; k++) atomic_add_f32(dst + k, g[k]);
-            }
+            atomic_add_f32(dst + 9, sacc[12]);
+            atomic_add_f32(dst + 10, sacc[13]);
+            for (int i = 0; i < 3; i++) atomic_add_f32(dst + 11 + i, sacc[14 + i]);
+            atomic_add_f32(dst + 14, sacc[17]);
+            for (int i = 0; i < 3; i++) atomic_add_f32(dst + 15 + i, sacc[18 + i]);
         }
     }
+}
+
+// butterfly self-test: in [64][21] (lane major) -> out[0..20] sums, out[21] = number of writer lanes
+__global__ void __launch_bounds__(64)
+selftest_butterfly_kernel(const float *__restrict__ in, float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    float v[21];
+    for (int k = 0; k < 21; k++) v[k] = in[lane * 21 + k];
+    const float s = butterfly21(v, lane);
+    const int slot = slot_of_lane(lane);
+    if (slot >= 0) atomicAdd(&out[slot], s);
+    atomicAdd(&out[21], slot >= 0 ? 1.0f : 0.0f);
 }
 
 }  // namespace
@@ -346,8 +488,8 @@ int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float
     {
         L2D_PROF("composite_fwd", s);
         hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
-                           st.point_list, (const float4 *)st.geom, st.final_T, st.n_contrib, out_color,
-                           out_allmap);
+                           st.point_list, (const float4 *)st.geom, (const float4 *)st.cullbox,
+                           st.final_T, st.n_contrib, out_color, out_allmap);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
@@ -358,9 +500,15 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
     {
         L2D_PROF("composite_bwd", s);
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
-                           st.point_list, (const float4 *)st.geom, st.final_T, st.n_contrib, dL_dcolor,
-                           dL_dallmap, sc.grad);
+                           st.point_list, (const float4 *)st.geom, (const float4 *)st.cullbox,
+                           st.final_T, st.n_contrib, dL_dcolor, dL_dallmap, sc.grad);
     }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int launch_selftest_butterfly(const float *in, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(selftest_butterfly_kernel, dim3(1), dim3(64), 0, s, in, out);
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }

@@ -126,7 +126,8 @@ surfel_forward(const ViewDev &v, const int idx, const float *__restrict__ means3
                const float *__restrict__ shs, const float *__restrict__ colors_precomp,
                const float *__restrict__ opacities, const float2 *__restrict__ scales,
                const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
-               float4 *__restrict__ geom, int32_t *__restrict__ radii) {
+               float4 *__restrict__ geom, float4 *__restrict__ cullbox,
+               int32_t *__restrict__ radii) {
     const ushort4 culled = make_ushort4(0, 0, 0, 0);
     radii[idx] = 0;
 
@@ -197,10 +198,46 @@ surfel_forward(const ViewDev &v, const int idx, const float *__restrict__ means3
         for (int ch = 0; ch < 3; ch++) rgb[ch] = colors_precomp[3 * (size_t)idx + ch];
     }
 
+    // Conservative pixel box of {alpha >= 1/255} for the composite's quadrant culling.
+    //   alpha >= 1/255  <=>  min(rho3d, rho2d) <= tau,  tau = 2 ln(255 opacity)
+    //   rho2d <= tau: disc of radius sqrt(tau/2) around the 3-sigma box centre (ptx, pty)
+    //   rho3d <= tau: the projected disc of radius sqrt(tau); its exact AABB is the formula above
+    //                 with cutoff^2 = tau, valid while the disc stays in front of the w = 0 plane
+    //                 (d < 0); otherwise no culling for this surfel.
+    // Margins cover fp32 rounding here and in the composite's own evaluation of rho.
+    const float opa = opacities[idx];
+    const float INF = __uint_as_float(0x7f800000u);
+    float4 cb = make_float4(INF, -INF, INF, -INF);  // empty: can never reach 1/255
+    if (opa >= 1.0f / 255.0f) {
+        const float tau = 2.0f * logf(255.0f * opa) * 1.0001f + 1e-3f;
+        const float rA = sqrtf(0.5f * tau) + 0.01f;
+        float minx = ptx - rA, maxx = ptx + rA, miny = pty - rA, maxy = pty + rA;
+        const float tt[3] = {tau, tau, -1.0f};
+        const float dd = T3[0] * T3[0] * tt[0] + T3[1] * T3[1] * tt[1] + T3[2] * T3[2] * tt[2];
+        bool boxed = false;
+        if (dd < 0.0f) {
+            const float iv = 1.0f / dd;
+            const float ff[3] = {iv * tt[0], iv * tt[1], iv * tt[2]};
+            const float cx = ff[0] * T0[0] * T3[0] + ff[1] * T0[1] * T3[1] + ff[2] * T0[2] * T3[2];
+            const float cy = ff[0] * T1[0] * T3[0] + ff[1] * T1[1] * T3[1] + ff[2] * T1[2] * T3[2];
+            const float qx = ff[0] * T0[0] * T0[0] + ff[1] * T0[1] * T0[1] + ff[2] * T0[2] * T0[2];
+            const float qy = ff[0] * T1[0] * T1[0] + ff[1] * T1[1] * T1[1] + ff[2] * T1[2] * T1[2];
+            const float hx = sqrtf(fmaxf(0.0f, cx * cx - qx) + 1e-5f * cx * cx + 0.01f) * 1.001f + 0.05f;
+            const float hy = sqrtf(fmaxf(0.0f, cy * cy - qy) + 1e-5f * cy * cy + 0.01f) * 1.001f + 0.05f;
+            if (hx == hx && hy == hy && cx == cx && cy == cy) {  // no NaN
+                boxed = true;
+                minx = fminf(minx, cx - hx); maxx = fmaxf(maxx, cx + hx);
+                miny = fminf(miny, cy - hy); maxy = fmaxf(maxy, cy + hy);
+            }
+        }
+        cb = boxed ? make_float4(minx, maxx, miny, maxy) : make_float4(-INF, INF, -INF, INF);
+    }
+    cullbox[idx] = cb;
+
     float4 *g = geom + (size_t)idx * 5;
     g[0] = make_float4(T0[0], T0[1], T0[2], T1[0]);
     g[1] = make_float4(T1[1], T1[2], T3[0], T3[1]);
-    g[2] = make_float4(T3[2], ptx, pty, opacities[idx]);
+    g[2] = make_float4(T3[2], ptx, pty, opa);
     g[3] = make_float4(normal[0], normal[1], normal[2], p_view[2]);
     g[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
     radii[idx] = max_radius;
@@ -218,8 +255,9 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
                       const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
                       const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
                       const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
-                      ushort4 *__restrict__ rect_out, uint32_t *__restrict__ tile_count,
-                      int32_t *__restrict__ radii, const int use_lds) {
+                      float4 *__restrict__ cullbox, ushort4 *__restrict__ rect_out,
+                      uint32_t *__restrict__ tile_count, int32_t *__restrict__ radii,
+                      const int use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (use_lds) {
@@ -229,7 +267,7 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     ushort4 r = make_ushort4(0, 0, 0, 0);
     if (idx < v.P) {
         r = surfel_forward<DEG>(v, idx, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                transmat_precomp, geom, radii);
+                                transmat_precomp, geom, cullbox, radii);
         rect_out[idx] = r;
     }
     for (int y = r.y; y < r.w; y++)
@@ -466,8 +504,8 @@ int launch_preprocess_fwd(const ViewDev &v, const float *means3D, const float *s
 #define L2D_PRE(DEG)                                                                             \
     hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds_bytes, s, v, means3D, shs,   \
                        colors_precomp, opacities, (const float2 *)scales,                        \
-                       (const float4 *)rotations, transmat_precomp, st.geom, sc.rect,            \
-                       sc.tile_count, radii, use_lds)
+                       (const float4 *)rotations, transmat_precomp, st.geom, st.cullbox,         \
+                       sc.rect, sc.tile_count, radii, use_lds)
     {
         L2D_PROF("preprocess_fwd", s);
         switch (colors_precomp ? 0 : v.deg) {

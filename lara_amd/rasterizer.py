@@ -46,7 +46,7 @@ class _View(ctypes.Structure):
 
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
-                ("header", "geom", "point_list", "ranges", "final_T", "n_contrib", "total")]
+                ("header", "geom", "cullbox", "point_list", "ranges", "final_T", "n_contrib", "total")]
 
 
 _lib = None
@@ -84,6 +84,8 @@ def load_library():
     lib.lara2dgs_profile_enable.argtypes = [ctypes.c_int]
     lib.lara2dgs_profile_collect.restype = ctypes.c_int
     lib.lara2dgs_profile_collect.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    lib.lara2dgs_selftest.restype = ctypes.c_int
+    lib.lara2dgs_selftest.argtypes = [ctypes.c_int, vp, vp, vp]
     if lib.lara2dgs_abi_version() != ABI_VERSION:
         raise RuntimeError("lara_amd: liblara2dgs.so ABI version mismatch; rebuild the library")
     _lib = lib
@@ -397,6 +399,7 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
     return dict(
         header=hdr,
         geom=sec(L.geom, P * 80, torch.float32, (P, 20)),
+        cullbox=sec(L.cullbox, P * 16, torch.float32, (P, 4)),
         point_list=sec(L.point_list, cap * 4, torch.int32, (cap,)),
         ranges=sec(L.ranges, tiles * 8, torch.int32, (tiles, 2)),
         final_T=sec(L.final_T, 3 * H * W * 4, torch.float32, (3, H, W)),

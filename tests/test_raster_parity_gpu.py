@@ -276,3 +276,16 @@ def test_full_size_properties_and_oracle(hip_lib):
     for x, y, z in zip(a, b, c):
         lin = 2 * x - 3 * y
         assert float((lin - z).abs().max()) <= 1e-3 * float(z.abs().max())
+
+
+def test_butterfly_reduction_selftest(hip_lib):
+    """The packed 21-value wave reduction (permlane32/16 swap + DPP) against a plain sum."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 21, generator=g, dtype=torch.float32)
+    out = torch.zeros(22, device=DEV)
+    rc = hip_lib.lara2dgs_selftest(0, x.to(DEV).data_ptr(), out.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got[21] == 21.0
+    np.testing.assert_allclose(got[:21], x.double().sum(0).numpy(), rtol=1e-5, atol=1e-5)
