@@ -73,6 +73,8 @@ typedef struct lara2dgs_state_layout {
                           * alpha >= 1/255 (conservative; lets the composite skip 8x8 quadrants) */
     int64_t point_list;  /* uint32[capacity]: surfel ids, per tile, sorted by (depth bits, id) */
     int64_t ranges;      /* uint32[tiles][2]: [start, end) per 16x16 tile, (0,0) when empty */
+    int64_t tile_order;  /* uint32[tiles]: tile ids sorted by list length, longest first: the composite
+                          * kernels' workgroup -> tile map (load balance across the 256 CUs) */
     int64_t final_T;     /* float[3][H][W]: T, M1, M2 */
     int64_t n_contrib;   /* uint32[2][H][W]: last contributor, median contributor */
     int64_t total;

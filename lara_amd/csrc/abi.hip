@@ -1,4 +1,5 @@
 // abi.hip -- extern "C" entry points of liblara2dgs.so (see include/lara2dgs.h).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -58,6 +59,10 @@ bool make_view(const lara2dgs_view *view, ViewDev &v) {
     if (v.gx > 65535 || v.gy > 65535) return false;
     v.scale_modifier = view->scale_modifier;
     v.cap = (unsigned)view->capacity;
+    {
+        static const unsigned dbg = getenv("LARA2DGS_DEBUG_FLAGS") ? (unsigned)strtoul(getenv("LARA2DGS_DEBUG_FLAGS"), nullptr, 0) : 0u;
+        v.dbg = dbg;
+    }
     v.bg = view->bg;
     v.viewmatrix = view->viewmatrix;
     v.projmatrix = view->projmatrix;
@@ -75,6 +80,7 @@ StateView carve_state(const ViewDev &v, void *state) {
     s.cullbox = (float4 *)(b + L.cullbox);
     s.point_list = (uint32_t *)(b + L.point_list);
     s.ranges = (uint2 *)(b + L.ranges);
+    s.tile_order = (uint32_t *)(b + L.tile_order);
     s.final_T = (float *)(b + L.final_T);
     s.n_contrib = (uint32_t *)(b + L.n_contrib);
     return s;

@@ -21,12 +21,37 @@
 
 namespace {
 
+// ---- sorting network shared by the tile-order sort and the per-tile key sort ----------------
+// Bitonic network in its "all comparators ascending" form (first step of each merge mirrors the
+// block), so virtual +inf padding above n never moves: comparators touching an index >= n are
+// skipped.  Works for any n, in LDS or (oversized tiles) directly in the global segment -- one
+// workgroup owns a segment, and __syncthreads() orders its own global accesses.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort(Ptr a, const uint32_t n, const uint32_t m /*pow2 >= n*/) {
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const bool flip = (j == (k >> 1));
+            for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+                // t-th comparator: lower index i has bit j clear
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t p = flip ? (i ^ (k - 1)) : (i ^ j);
+                if (p < n) {  // i < p always
+                    const uint64_t x = a[i], y = a[p];
+                    if (y < x) { a[i] = y; a[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- 2. exclusive scan of tile counts -> ranges ------------------------------------------------
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
-                 uint32_t *__restrict__ header) {
+                 uint32_t *__restrict__ header, uint32_t *__restrict__ tile_order) {
     __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t carry_s;
+    __shared__ uint32_t carry_s, s_max;
+    __shared__ uint32_t bcnt[64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -69,6 +94,33 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__re
         header[0] = total;
         header[1] = total > v.cap ? 1u : 0u;
         header[2] = m;
+        s_max = m;
+    }
+    // Launch order of the composite kernels: longest list first (LPT), so that the heavy centre
+    // tiles spread over all CUs instead of piling onto the few CUs their ids map to.  A 64-bucket
+    // counting sort on the list length is enough (order inside a bucket is irrelevant).
+    if (tid < 64) bcnt[tid] = 0;
+    __syncthreads();
+    const uint32_t denom = s_max + 1u;
+    for (int i = tid; i < v.tiles; i += 1024) {
+        const uint32_t b = 63u - (uint32_t)(((uint64_t)tile_count[i] * 64u) / denom);
+        atomicAdd(&bcnt[b], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the 64 bucket sizes inside wave 0
+        const uint32_t c = bcnt[tid];
+        uint32_t x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        bcnt[tid] = x - c;
+    }
+    __syncthreads();
+    for (int i = tid; i < v.tiles; i += 1024) {
+        const uint32_t b = 63u - (uint32_t)(((uint64_t)tile_count[i] * 64u) / denom);
+        tile_order[atomicAdd(&bcnt[b], 1u)] = (uint32_t)i;
     }
 }
 
@@ -119,30 +171,7 @@ scatter_kernel(ViewDev v, const ushort4 *__restrict__ rect,
     }
 }
 
-// ---- 4. per-tile sort ----------------------------------------------------------------------------
-// Bitonic network in its "all comparators ascending" form (first step of each merge mirrors the
-// block), so virtual +inf padding above n never moves: comparators touching an index >= n are
-// skipped.  Works for any n, in LDS or (oversized tiles) directly in the global segment -- one
-// workgroup owns a segment, and __syncthreads() orders its own global accesses.
-template <typename Ptr>
-__device__ __forceinline__ void bitonic_sort(Ptr a, const uint32_t n, const uint32_t m /*pow2 >= n*/) {
-    for (uint32_t k = 2; k <= m; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const bool flip = (j == (k >> 1));
-            for (uint32_t t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
-                // t-th comparator: lower index i has bit j clear
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t p = flip ? (i ^ (k - 1)) : (i ^ j);
-                if (p < n) {  // i < p always
-                    const uint64_t x = a[i], y = a[p];
-                    if (y < x) { a[i] = y; a[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
+// ---- 4. per-tile sort (network defined above) ------------------------------------------------
 __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
     return n <= 1 ? 1u : 1u << (32 - __clz(n - 1));
 }
@@ -176,7 +205,8 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s) {
     {
         L2D_PROF("tile_scan", s);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, st.ranges, st.header);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, st.ranges, st.header,
+                           st.tile_order);
     }
     L2D_CHECK_LAUNCH();
     if (v.P == 0) return LARA2DGS_OK;

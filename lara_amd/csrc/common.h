@@ -20,6 +20,7 @@ struct ViewDev {
     int P, deg, M, H, W, gx, gy, tiles;
     float scale_modifier;
     unsigned cap;  // capacity in (tile, surfel) pairs
+    unsigned dbg;  // LARA2DGS_DEBUG_FLAGS (perf experiments only; 0 in production)
     const float *bg, *viewmatrix, *projmatrix, *campos;
 };
 
@@ -29,6 +30,7 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     float4 *cullbox;      // [P] minx,maxx,miny,maxy: conservative box of {alpha >= 1/255}
     uint32_t *point_list; // [cap]
     uint2 *ranges;        // [tiles]
+    uint32_t *tile_order; // [tiles] tile ids, longest list first (work-balanced launch order)
     float *final_T;       // [3][HW]
     uint32_t *n_contrib;  // [2][HW]
 };
@@ -52,6 +54,7 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->cullbox = o;     o = align_up(o + (int64_t)P * 16, 256);
     L->point_list = o;  o = align_up(o + cap * 4, 256);
     L->ranges = o;      o = align_up(o + tiles * 8, 256);
+    L->tile_order = o;  o = align_up(o + tiles * 4, 256);
     L->final_T = o;     o = align_up(o + 3 * HW * 4, 256);
     L->n_contrib = o;   o = align_up(o + 2 * HW * 4, 256);
     L->total = o;

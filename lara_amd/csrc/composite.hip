@@ -110,14 +110,49 @@ __device__ __forceinline__ bool eval_entry(const float4 *rec, const int j, const
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// per-pixel compositing state; blend() is branch-free per lane (invalid lanes blend with alpha 0)
+struct FwdPixel {
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    float Dd = 0.f, M1 = 0.f, M2 = 0.f, distortion = 0.f, median_depth = 0.f;
+    uint32_t last_contributor = 0, median_contributor = 0;
+    bool done = false;
+
+    __device__ __forceinline__ void blend(const float4 *rec, const int j, const int base, bool valid,
+                                          const Hit &h) {
+        valid = valid && !done;
+        const float test_T = T * (1.0f - h.alpha);
+        const bool kill = valid && test_T < 0.0001f;  // would push T below 1e-4: not composited, pixel ends
+        done = done || kill;
+        valid = valid && !kill;
+        if (__ballot(valid) == 0ull) return;
+        const float4 r4 = rec[4 * CHUNK + j], r5 = rec[5 * CHUNK + j];
+        const float a = valid ? h.alpha : 0.f;
+        const float depth = valid ? h.depth : 1.0f;
+        const float w = a * T;
+        const float A = 1.0f - T;
+        const float mm = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N * __builtin_amdgcn_rcpf(depth));
+        distortion += (mm * mm * A + M2 - 2.0f * mm * M1) * w;
+        Dd += depth * w;
+        M1 += mm * w;
+        M2 += mm * mm * w;
+        const bool med = valid && T > 0.5f;
+        median_depth = med ? depth : median_depth;
+        median_contributor = med ? (uint32_t)(base + j + 1) : median_contributor;
+        N0 += r4.x * w; N1 += r4.y * w; N2 += r4.z * w;
+        C0 += r4.w * w; C1 += r5.x * w; C2 += r5.y * w;
+        T = valid ? test_T : T;
+        last_contributor = valid ? (uint32_t)(base + j + 1) : last_contributor;
+    }
+};
+
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
-                     const float4 *__restrict__ cullbox, float *__restrict__ final_T,
-                     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
-                     float *__restrict__ out_allmap) {
+                     const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
+                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                     float *__restrict__ out_color, float *__restrict__ out_allmap) {
     __shared__ float4 rec[REC4 * CHUNK];
-    const int tile = blockIdx.x;
+    const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lxi = (wave & 1) * 8 + (lane & 7), lyi = (wave >> 1) * 8 + (lane >> 3);
@@ -141,70 +176,61 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
-    float Dd = 0.f, M1 = 0.f, M2 = 0.f, distortion = 0.f, median_depth = 0.f;
-    uint32_t last_contributor = 0, median_contributor = 0;
+    FwdPixel px;
+    px.done = !inside;
+    uint32_t *dbg_hdr = const_cast<uint32_t *>(header);
 
     for (int base = 0; base < total; base += CHUNK) {
-        if (__syncthreads_count(done) == 256) break;
+        if (__syncthreads_count(px.done) == 256) break;
         stage_entry(point_list, geom, cullbox, range.x + base + threadIdx.x,
                     base + (int)threadIdx.x < total, X0, Y0, rec, nullptr);
         __syncthreads();
-        if (__ballot(!done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
+        if (__ballot(!px.done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
 #pragma unroll 1
         for (int sub = 0; sub < CHUNK; sub += 64) {
             if (base + sub >= total) break;
             const uint32_t qm = __float_as_uint(rec[3 * CHUNK + sub + lane].w);
             unsigned long long m = __ballot((qm >> wave) & 1u);
+            // two list entries per trip: their evaluations are independent (ILP), blending stays
+            // strictly in list order
             while (m) {
-                const int j = sub + __builtin_ctzll(m);
+                const int j0 = sub + __builtin_ctzll(m);
                 m &= m - 1;
-                Hit h;
-                float Tw[3], opa;
-                bool valid = eval_entry(rec, j, lx, ly, h, Tw, opa) && !done;
-                const float test_T = T * (1.0f - h.alpha);
-                const bool kill = valid && test_T < 0.0001f;
-                done = done || kill;
-                valid = valid && !kill;
-                if (__ballot(valid) == 0ull) continue;
-                const float4 r4 = rec[4 * CHUNK + j], r5 = rec[5 * CHUNK + j];
-                const float a = valid ? h.alpha : 0.f;
-                const float depth = valid ? h.depth : 1.0f;
-                const float w = a * T;
-                const float A = 1.0f - T;
-                const float mm = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N * __builtin_amdgcn_rcpf(depth));
-                distortion += (mm * mm * A + M2 - 2.0f * mm * M1) * w;
-                Dd += depth * w;
-                M1 += mm * w;
-                M2 += mm * mm * w;
-                const bool med = valid && T > 0.5f;
-                median_depth = med ? depth : median_depth;
-                median_contributor = med ? (uint32_t)(base + j + 1) : median_contributor;
-                N0 += r4.x * w; N1 += r4.y * w; N2 += r4.z * w;
-                C0 += r4.w * w; C1 += r5.x * w; C2 += r5.y * w;
-                T = valid ? test_T : T;
-                last_contributor = valid ? (uint32_t)(base + j + 1) : last_contributor;
+                const bool two = m != 0ull;
+                const int j1 = two ? sub + __builtin_ctzll(m) : j0;
+                m &= m - 1;  // no-op when m == 0
+                Hit h0, h1;
+                float Tw0[3], Tw1[3], opa0, opa1;
+                const bool e0 = eval_entry(rec, j0, lx, ly, h0, Tw0, opa0);
+                const bool e1 = eval_entry(rec, j1, lx, ly, h1, Tw1, opa1) && two;
+                if (v.dbg & 4u) {  // statistics: candidates, valid (pixel, entry) pairs, live pairs
+                    if (lane == 0) atomicAdd(&dbg_hdr[4], two ? 2u : 1u);
+                    atomicAdd(&dbg_hdr[5], (unsigned)e0 + (unsigned)e1);
+                    atomicAdd(&dbg_hdr[6], (unsigned)(e0 && !px.done) + (unsigned)(e1 && !px.done));
+                }
+                px.blend(rec, j0, base, e0, h0);
+                px.blend(rec, j1, base, e1, h1);
             }
         }
     }
+    const float T = px.T;
 
     if (inside) {
         final_T[pix] = T;
-        final_T[pix + HW] = M1;
-        final_T[pix + 2 * HW] = M2;
-        n_contrib[pix] = last_contributor;
-        n_contrib[pix + HW] = median_contributor;
-        out_color[0 * HW + pix] = C0 + T * v.bg[0];
-        out_color[1 * HW + pix] = C1 + T * v.bg[1];
-        out_color[2 * HW + pix] = C2 + T * v.bg[2];
-        out_allmap[0 * HW + pix] = Dd;
+        final_T[pix + HW] = px.M1;
+        final_T[pix + 2 * HW] = px.M2;
+        n_contrib[pix] = px.last_contributor;
+        n_contrib[pix + HW] = px.median_contributor;
+        out_color[0 * HW + pix] = px.C0 + T * v.bg[0];
+        out_color[1 * HW + pix] = px.C1 + T * v.bg[1];
+        out_color[2 * HW + pix] = px.C2 + T * v.bg[2];
+        out_allmap[0 * HW + pix] = px.Dd;
         out_allmap[1 * HW + pix] = 1.0f - T;
-        out_allmap[2 * HW + pix] = N0;
-        out_allmap[3 * HW + pix] = N1;
-        out_allmap[4 * HW + pix] = N2;
-        out_allmap[5 * HW + pix] = median_depth;
-        out_allmap[6 * HW + pix] = distortion;
+        out_allmap[2 * HW + pix] = px.N0;
+        out_allmap[3 * HW + pix] = px.N1;
+        out_allmap[4 * HW + pix] = px.N2;
+        out_allmap[5 * HW + pix] = px.median_depth;
+        out_allmap[6 * HW + pix] = px.distortion;
     }
 }
 
@@ -283,15 +309,16 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
-                     const float4 *__restrict__ cullbox, const float *__restrict__ final_T,
-                     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
-                     const float *__restrict__ dL_dallmap, float *__restrict__ grad) {
+                     const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
+                     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                     const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
+                     float *__restrict__ grad) {
     __shared__ float4 rec[REC4 * CHUNK];
     __shared__ float acc[CHUNK * ACC_STRIDE];  // [entry][slot]
     __shared__ uint32_t s_id[CHUNK];
     __shared__ uint32_t s_maxc;
     if (header[1]) return;
-    const int tile = blockIdx.x;
+    const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lxi = (wave & 1) * 8 + (lane & 7), lyi = (wave >> 1) * 8 + (lane >> 3);
@@ -425,6 +452,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     }
                     g[17] = G * dL_dalpha;
                 }
+                if (v.dbg & 2u) { float z = 0.f; for (int k = 0; k < 21; k++) z += g[k]; if (z == 123.456f) acc[0] = z; continue; }
                 const float s = butterfly21(g, lane);
                 if (slot >= 0) atomicAdd(&acc[j * ACC_STRIDE + slot], s);     // ds_add_f32, 21 lanes
                 if (lane == 1) atomicAdd(&acc[j * ACC_STRIDE + 21], 1.0f);    // touched marker
@@ -434,7 +462,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 
         // phase S2: thread e turns its entry's 21 coefficient-space sums into dL/d(Tu,Tv,Tw,...)
         const int e = threadIdx.x;
-        if (e < cnt && acc[e * ACC_STRIDE + 21] > 0.f) {
+        if (e < cnt && acc[e * ACC_STRIDE + 21] > 0.f && !(v.dbg & 1u)) {
             float sacc[21];
 #pragma unroll
             for (int k = 0; k < 21; k++) sacc[k] = acc[e * ACC_STRIDE + k];
@@ -488,8 +516,8 @@ int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float
     {
         L2D_PROF("composite_fwd", s);
         hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
-                           st.point_list, (const float4 *)st.geom, (const float4 *)st.cullbox,
-                           st.final_T, st.n_contrib, out_color, out_allmap);
+                           st.point_list, (const float4 *)st.geom, st.tile_order,
+                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, out_color, out_allmap);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
@@ -500,8 +528,9 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
     {
         L2D_PROF("composite_bwd", s);
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
-                           st.point_list, (const float4 *)st.geom, (const float4 *)st.cullbox,
-                           st.final_T, st.n_contrib, dL_dcolor, dL_dallmap, sc.grad);
+                           st.point_list, (const float4 *)st.geom, st.tile_order,
+                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, dL_dcolor, dL_dallmap,
+                           sc.grad);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -46,7 +46,7 @@ class _View(ctypes.Structure):
 
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
-                ("header", "geom", "cullbox", "point_list", "ranges", "final_T", "n_contrib", "total")]
+                ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "final_T", "n_contrib", "total")]
 
 
 _lib = None
@@ -402,6 +402,7 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
         cullbox=sec(L.cullbox, P * 16, torch.float32, (P, 4)),
         point_list=sec(L.point_list, cap * 4, torch.int32, (cap,)),
         ranges=sec(L.ranges, tiles * 8, torch.int32, (tiles, 2)),
+        tile_order=sec(L.tile_order, tiles * 4, torch.int32, (tiles,)),
         final_T=sec(L.final_T, 3 * H * W * 4, torch.float32, (3, H, W)),
         n_contrib=sec(L.n_contrib, 2 * H * W * 4, torch.int32, (2, H, W)),
     )
