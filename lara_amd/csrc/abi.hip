@@ -92,7 +92,8 @@ ScratchView carve_scratch(const ViewDev &v, void *scratch, ScratchLayout &L) {
     ScratchView s;
     s.tile_count = (uint32_t *)(b + L.tile_count);
     s.tile_fill = (uint32_t *)(b + L.tile_fill);
-    s.rect = (ushort4 *)(b + L.rect);
+    s.sub_start = (uint32_t *)(b + L.sub_start);
+    s.rect = (uint4 *)(b + L.rect);
     s.keys = (uint64_t *)(b + L.keys);
     s.grad = (float *)(b + L.grad);
     return s;
@@ -158,7 +159,7 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
     ScratchView sc = carve_scratch(v, scratch, SL);
     // header + tile_count + tile_fill start at zero
     hipError_t e = hipMemsetAsync(st.header, 0, 64, s);
-    if (e == hipSuccess) e = hipMemsetAsync(sc.tile_count, 0, (size_t)(SL.rect - SL.tile_count), s);
+    if (e == hipSuccess) e = hipMemsetAsync(sc.tile_count, 0, (size_t)(SL.sub_start - SL.tile_count), s);
     if (e != hipSuccess) { l2d_set_hip_error(e); return LARA2DGS_E_LAUNCH; }
     int rc = launch_preprocess_fwd(v, means3D, shs, colors_precomp, opacities, scales, rotations,
                                    transmat_precomp, st, sc, out_radii, s);

@@ -47,8 +47,9 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, const uint32_t n, const uint
 
 // ---- 2. exclusive scan of tile counts -> ranges ------------------------------------------------
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
-                 uint32_t *__restrict__ header, uint32_t *__restrict__ tile_order) {
+tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ sub_start,
+                 uint2 *__restrict__ ranges, uint32_t *__restrict__ header,
+                 uint32_t *__restrict__ tile_order) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s, s_max;
     __shared__ uint32_t bcnt[64];
@@ -58,7 +59,18 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__re
     uint32_t max_len = 0;
     for (int base = 0; base < v.tiles; base += 1024) {
         const int i = base + tid;
-        const uint32_t c = i < v.tiles ? tile_count[i] : 0u;
+        uint32_t sub[L2D_SLICES];
+        uint32_t c = 0;
+        if (i < v.tiles) {
+            const uint4 *tc = (const uint4 *)(tile_count + (size_t)i * L2D_SLICES);
+#pragma unroll
+            for (int q = 0; q < L2D_SLICES / 4; q++) {
+                const uint4 w4 = tc[q];
+                sub[4 * q] = w4.x; sub[4 * q + 1] = w4.y; sub[4 * q + 2] = w4.z; sub[4 * q + 3] = w4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < L2D_SLICES; q++) c += sub[q];
+        }
         max_len = c > max_len ? c : max_len;
         // inclusive scan inside the wave
         uint32_t x = c;
@@ -73,7 +85,20 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__re
         for (int w = 0; w < wid; w++) wave_off += wave_sums[w];
         const uint32_t carry = carry_s;
         const uint32_t incl = carry + wave_off + x;
-        if (i < v.tiles) ranges[i] = c ? make_uint2(incl - c, incl) : make_uint2(0u, 0u);
+        if (i < v.tiles) {
+            ranges[i] = c ? make_uint2(incl - c, incl) : make_uint2(0u, 0u);
+            uint32_t run = incl - c;
+            uint4 *ss = (uint4 *)(sub_start + (size_t)i * L2D_SLICES);
+#pragma unroll
+            for (int q = 0; q < L2D_SLICES / 4; q++) {
+                uint4 w4;
+                w4.x = run; run += sub[4 * q];
+                w4.y = run; run += sub[4 * q + 1];
+                w4.z = run; run += sub[4 * q + 2];
+                w4.w = run; run += sub[4 * q + 3];
+                ss[q] = w4;
+            }
+        }
         __syncthreads();
         if (tid == 1023) carry_s = incl;
         __syncthreads();
@@ -103,7 +128,8 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__re
     __syncthreads();
     const uint32_t denom = s_max + 1u;
     for (int i = tid; i < v.tiles; i += 1024) {
-        const uint32_t b = 63u - (uint32_t)(((uint64_t)tile_count[i] * 64u) / denom);
+        const uint2 rg = ranges[i];
+        const uint32_t b = 63u - (uint32_t)(((uint64_t)(rg.y - rg.x) * 64u) / denom);
         atomicAdd(&bcnt[b], 1u);
     }
     __syncthreads();
@@ -119,7 +145,8 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__re
     }
     __syncthreads();
     for (int i = tid; i < v.tiles; i += 1024) {
-        const uint32_t b = 63u - (uint32_t)(((uint64_t)tile_count[i] * 64u) / denom);
+        const uint2 rg = ranges[i];
+        const uint32_t b = 63u - (uint32_t)(((uint64_t)(rg.y - rg.x) * 64u) / denom);
         tile_order[atomicAdd(&bcnt[b], 1u)] = (uint32_t)i;
     }
 }
@@ -129,74 +156,159 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint2 *__re
 // contiguous run per touched tile with ONE returning device-scope atomic, then hands out slots
 // inside the run with LDS atomics.  (Order inside a tile segment is arbitrary by design.)
 __global__ void __launch_bounds__(256)
-scatter_kernel(ViewDev v, const ushort4 *__restrict__ rect,
-               const float4 *__restrict__ geom, const uint2 *__restrict__ ranges,
+scatter_kernel(ViewDev v, const uint4 *__restrict__ rect, const uint32_t *__restrict__ sub_start,
                uint32_t *__restrict__ tile_fill, uint64_t *__restrict__ keys, const int use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    ushort4 r = make_ushort4(0, 0, 0, 0);
+    const int slice = blockIdx.x % L2D_SLICES;
+    int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
     uint64_t word = 0;
     if (idx < v.P) {
-        r = rect[idx];
-        if (r.z > r.x && r.w > r.y) {
-            const float depth = geom[(size_t)idx * 5 + 3].w;
-            word = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
-        }
+        const uint4 r = rect[idx];
+        rx0 = r.x & 0xffff; ry0 = r.x >> 16; rx1 = r.y & 0xffff; ry1 = r.y >> 16;
+        word = ((uint64_t)r.z << 32) | (uint32_t)idx;
     }
     if (use_lds) {
         for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) hist[t] = 0;
         __syncthreads();
-        for (int y = r.y; y < r.w; y++)
-            for (int x = r.x; x < r.z; x++) atomicAdd(&hist[y * v.gx + x], 1u);
+        for (int y = ry0; y < ry1; y++)
+            for (int x = rx0; x < rx1; x++) atomicAdd(&hist[y * v.gx + x], 1u);
         __syncthreads();
         for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) {
             const uint32_t c = hist[t];
-            if (c) hist[t] = ranges[t].x + __hip_atomic_fetch_add(&tile_fill[t], c, __ATOMIC_RELAXED,
-                                                                 __HIP_MEMORY_SCOPE_AGENT);
+            if (c) hist[t] = sub_start[t * L2D_SLICES + slice] +
+                             __hip_atomic_fetch_add(&tile_fill[t * L2D_SLICES + slice], c, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        for (int y = r.y; y < r.w; y++)
-            for (int x = r.x; x < r.z; x++) {
+        for (int y = ry0; y < ry1; y++)
+            for (int x = rx0; x < rx1; x++) {
                 const uint32_t slot = atomicAdd(&hist[y * v.gx + x], 1u);
                 if (slot < v.cap) keys[slot] = word;
             }
     } else {
-        for (int y = r.y; y < r.w; y++)
-            for (int x = r.x; x < r.z; x++) {
-                const int t = y * v.gx + x;
-                const uint32_t slot = ranges[t].x + __hip_atomic_fetch_add(&tile_fill[t], 1u, __ATOMIC_RELAXED,
-                                                                            __HIP_MEMORY_SCOPE_AGENT);
+        for (int y = ry0; y < ry1; y++)
+            for (int x = rx0; x < rx1; x++) {
+                const int t = (y * v.gx + x) * L2D_SLICES + slice;
+                const uint32_t slot = sub_start[t] + __hip_atomic_fetch_add(&tile_fill[t], 1u, __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_AGENT);
                 if (slot < v.cap) keys[slot] = word;
             }
     }
 }
 
-// ---- 4. per-tile sort (network defined above) ------------------------------------------------
 __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
     return n <= 1 ? 1u : 1u << (32 - __clz(n - 1));
 }
 
-template <int LDS_ENTRIES, bool SMALL>
+// ---- 4. per-tile sort -----------------------------------------------------------------------------
+// Register-blocked bitonic network: a 256-thread workgroup sorts 256*E keys, thread t holding the
+// E consecutive keys [t*E, t*E+E).  Comparators whose partner lives in the same thread are plain
+// register compare-exchanges; partners in the same wave are reached with ds_bpermute; only
+// partners in another wave (thread distance >= 64) go through LDS (element-major, conflict free).
+// Padding keys are ~0 and, the network being all-ascending, stay above every real key.
+__device__ __forceinline__ void ce(uint64_t &a, uint64_t &b) {  // a <- min, b <- max
+    const bool sw = b < a;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t x, int src_lane) {
+    const uint32_t lo = __shfl((uint32_t)x, src_lane, 64), hi = __shfl((uint32_t)(x >> 32), src_lane, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// compare-exchange every key with partner thread pt's key (REVERSED: its key E-1-e, the mirror
+// step that opens a merge); the lower-numbered thread keeps the minima
+template <int E, bool REVERSED>
+__device__ __forceinline__ void xchg(uint64_t (&x)[E], const int t, const int pt, uint64_t *lds) {
+    uint64_t o[E];
+    if ((t ^ pt) < 64) {  // partner in the same wave (uniform: the xor distance is common to all t)
+#pragma unroll
+        for (int e = 0; e < E; e++) o[e] = shfl64(x[REVERSED ? E - 1 - e : e], pt & 63);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; e++) lds[e * 256 + t] = x[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; e++) o[e] = lds[(REVERSED ? E - 1 - e : e) * 256 + pt];
+        __syncthreads();
+    }
+    const bool keep_min = t < pt;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const bool take = keep_min ? (o[e] < x[e]) : (x[e] < o[e]);
+        x[e] = take ? o[e] : x[e];
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void block_sort(uint64_t (&x)[E], uint64_t *lds) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 2; k <= E; k <<= 1) {  // merges that fit inside a thread
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int p = e ^ (k - 1);
+            if (p > e) ce(x[e], x[p]);
+        }
+#pragma unroll
+        for (int j = k >> 2; j >= 1; j >>= 1)
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if ((e & j) == 0) ce(x[e], x[e | j]);
+    }
+#pragma unroll 1
+    for (int kt = 2; kt <= 256; kt <<= 1) {  // merges of kt threads' worth of keys
+        xchg<E, true>(x, t, t ^ (kt - 1), lds);
+#pragma unroll 1
+        for (int jt = kt >> 2; jt >= 1; jt >>= 1) xchg<E, false>(x, t, t ^ jt, lds);
+#pragma unroll
+        for (int j = E >> 1; j >= 1; j >>= 1)
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if ((e & j) == 0) ce(x[e], x[e | j]);
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ seg, const uint32_t n,
+                                          uint32_t *__restrict__ out, uint64_t *lds) {
+    uint64_t x[E];
+    const uint32_t i0 = threadIdx.x * E;
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = (i0 + e < n) ? seg[i0 + e] : ~0ull;
+    block_sort<E>(x, lds);
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if (i0 + e < n) out[i0 + e] = (uint32_t)x[e];
+}
+
+// LARGE = false: tiles with n <= 2048 (16 KB LDS); LARGE = true: 2048 < n (64 KB LDS; lists longer
+// than 8192 fall back to the generic network run directly on the global segment)
+template <bool LARGE>
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ header,
-                 uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list) {
-    __shared__ uint64_t buf[LDS_ENTRIES];
-    const uint2 rg = ranges[blockIdx.x];
-    uint32_t n = rg.y - rg.x;
+                 const uint32_t *__restrict__ tile_order, uint64_t *__restrict__ keys,
+                 uint32_t *__restrict__ point_list) {
+    __shared__ uint64_t lds[LARGE ? 8192 : 2048];
+    const uint2 rg = ranges[tile_order[blockIdx.x]];
+    const uint32_t n = rg.y - rg.x;
     if (header[1]) return;  // capacity overflow: lists are incomplete, outputs get poisoned instead
-    if (SMALL ? (n > (uint32_t)LDS_ENTRIES) : (n <= 2048u)) return;  // the other kernel's tile
-    if (n == 0) return;
-    const uint32_t m = next_pow2(n);
+    if (n == 0 || (LARGE ? (n <= 2048u) : (n > 2048u))) return;  // the other kernel's tile
     uint64_t *seg = keys + rg.x;
-    if (n <= (uint32_t)LDS_ENTRIES) {
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) buf[i] = seg[i];
-        __syncthreads();
-        bitonic_sort(buf, n, m);
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) point_list[rg.x + i] = (uint32_t)buf[i];
+    uint32_t *out = point_list + rg.x;
+    if (!LARGE) {
+        if (n <= 256u) sort_tile<1>(seg, n, out, lds);
+        else if (n <= 512u) sort_tile<2>(seg, n, out, lds);
+        else if (n <= 1024u) sort_tile<4>(seg, n, out, lds);
+        else sort_tile<8>(seg, n, out, lds);
     } else {
-        __syncthreads();
-        bitonic_sort(seg, n, m);
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) point_list[rg.x + i] = (uint32_t)seg[i];
+        if (n <= 4096u) sort_tile<16>(seg, n, out, lds);
+        else if (n <= 8192u) sort_tile<32>(seg, n, out, lds);
+        else {
+            bitonic_sort(seg, n, next_pow2(n));
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = (uint32_t)seg[i];
+        }
     }
 }
 
@@ -205,8 +317,8 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s) {
     {
         L2D_PROF("tile_scan", s);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, st.ranges, st.header,
-                           st.tile_order);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
+                           st.ranges, st.header, st.tile_order);
     }
     L2D_CHECK_LAUNCH();
     if (v.P == 0) return LARA2DGS_OK;
@@ -214,20 +326,20 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
         L2D_PROF("scatter", s);
         const int use_lds = v.tiles <= L2D_LDS_HIST_TILES;
         hipLaunchKernelGGL(scatter_kernel, dim3((v.P + 255) / 256), dim3(256),
-                           use_lds ? (size_t)v.tiles * 4 : 0, s, v, sc.rect, (const float4 *)st.geom,
-                           st.ranges, sc.tile_fill, sc.keys, use_lds);
+                           use_lds ? (size_t)v.tiles * 4 : 0, s, v, sc.rect, sc.sub_start, sc.tile_fill,
+                           sc.keys, use_lds);
     }
     L2D_CHECK_LAUNCH();
     {
         L2D_PROF("tile_sort_small", s);
-        hipLaunchKernelGGL((tile_sort_kernel<2048, true>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
-                           st.header, sc.keys, st.point_list);
+        hipLaunchKernelGGL((tile_sort_kernel<false>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
+                           st.header, st.tile_order, sc.keys, st.point_list);
     }
     L2D_CHECK_LAUNCH();
     {
         L2D_PROF("tile_sort_large", s);
-        hipLaunchKernelGGL((tile_sort_kernel<8192, false>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
-                           st.header, sc.keys, st.point_list);
+        hipLaunchKernelGGL((tile_sort_kernel<true>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
+                           st.header, st.tile_order, sc.keys, st.point_list);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

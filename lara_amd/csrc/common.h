@@ -12,6 +12,7 @@
 #define FILTER_INV_SQUARE 2.0f
 #define CUTOFF 3.0f
 #define GEOM_F 20          // floats per surfel record in the state buffer
+#define L2D_SLICES 16            // per-tile counters are split 16 ways to shorten same-address atomic chains
 #define L2D_LDS_HIST_TILES 8192  // per-workgroup LDS tile histogram up to this many tiles (32 KB)
 #define GRAD_F 20          // floats per surfel in the backward accumulator (18 used)
 
@@ -36,9 +37,10 @@ struct StateView {  // typed pointers into the caller's `state` buffer
 };
 
 struct ScratchView {
-    uint32_t *tile_count;  // [tiles]
-    uint32_t *tile_fill;   // [tiles]
-    ushort4 *rect;         // [P]
+    uint32_t *tile_count;  // [tiles][L2D_SLICES]  population per (tile, surfel-block slice)
+    uint32_t *tile_fill;   // [tiles][L2D_SLICES]  scatter cursors
+    uint32_t *sub_start;   // [tiles][L2D_SLICES]  first slot of each (tile, slice) sub-segment
+    uint4 *rect;           // [P] tile rectangle (4 x u16 in .x,.y) + depth bits (.z)
     uint64_t *keys;        // [cap]  (depth bits << 32) | surfel id, grouped per tile, unsorted
     float *grad;           // [P][GRAD_F] backward accumulators (aliases keys/rect region)
 };
@@ -60,14 +62,15 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->total = o;
 }
 
-struct ScratchLayout { int64_t tile_count, tile_fill, rect, keys, grad, total; };
+struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, rect, keys, grad, total; };
 static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     int64_t o = 0;
-    L->tile_count = o;  o = align_up(o + tiles * 4, 256);
-    L->tile_fill = o;   o = align_up(o + tiles * 4, 256);
+    L->tile_count = o;  o = align_up(o + tiles * 4 * L2D_SLICES, 256);
+    L->tile_fill = o;   o = align_up(o + tiles * 4 * L2D_SLICES, 256);
+    L->sub_start = o;   o = align_up(o + tiles * 4 * L2D_SLICES, 256);
     const int64_t fwd0 = o;
-    L->rect = o;        o = align_up(o + (int64_t)P * 8, 256);
+    L->rect = o;        o = align_up(o + (int64_t)P * 16, 256);
     L->keys = o;        o = align_up(o + cap * 8, 256);
     const int64_t fwd_end = o;
     L->grad = fwd0;     // backward reuses the forward-only region

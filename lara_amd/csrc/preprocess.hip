@@ -255,11 +255,12 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
                       const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
                       const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
                       const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
-                      float4 *__restrict__ cullbox, ushort4 *__restrict__ rect_out,
+                      float4 *__restrict__ cullbox, uint4 *__restrict__ rect_out,
                       uint32_t *__restrict__ tile_count, int32_t *__restrict__ radii,
                       const int use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slice = blockIdx.x % L2D_SLICES;
     if (use_lds) {
         for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) hist[t] = 0;
         __syncthreads();
@@ -268,18 +269,21 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     if (idx < v.P) {
         r = surfel_forward<DEG>(v, idx, means3D, shs, colors_precomp, opacities, scales, rotations,
                                 transmat_precomp, geom, cullbox, radii);
-        rect_out[idx] = r;
+        // tile rectangle + depth key bits, 16 B per surfel, for the scatter pass
+        const float depth = (r.z > r.x && r.w > r.y) ? geom[(size_t)idx * 5 + 3].w : 0.f;
+        rect_out[idx] = make_uint4((uint32_t)r.x | ((uint32_t)r.y << 16), (uint32_t)r.z | ((uint32_t)r.w << 16),
+                                   __float_as_uint(depth), 0u);
     }
     for (int y = r.y; y < r.w; y++)
         for (int x = r.x; x < r.z; x++) {
             if (use_lds) atomicAdd(&hist[y * v.gx + x], 1u);
-            else __hip_atomic_fetch_add(&tile_count[y * v.gx + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(&tile_count[(y * v.gx + x) * L2D_SLICES + slice], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     if (use_lds) {
         __syncthreads();
         for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) {
             const uint32_t c = hist[t];
-            if (c) __hip_atomic_fetch_add(&tile_count[t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c) __hip_atomic_fetch_add(&tile_count[t * L2D_SLICES + slice], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
