@@ -54,9 +54,10 @@ def parse():
 
 def build_batch(args, device, rank):
     from lara_amd import cameras, synthetic, GaussianRasterizationSettings
+    from lara_amd import dp
     scenes = []
-    for i in range(args.scenes):
-        sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=1000 * rank + i, device=device)
+    for seed in dp.scene_seeds(rank, args.scenes):
+        sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=seed, device=device)
         scenes.append({k: v.requires_grad_(True) for k, v in sc.items()})
     cams = cameras.make_cameras(cameras.turntable_c2w(args.views), args.res, args.res, 0.75, 0.75,
                                 1.906 - 0.8, 1.906 + 0.8, device=device)
@@ -143,32 +144,35 @@ def measure_roofline(scenes, settings, gc, ga, args):
 
 
 def cpu_baseline(args):
-    """The CPU oracle (fp32 restatement, OpenMP over tiles) on a bounded sample: ONE frame
-    (forward + backward of view 0 of scene 0) of the same workload."""
+    """The CPU oracle (fp32 restatement, OpenMP over tiles) on a bounded sample of the same
+    workload: the 8 views of scene 0, forward + backward each (about 10-30 s of CPU work)."""
     import numpy as np
     import oracle
     from lara_amd import cameras, synthetic
     sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=0)
     act = {k: v.numpy() for k, v in synthetic.activate(sc).items()}
     res = args.cpu_sample_res
-    cam = cameras.make_cameras(cameras.turntable_c2w(args.views)[:1], res, res, 0.75, 0.75,
-                               1.906 - 0.8, 1.906 + 0.8)[0]
-    view = oracle.View(res, res, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0,
-                       cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 1,
-                       cam.camera_center.numpy())
+    cams = cameras.make_cameras(cameras.turntable_c2w(args.views), res, res, 0.75, 0.75,
+                                1.906 - 0.8, 1.906 + 0.8)
     oracle.build()
     g = np.random.default_rng(0)
     dc = g.normal(size=(3, res, res)).astype(np.float32)
     da = g.normal(size=(7, res, res)).astype(np.float32)
     t0 = time.perf_counter()
-    r = oracle.forward(view, act["means3D"], act["opacities"], shs=act["shs"], scales=act["scales"],
-                       rotations=act["rotations"])
-    oracle.backward(r, dc, da)
+    D = 0
+    for cam in cams:
+        view = oracle.View(res, res, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0,
+                           cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 1,
+                           cam.camera_center.numpy())
+        r = oracle.forward(view, act["means3D"], act["opacities"], shs=act["shs"], scales=act["scales"],
+                           rotations=act["rotations"])
+        oracle.backward(r, dc, da)
+        D = r.num_rendered
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame (fwd+bwd, view 0 of scene 0, {res}x{res}, P={act['means3D'].shape[0]}, "
-                      f"D={r.num_rendered}) with the OpenMP fp32 oracle; {dt:.2f} s"}
+    return {"value": round(len(cams) / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{len(cams)} frames (fwd+bwd, the {len(cams)} views of scene 0, {res}x{res}, "
+                      f"P={act['means3D'].shape[0]}, D~{D}) with the OpenMP fp32 oracle; {dt:.2f} s"}
 
 
 def main():
@@ -190,16 +194,15 @@ def main():
     rasterizer.load_library()
     scenes, settings, gc, ga = build_batch(args, device, rank)
 
+    from lara_amd import dp
     comm_stream = torch.cuda.Stream(device) if world > 1 else None
     grad_buf = torch.zeros(ENCODER_PARAMS, device=device) if world > 1 else None
-    BUCKET = 25 * 1024 * 1024 // 4
 
     def full_step():
         if world > 1:  # DDP-style bucketed all-reduce, overlapped with the raster work on a side stream
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                for o in range(0, grad_buf.numel(), BUCKET):
-                    dist.all_reduce(grad_buf[o:o + BUCKET])
+                dp.bucketed_all_reduce(grad_buf)
         step(scenes, settings, gc, ga)
         if world > 1:
             torch.cuda.current_stream().wait_stream(comm_stream)
@@ -220,9 +223,7 @@ def main():
     dt = time.perf_counter() - t0
     rasterizer.check_pending(block=True)
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = dp.max_over_ranks(dt, device)
 
     frames_per_step = args.scenes * args.views * world
     out = {
