@@ -130,8 +130,8 @@ int lara2dgs_mark_visible(int32_t P, const float *means3D, const float *viewmatr
  * bytes; duration in milliseconds -> `ms`), clears the log and returns the number written. */
 int lara2dgs_profile_enable(int on);
 /* Device self-tests of building blocks whose correctness rests on gfx950 lane semantics.
- * which = 0: packed butterfly reduction; in = float[64][21] (lane major), out = float[22] zeroed
- * by the caller: out[k] = sum over lanes of in[.][k], out[21] = 21 (number of writer lanes). */
+ * which = 0: DPP quad reduce-scatter of the backward composite; in = float[64][22] (lane major),
+ * out = float[16][22]: out[q][k] = sum over the 4 lanes of quad q of in[.][k]. */
 int lara2dgs_selftest(int which, const float *in, float *out, void *stream);
 int lara2dgs_profile_collect(char *names, int names_len, float *ms, int max_entries);
 

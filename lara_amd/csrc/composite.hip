@@ -6,31 +6,33 @@
 // (colour = C + T*bg; allmap = [sum w*depth, 1-T, sum w*normal (view space), median depth,
 // distortion]).
 //
-// Structure (both directions).  One 256-thread workgroup per 16x16 tile; each of its four wave64s
-// owns an 8x8 pixel quadrant (lane = pixel).  A tile's list is consumed 256 entries at a time in
-// two phases:
+// Structure (both directions).  One 256-thread workgroup per 16x16 tile (the binning contract),
+// four wave64s = four 8x8 quadrants.  Inside a wave every group of 4 lanes (a DPP quad) owns a
+// 2x2 pixel block and walks ITS OWN candidate list ("quad-SIMT"): at LaRa's statistics a surfel
+// reaches alpha >= 1/255 on ~14 pixels of a tile, so with one candidate stream per wave only 11 of
+// 64 lanes did useful work; per-quad streams need 2.5x fewer wave iterations.
+// A tile's list is consumed 256 entries at a time in two phases:
 //   phase S  (thread = list entry)  gather the surfel record through the sorted id list, turn it
 //            into TILE-RELATIVE coefficients -- the ray/surfel intersection p = k x l is affine in
 //            the pixel offset: p(lx,ly) = A + lx*B + ly*C with A = k0 x l0, B = Tw x l0,
-//            C = k0 x Tw, k0/l0 = the reference's k/l at the tile origin -- test the surfel's
-//            conservative alpha>=1/255 bounding box against the four quadrants (4-bit mask), and
-//            park everything in LDS.  All of this costs 1/64 of a wave-instruction per entry.
-//   phase P  (lane = pixel)  each wave ballots the quadrant bits of 64 entries into a mask and
-//            walks only the set bits; every lane reads the same LDS record (broadcast).  Entries a
-//            quadrant cannot see cost nothing; the reference evaluates every pixel of the tile
-//            against every entry.  Skipping is exact: an entry is skipped only if the reference
-//            would have skipped it for all 64 pixels (alpha < 1/255), and list positions
-//            (`contributor` numbering) are kept.
-// Backward adds: per entry, 21 per-pixel partial derivatives (in coefficient space) are reduced
-// across the wave with a packed butterfly (v_permlane32_swap / v_permlane16_swap / DPP: ~55 VALU
-// ops instead of 126 for 21 separate wave reductions), accumulated per tile in LDS, transformed to
-// dL/dT etc. by the entry's own thread (phase S2) and only then added to HBM: one atomic per
-// (tile, surfel, component) instead of one per (pixel, surfel, component).
+//            C = k0 x Tw, k0/l0 = the reference's k/l at the tile origin -- and rasterise the
+//            surfel's conservative alpha>=1/255 box onto the tile's 8x8 grid of 2x2 blocks (64-bit
+//            mask).  Costs 1/64 of a wave-instruction per entry.
+//   phase P  (lane = pixel)  per 64 entries each wave transposes the (entry x block) bit matrix
+//            with 16 ballots, every quad keeps the mask of its block and walks only its set bits;
+//            records are read from LDS with per-quad addresses.  Skipping is exact: an entry is
+//            skipped for a block only if the reference would have skipped it for all 4 pixels
+//            (alpha < 1/255), and list positions (`contributor` numbering) are kept.
+// Backward adds: the 22 per-pixel partial derivatives of an entry (coefficient space) are reduced
+// over the quad with a 2-step DPP reduce-scatter, accumulated per tile in LDS (ds_add_f32),
+// transformed to dL/dT etc. by the entry's own thread (phase S2) and only then added to HBM: one
+// atomic per (tile, surfel, component) instead of one per (pixel, surfel, component).
 #include "common.h"
 
 namespace {
 
-constexpr int CHUNK = 256;
+constexpr int FWD_CHUNK = 256;  // list entries staged per round, forward
+constexpr int BWD_CHUNK = 128;  // backward (its LDS also holds the f64 accumulators)
 constexpr int REC4 = 6;        // float4 planes per staged entry (see stage_entry)
 constexpr int ACC_STRIDE = 23; // 21 sums + touch counter, odd stride -> conflict-free LDS banks
 
@@ -42,7 +44,9 @@ __device__ __forceinline__ void cross3(const float a[3], const float b[3], float
 
 // phase S: thread `e` stages list entry `pos` (if valid) as tile-relative coefficients
 //   plane 0: A.xyz B.x   plane 1: B.yz C.xy   plane 2: C.z dx0 dy0 Tw.x
-//   plane 3: Tw.yz opacity qmask   plane 4: normal.xyz r   plane 5: g b - -
+//   plane 3: Tw.yz opacity mask_lo   plane 4: normal.xyz r   plane 5: g b mask_hi -
+//   mask bit (gy*8 + gx) <=> the 2x2 block (gx, gy) of the tile may see the surfel
+template <int CHUNK>
 __device__ __forceinline__ void stage_entry(const uint32_t *__restrict__ point_list,
                                             const float4 *__restrict__ geom,
                                             const float4 *__restrict__ cullbox, const uint32_t pos,
@@ -50,7 +54,7 @@ __device__ __forceinline__ void stage_entry(const uint32_t *__restrict__ point_l
                                             float4 *rec, uint32_t *ids) {
     const int e = threadIdx.x;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
-    uint32_t qmask = 0, id = 0;
+    uint32_t mask_lo = 0, mask_hi = 0, id = 0;
     if (valid) {
         id = point_list[pos];
         const float4 *g = geom + (size_t)id * 5;
@@ -63,16 +67,25 @@ __device__ __forceinline__ void stage_entry(const uint32_t *__restrict__ point_l
         cross3(k0, l0, A);
         cross3(Tw, l0, B);
         cross3(k0, Tw, C);
-        const bool xl = cb.x <= X0 + 7.f && cb.y >= X0, xr = cb.x <= X0 + 15.f && cb.y >= X0 + 8.f;
-        const bool yt = cb.z <= Y0 + 7.f && cb.w >= Y0, yb = cb.z <= Y0 + 15.f && cb.w >= Y0 + 8.f;
-        qmask = (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) |
-                ((uint32_t)(xr && yb) << 3);
+        // block gx covers pixels X0+2gx, X0+2gx+1: overlap <=> minx <= X0+2gx+1 and maxx >= X0+2gx
+        const int gx0 = (int)ceilf(fminf(fmaxf((cb.x - X0 - 1.f) * 0.5f, 0.f), 8.f));
+        const int gx1 = (int)floorf(fminf(fmaxf((cb.y - X0) * 0.5f, -1.f), 7.f));
+        const int gy0 = (int)ceilf(fminf(fmaxf((cb.z - Y0 - 1.f) * 0.5f, 0.f), 8.f));
+        const int gy1 = (int)floorf(fminf(fmaxf((cb.w - Y0) * 0.5f, -1.f), 7.f));
+        if (gx0 <= gx1 && gy0 <= gy1) {
+            const uint32_t cols = ((1u << (gx1 - gx0 + 1)) - 1u) << gx0;  // 8 bits
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (r >= gy0 && r <= gy1) mask_lo |= cols << (8 * r);
+                if (r + 4 >= gy0 && r + 4 <= gy1) mask_hi |= cols << (8 * r);
+            }
+        }
         r0 = make_float4(A[0], A[1], A[2], B[0]);
         r1 = make_float4(B[1], B[2], C[0], C[1]);
         r2 = make_float4(C[2], g2.y - X0, g2.z - Y0, Tw[0]);
-        r3 = make_float4(Tw[1], Tw[2], g2.w, __uint_as_float(qmask));
+        r3 = make_float4(Tw[1], Tw[2], g2.w, __uint_as_float(mask_lo));
         r4 = make_float4(g3.x, g3.y, g3.z, g4.x);
-        r5 = make_float4(g4.y, g4.z, 0.f, 0.f);
+        r5 = make_float4(g4.y, g4.z, __uint_as_float(mask_hi), 0.f);
     }
     rec[0 * CHUNK + e] = r0; rec[1 * CHUNK + e] = r1; rec[2 * CHUNK + e] = r2;
     rec[3 * CHUNK + e] = r3; rec[4 * CHUNK + e] = r4; rec[5 * CHUNK + e] = r5;
@@ -85,6 +98,7 @@ struct Hit {
 };
 
 // phase P: evaluate staged entry j for this lane's pixel (lx, ly = offsets inside the tile)
+template <int CHUNK>
 __device__ __forceinline__ bool eval_entry(const float4 *rec, const int j, const float lx,
                                            const float ly, Hit &h, float Tw[3], float &opa) {
     const float4 r0 = rec[0 * CHUNK + j], r1 = rec[1 * CHUNK + j], r2 = rec[2 * CHUNK + j],
@@ -107,6 +121,20 @@ __device__ __forceinline__ bool eval_entry(const float4 *rec, const int j, const
     return (pz != 0.0f) & (h.depth >= NEAR_N) & !(power > 0.0f) & !(h.alpha < 1.0f / 255.0f);
 }
 
+// Transpose the (64 entries x 16 blocks of this wave) bit matrix: 16 ballots, then every lane keeps
+// the 64-entry mask of its own quad.  `bm` = this lane's entry's 32-bit half mask (the half that
+// holds the wave's quadrant rows), `bit0` = bit index of the wave's first block inside that half.
+__device__ __forceinline__ unsigned long long quad_masks(const uint32_t bm, const int qx4, const int grp) {
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        const int bit = (g >> 2) * 8 + qx4 + (g & 3);
+        const unsigned long long b = __ballot((bm >> bit) & 1u);
+        m = (grp == g) ? b : m;
+    }
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -117,6 +145,7 @@ struct FwdPixel {
     uint32_t last_contributor = 0, median_contributor = 0;
     bool done = false;
 
+    template <int CHUNK>
     __device__ __forceinline__ void blend(const float4 *rec, const int j, const int base, bool valid,
                                           const Hit &h) {
         valid = valid && !done;
@@ -151,11 +180,14 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      float *__restrict__ out_color, float *__restrict__ out_allmap) {
+    constexpr int CHUNK = FWD_CHUNK;
     __shared__ float4 rec[REC4 * CHUNK];
     const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lxi = (wave & 1) * 8 + (lane & 7), lyi = (wave >> 1) * 8 + (lane >> 3);
+    const int grp = lane >> 2;  // quad = 2x2 pixel block; 4x4 quads per 8x8 quadrant
+    const int lxi = (wave & 1) * 8 + (grp & 3) * 2 + (lane & 1);
+    const int lyi = (wave >> 1) * 8 + (grp >> 2) * 2 + ((lane >> 1) & 1);
     const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
     const bool inside = pxi < v.W && pyi < v.H;
     const size_t HW = (size_t)v.H * v.W;
@@ -182,34 +214,42 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 
     for (int base = 0; base < total; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
-        stage_entry(point_list, geom, cullbox, range.x + base + threadIdx.x,
-                    base + (int)threadIdx.x < total, X0, Y0, rec, nullptr);
+        stage_entry<CHUNK>(point_list, geom, cullbox, range.x + base + threadIdx.x,
+                           base + (int)threadIdx.x < total, X0, Y0, rec, nullptr);
         __syncthreads();
         if (__ballot(!px.done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
 #pragma unroll 1
         for (int sub = 0; sub < CHUNK; sub += 64) {
             if (base + sub >= total) break;
-            const uint32_t qm = __float_as_uint(rec[3 * CHUNK + sub + lane].w);
-            unsigned long long m = __ballot((qm >> wave) & 1u);
-            // two list entries per trip: their evaluations are independent (ILP), blending stays
-            // strictly in list order
-            while (m) {
-                const int j0 = sub + __builtin_ctzll(m);
-                m &= m - 1;
-                const bool two = m != 0ull;
-                const int j1 = two ? sub + __builtin_ctzll(m) : j0;
-                m &= m - 1;  // no-op when m == 0
-                Hit h0, h1;
-                float Tw0[3], Tw1[3], opa0, opa1;
-                const bool e0 = eval_entry(rec, j0, lx, ly, h0, Tw0, opa0);
-                const bool e1 = eval_entry(rec, j1, lx, ly, h1, Tw1, opa1) && two;
-                if (v.dbg & 4u) {  // statistics: candidates, valid (pixel, entry) pairs, live pairs
-                    if (lane == 0) atomicAdd(&dbg_hdr[4], two ? 2u : 1u);
-                    atomicAdd(&dbg_hdr[5], (unsigned)e0 + (unsigned)e1);
-                    atomicAdd(&dbg_hdr[6], (unsigned)(e0 && !px.done) + (unsigned)(e1 && !px.done));
+            const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + sub + lane;
+            const uint32_t bm = __float_as_uint((wave >> 1) ? mrec->z : mrec->w);
+            if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) == 0ull) continue;
+            const unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+                const int jb = sub + 32 * half;
+                // each quad pops its own next entries; two per trip (independent evaluations),
+                // blended strictly in list order
+                while (__ballot(mm != 0u) != 0ull) {
+                    const bool has0 = mm != 0u;
+                    const int j0 = jb + (has0 ? __builtin_ctz(mm) : 0);
+                    mm &= mm - 1u;
+                    const bool has1 = mm != 0u;
+                    const int j1 = jb + (has1 ? __builtin_ctz(mm) : 0);
+                    mm &= mm - 1u;  // stays 0 when already empty
+                    Hit h0, h1;
+                    float Tw0[3], Tw1[3], opa0, opa1;
+                    const bool e0 = eval_entry<CHUNK>(rec, j0, lx, ly, h0, Tw0, opa0) && has0;
+                    const bool e1 = eval_entry<CHUNK>(rec, j1, lx, ly, h1, Tw1, opa1) && has1;
+                    if (v.dbg & 4u) {  // statistics: quad candidates, valid (pixel, entry) pairs
+                        atomicAdd(&dbg_hdr[4], ((lane & 3) == 0) ? (unsigned)has0 + (unsigned)has1 : 0u);
+                        atomicAdd(&dbg_hdr[5], (unsigned)e0 + (unsigned)e1);
+                        if (lane == 0) atomicAdd(&dbg_hdr[6], 1u);
+                    }
+                    px.blend<CHUNK>(rec, j0, base, e0, h0);
+                    px.blend<CHUNK>(rec, j1, base, e1, h1);
                 }
-                px.blend(rec, j0, base, e0, h0);
-                px.blend(rec, j1, base, e1, h1);
             }
         }
     }
@@ -235,68 +275,31 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 }
 
 // ------------------------------------------------------------------------------------------------
-// packed butterfly reduction of 21 per-lane values over the 64 lanes of a wave
+// quad (4-lane) reduce-scatter of 22 per-lane values with DPP quad_perm
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float f_of(unsigned u) { return __uint_as_float(u); }
-__device__ __forceinline__ unsigned u_of(float f) { return __float_as_uint(f); }
-
-// lanes 0..31 <- a[l] + a[l+32] ; lanes 32..63 <- b[l-32] + b[l]
-__device__ __forceinline__ float pair32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(u_of(a), u_of(b), false, false);
-    return f_of(r[0]) + f_of(r[1]);
-}
-// rows 0,2 <- a summed over (row, row+1) ; rows 1,3 <- b summed over (row-1, row)
-__device__ __forceinline__ float pair16(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(u_of(a), u_of(b), false, false);
-    return f_of(r[0]) + f_of(r[1]);
-}
 template <int CTRL>
 __device__ __forceinline__ float dpp_full(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
 }
-// lanes with bit3 clear <- a[l] + a[l^8] ; bit3 set <- b[l] + b[l^8]
-__device__ __forceinline__ float pair8(float a, float b, bool bit3) {
-    const float t = a + dpp_full<0x128>(a), u = b + dpp_full<0x128>(b);  // row_ror:8
-    return bit3 ? u : t;
-}
-// lanes with bit2 clear <- a[l] + a[l+4] ; bit2 set <- b[l] + b[l-4]
-__device__ __forceinline__ float pair4(float a, float b, bool bit2) {
-    int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0,2
-    y = __builtin_amdgcn_update_dpp(y, __float_as_int(b), 0x114, 0xf, 0xa, false);      // row_shr:4 -> banks 1,3
-    return (bit2 ? b : a) + __int_as_float(y);
-}
-// lanes with bit1 clear <- a[l] + a[l^2] ; bit1 set <- b[l] + b[l^2]
-__device__ __forceinline__ float pair2(float a, float b, bool bit1) {
-    const float t = a + dpp_full<0x4E>(a), u = b + dpp_full<0x4E>(b);  // quad_perm [2,3,0,1]
-    return bit1 ? u : t;
-}
-__device__ __forceinline__ float fold1(float a) { return a + dpp_full<0xB1>(a); }  // quad_perm [1,0,3,2]
-
-// After the call, lane l holds the full 64-lane sum of value slot_of_lane(l) (see below).
-__device__ __forceinline__ float butterfly21(const float v[21], const int lane) {
-    float r[11];
+// step 1 (xor 1): lane keeps the 11 values of its own parity; step 2 (xor 2): keeps every second of
+// those.  Result: r[i] = quad sum of g[4i + (lane&3)], i = 0..4; r[5] = quad sum of g[20 + (lane&1)]
+// (valid in lanes with bit 1 clear).
+__device__ __forceinline__ void quad_reduce_scatter(const float g[22], float r[6], const int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float v1[11];
 #pragma unroll
-    for (int i = 0; i < 10; i++) r[i] = pair32(v[2 * i], v[2 * i + 1]);
-    r[10] = pair32(v[20], v[20]);
-    float q[6];
+    for (int i = 0; i < 11; i++) {
+        const float mine = b0 ? g[2 * i + 1] : g[2 * i];
+        const float send = b0 ? g[2 * i] : g[2 * i + 1];
+        v1[i] = mine + dpp_full<0xB1>(send);  // quad_perm [1,0,3,2]
+    }
 #pragma unroll
-    for (int i = 0; i < 5; i++) q[i] = pair16(r[2 * i], r[2 * i + 1]);
-    q[5] = pair16(r[10], r[10]);
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-    const float o0 = pair8(q[0], q[1], b3), o1 = pair8(q[2], q[3], b3), o2 = pair8(q[4], q[5], b3);
-    const float n0 = pair4(o0, o1, b2), n1 = pair4(o2, o2, b2);
-    return fold1(pair2(n0, n1, b1));
-}
-// which of the 21 values lane l ends up with (-1: duplicate holder, must not write)
-__device__ __forceinline__ int slot_of_lane(const int l) {
-    if (l & 1) return -1;
-    const int b1 = (l >> 1) & 1, b2 = (l >> 2) & 1, b3 = (l >> 3) & 1, b4 = (l >> 4) & 1, b5 = (l >> 5) & 1;
-    int o;  // index among o0..o2
-    if (b1) { if (b2) return -1; o = 2; } else o = b2;
-    const int q = 2 * o + b3;  // index among q0..q5
-    if (q == 5) return (b4 | b5) ? -1 : 20;
-    const int r = 2 * q + b4;  // index among r0..r9
-    return 2 * r + b5;
+    for (int i = 0; i < 5; i++) {
+        const float mine = b1 ? v1[2 * i + 1] : v1[2 * i];
+        const float send = b1 ? v1[2 * i] : v1[2 * i + 1];
+        r[i] = mine + dpp_full<0x4E>(send);  // quad_perm [2,3,0,1]
+    }
+    r[5] = v1[10] + dpp_full<0x4E>(v1[10]);
 }
 
 __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
@@ -313,15 +316,20 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                      float *__restrict__ grad) {
+    constexpr int CHUNK = BWD_CHUNK;
+    // f64 accumulators: ds_add_f64 runs at 18 cycles per wave instruction on gfx950, ds_add_f32 at
+    // 169 (measured, tools/ubench/lds_atomic.hip) -- and the tile sums get double accumulation
     __shared__ float4 rec[REC4 * CHUNK];
-    __shared__ float acc[CHUNK * ACC_STRIDE];  // [entry][slot]
+    __shared__ double acc[CHUNK * ACC_STRIDE];  // [entry][slot]
     __shared__ uint32_t s_id[CHUNK];
     __shared__ uint32_t s_maxc;
     if (header[1]) return;
     const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lxi = (wave & 1) * 8 + (lane & 7), lyi = (wave >> 1) * 8 + (lane >> 3);
+    const int grp = lane >> 2, q4 = lane & 3;
+    const int lxi = (wave & 1) * 8 + (grp & 3) * 2 + (lane & 1);
+    const int lyi = (wave >> 1) * 8 + (grp >> 2) * 2 + ((lane >> 1) & 1);
     const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
     const bool inside = pxi < v.W && pyi < v.H;
     const size_t HW = (size_t)v.H * v.W;
@@ -329,7 +337,6 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const float lx = (float)lxi, ly = (float)lyi;
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
     const uint2 range = ranges[tile];
-    const int slot = slot_of_lane(lane);
 
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
@@ -369,103 +376,120 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         const int lo = c * CHUNK;
         const int cnt = min(CHUNK, total - lo);
         __syncthreads();  // previous chunk's phase S2 is done with rec / acc / s_id
-        stage_entry(point_list, geom, cullbox, range.x + lo + threadIdx.x, (int)threadIdx.x < cnt,
-                    X0, Y0, rec, s_id);
-#pragma unroll
-        for (int k = 0; k < ACC_STRIDE; k++) acc[threadIdx.x * ACC_STRIDE + k] = 0.f;
+        if ((int)threadIdx.x < CHUNK)
+            stage_entry<CHUNK>(point_list, geom, cullbox, range.x + lo + threadIdx.x,
+                               (int)threadIdx.x < cnt, X0, Y0, rec, s_id);
+        for (int k = threadIdx.x; k < CHUNK * ACC_STRIDE; k += 256) acc[k] = 0.0;
         __syncthreads();
 
 #pragma unroll 1
         for (int sub = ((cnt - 1) >> 6) << 6; sub >= 0; sub -= 64) {
-            const uint32_t qm = __float_as_uint(rec[3 * CHUNK + sub + lane].w);
-            unsigned long long m = __ballot((qm >> wave) & 1u);
-            while (m) {
-                const int b = 63 - __builtin_clzll(m);
-                m &= ~(1ull << b);
-                const int j = sub + b;
-                const uint32_t contributor = (uint32_t)(lo + j);  // 0-based list position
-                Hit h;
-                float Tw[3], opa;
-                const bool active = eval_entry(rec, j, lx, ly, h, Tw, opa) && contributor < last_contributor;
-                if (__ballot(active) == 0ull) continue;
+            const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + sub + lane;
+            const uint32_t bm = __float_as_uint((wave >> 1) ? mrec->z : mrec->w);
+            if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) == 0ull) continue;
+            const unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
+#pragma unroll 1
+            for (int half = 1; half >= 0; half--) {
+                uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+                const int jb = sub + 32 * half;
+                while (__ballot(mm != 0u) != 0ull) {  // every quad pops its own last entry
+                    const bool has = mm != 0u;
+                    const int b = has ? 31 - __builtin_clz(mm) : 0;
+                    mm &= ~(1u << b);  // mm == 0 stays 0 (b = 0, bit 0 clear)
+                    const int j = jb + b;
+                    const uint32_t contributor = (uint32_t)(lo + j);  // 0-based list position
+                    Hit h;
+                    float Tw[3], opa;
+                    const bool active = eval_entry<CHUNK>(rec, j, lx, ly, h, Tw, opa) && has && contributor < last_contributor;
+                    const unsigned long long amask = __ballot(active);
+                    if (amask == 0ull) continue;
 
-                float g[21];
+                    float g[22];
 #pragma unroll
-                for (int k = 0; k < 21; k++) g[k] = 0.f;
-                if (active) {
-                    const float4 r4 = rec[4 * CHUNK + j], r5 = rec[5 * CHUNK + j];
-                    const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
-                    const float alpha = h.alpha, G = h.G, c_d = h.depth;
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * inv_1ma;
-                    const float w = alpha * T;
-                    float dL_dalpha = 0.0f;
+                    for (int k = 0; k < 22; k++) g[k] = 0.f;
+                    if (active) {
+                        const float4 r4 = rec[4 * CHUNK + j], r5 = rec[5 * CHUNK + j];
+                        const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
+                        const float alpha = h.alpha, G = h.G, c_d = h.depth;
+                        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                        T = T * inv_1ma;
+                        const float w = alpha * T;
+                        float dL_dalpha = 0.0f;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                        last_color[ch] = rgb[ch];
-                        dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
-                        g[18 + ch] = w * dpix[ch];
-                    }
-                    float dL_dz = 0.0f, dL_dweight = 0.0f;
-                    const float inv_cd = __builtin_amdgcn_rcpf(c_d);
-                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
-                    const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
-                    if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
-                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
-                    dL_dalpha += dL_dweight - last_dL_dT;
-                    last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                    dL_dz += dL_dmd * dmd_dd;
+                        for (int ch = 0; ch < 3; ch++) {
+                            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                            last_color[ch] = rgb[ch];
+                            dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
+                            g[18 + ch] = w * dpix[ch];
+                        }
+                        float dL_dz = 0.0f, dL_dweight = 0.0f;
+                        const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                        const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
+                        const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
+                        if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
+                        dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
+                        dL_dalpha += dL_dweight - last_dL_dT;
+                        last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                        dL_dz += dL_dmd * dmd_dd;
 
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                    last_depth = c_d;
-                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
+                        accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                        last_depth = c_d;
+                        dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                        accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                        dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
-                        last_normal[ch] = nrm[ch];
-                        dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
-                        g[14 + ch] = w * dnrm[ch];
-                    }
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                        for (int ch = 0; ch < 3; ch++) {
+                            accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                            last_normal[ch] = nrm[ch];
+                            dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
+                            g[14 + ch] = w * dnrm[ch];
+                        }
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
 
-                    const float dL_dG = opa * dL_dalpha;
-                    dL_dz += w * dL_ddepth;
-                    // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
-                    g[9] = dL_dz * h.sx; g[10] = dL_dz * h.sy; g[11] = dL_dz;
-                    if (h.use3d) {
-                        const float dL_dsx = dL_dG * -G * h.sx + dL_dz * Tw[0];
-                        const float dL_dsy = dL_dG * -G * h.sy + dL_dz * Tw[1];
-                        const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
-                        const float dpz = -(dpx * h.sx + dpy * h.sy);
-                        g[0] = dpx; g[1] = dpy; g[2] = dpz;
-                        g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
-                        g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
-                    } else {
-                        g[12] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddx);
-                        g[13] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddy);
+                        const float dL_dG = opa * dL_dalpha;
+                        dL_dz += w * dL_ddepth;
+                        // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
+                        g[9] = dL_dz * h.sx; g[10] = dL_dz * h.sy; g[11] = dL_dz;
+                        if (h.use3d) {
+                            const float dL_dsx = dL_dG * -G * h.sx + dL_dz * Tw[0];
+                            const float dL_dsy = dL_dG * -G * h.sy + dL_dz * Tw[1];
+                            const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
+                            const float dpz = -(dpx * h.sx + dpy * h.sy);
+                            g[0] = dpx; g[1] = dpy; g[2] = dpz;
+                            g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
+                            g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
+                        } else {
+                            g[12] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddx);
+                            g[13] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddy);
+                        }
+                        g[17] = G * dL_dalpha;
+                        g[21] = 1.0f;  // touched marker
                     }
-                    g[17] = G * dL_dalpha;
+                    if (v.dbg & 2u) { float z = 0.f; for (int k = 0; k < 22; k++) z += g[k]; if (z == 123.456f) acc[0] = z; continue; }
+                    // quad reduce-scatter: lane q4 of the quad ends with the sums of values
+                    // k = 4i + q4 (i = 0..4) in r[i], and lanes 0/1 with value 20/21 in r[5]
+                    float r[6];
+                    quad_reduce_scatter(g, r, lane);
+                    if (((amask >> (lane & ~3)) & 0xfull) && !(v.dbg & 16u)) {  // some lane of my quad was active
+                        double *dst = acc + j * ACC_STRIDE + q4;
+#pragma unroll
+                        for (int i = 0; i < 5; i++) atomicAdd(dst + 4 * i, (double)r[i]);  // ds_add_f64
+                        if (q4 < 2) atomicAdd(dst + 20, (double)r[5]);
+                    }
                 }
-                if (v.dbg & 2u) { float z = 0.f; for (int k = 0; k < 21; k++) z += g[k]; if (z == 123.456f) acc[0] = z; continue; }
-                const float s = butterfly21(g, lane);
-                if (slot >= 0) atomicAdd(&acc[j * ACC_STRIDE + slot], s);     // ds_add_f32, 21 lanes
-                if (lane == 1) atomicAdd(&acc[j * ACC_STRIDE + 21], 1.0f);    // touched marker
             }
         }
         __syncthreads();
 
         // phase S2: thread e turns its entry's 21 coefficient-space sums into dL/d(Tu,Tv,Tw,...)
         const int e = threadIdx.x;
-        if (e < cnt && acc[e * ACC_STRIDE + 21] > 0.f && !(v.dbg & 1u)) {
+        if (e < cnt && acc[e * ACC_STRIDE + 21] > 0.0 && !(v.dbg & 1u)) {
             float sacc[21];
 #pragma unroll
-            for (int k = 0; k < 21; k++) sacc[k] = acc[e * ACC_STRIDE + k];
+            for (int k = 0; k < 21; k++) sacc[k] = (float)acc[e * ACC_STRIDE + k];
             const uint32_t id = s_id[e];
             const float4 *gm = geom + (size_t)id * 5;
             const float4 g0 = gm[0], g1 = gm[1], g2 = gm[2];
@@ -497,16 +521,16 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     }
 }
 
-// butterfly self-test: in [64][21] (lane major) -> out[0..20] sums, out[21] = number of writer lanes
+// reduce-scatter self-test: in [64][22] (lane major) -> out [16 quads][22] quad sums
 __global__ void __launch_bounds__(64)
 selftest_butterfly_kernel(const float *__restrict__ in, float *__restrict__ out) {
-    const int lane = threadIdx.x;
-    float v[21];
-    for (int k = 0; k < 21; k++) v[k] = in[lane * 21 + k];
-    const float s = butterfly21(v, lane);
-    const int slot = slot_of_lane(lane);
-    if (slot >= 0) atomicAdd(&out[slot], s);
-    atomicAdd(&out[21], slot >= 0 ? 1.0f : 0.0f);
+    const int lane = threadIdx.x, q4 = lane & 3;
+    float g[22], r[6];
+    for (int k = 0; k < 22; k++) g[k] = in[lane * 22 + k];
+    quad_reduce_scatter(g, r, lane);
+    float *dst = out + (lane >> 2) * 22 + q4;
+    for (int i = 0; i < 5; i++) dst[4 * i] = r[i];
+    if (q4 < 2) dst[20] = r[5];
 }
 
 }  // namespace

@@ -278,14 +278,14 @@ def test_full_size_properties_and_oracle(hip_lib):
         assert float((lin - z).abs().max()) <= 1e-3 * float(z.abs().max())
 
 
-def test_butterfly_reduction_selftest(hip_lib):
-    """The packed 21-value wave reduction (permlane32/16 swap + DPP) against a plain sum."""
+def test_quad_reduce_scatter_selftest(hip_lib):
+    """The 22-value DPP quad reduce-scatter of the backward composite against plain sums."""
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(64, 21, generator=g, dtype=torch.float32)
-    out = torch.zeros(22, device=DEV)
+    x = torch.randn(64, 22, generator=g, dtype=torch.float32)
+    out = torch.zeros(16 * 22, device=DEV)
     rc = hip_lib.lara2dgs_selftest(0, x.to(DEV).data_ptr(), out.data_ptr(), None)
     assert rc == 0
     torch.cuda.synchronize()
-    got = out.cpu().numpy()
-    assert got[21] == 21.0
-    np.testing.assert_allclose(got[:21], x.double().sum(0).numpy(), rtol=1e-5, atol=1e-5)
+    got = out.cpu().numpy().reshape(16, 22)
+    ref = x.double().reshape(16, 4, 22).sum(1).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
