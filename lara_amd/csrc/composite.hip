@@ -34,7 +34,7 @@ namespace {
 constexpr int FWD_CHUNK = 256;  // list entries staged per round, forward
 constexpr int BWD_CHUNK = 128;  // backward (its LDS also holds the f64 accumulators)
 constexpr int REC4 = 6;        // float4 planes per staged entry (see stage_entry)
-constexpr int ACC_STRIDE = 23; // 21 sums + touch counter, odd stride -> conflict-free LDS banks
+constexpr int ACC_STRIDE = 22; // floats per (wave, entry) result slot in the backward (21 used)
 
 __device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
     o[0] = a[1] * b[2] - a[2] * b[1];
@@ -97,12 +97,20 @@ struct Hit {
     bool use3d;
 };
 
-// phase P: evaluate staged entry j for this lane's pixel (lx, ly = offsets inside the tile)
+// phase P: the four LDS planes an evaluation needs (kept in registers one entry ahead of use, so
+// that the LDS latency -- and, in the backward, the ds_add_f64 queued in front -- is hidden)
+struct EntryRec { float4 r0, r1, r2, r3; };
 template <int CHUNK>
-__device__ __forceinline__ bool eval_entry(const float4 *rec, const int j, const float lx,
-                                           const float ly, Hit &h, float Tw[3], float &opa) {
-    const float4 r0 = rec[0 * CHUNK + j], r1 = rec[1 * CHUNK + j], r2 = rec[2 * CHUNK + j],
-                 r3 = rec[3 * CHUNK + j];
+__device__ __forceinline__ EntryRec load_entry(const float4 *rec, const int j) {
+    EntryRec e;
+    e.r0 = rec[0 * CHUNK + j]; e.r1 = rec[1 * CHUNK + j]; e.r2 = rec[2 * CHUNK + j]; e.r3 = rec[3 * CHUNK + j];
+    return e;
+}
+
+// evaluate a staged entry for this lane's pixel (lx, ly = offsets inside the tile)
+__device__ __forceinline__ bool eval_rec(const EntryRec &e, const float lx, const float ly, Hit &h,
+                                         float Tw[3], float &opa) {
+    const float4 r0 = e.r0, r1 = e.r1, r2 = e.r2, r3 = e.r3;
     const float px = r0.x + lx * r0.w + ly * r1.z;
     const float py = r0.y + lx * r1.x + ly * r1.w;
     const float pz = r0.z + lx * r1.y + ly * r2.x;
@@ -230,18 +238,26 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
                 const int jb = sub + 32 * half;
                 // each quad pops its own next entries; two per trip (independent evaluations),
-                // blended strictly in list order
-                while (__ballot(mm != 0u) != 0ull) {
-                    const bool has0 = mm != 0u;
-                    const int j0 = jb + (has0 ? __builtin_ctz(mm) : 0);
+                // blended strictly in list order; records are fetched one trip ahead
+                bool has0 = mm != 0u;
+                int j0 = jb + (has0 ? __builtin_ctz(mm) : 0);
+                mm &= mm - 1u;
+                bool has1 = mm != 0u;
+                int j1 = jb + (has1 ? __builtin_ctz(mm) : 0);
+                mm &= mm - 1u;  // stays 0 when already empty
+                EntryRec c0 = load_entry<CHUNK>(rec, j0), c1 = load_entry<CHUNK>(rec, j1);
+                while (__ballot(has0) != 0ull) {
+                    const bool n0 = mm != 0u;
+                    const int k0 = jb + (n0 ? __builtin_ctz(mm) : 0);
                     mm &= mm - 1u;
-                    const bool has1 = mm != 0u;
-                    const int j1 = jb + (has1 ? __builtin_ctz(mm) : 0);
-                    mm &= mm - 1u;  // stays 0 when already empty
+                    const bool n1 = mm != 0u;
+                    const int k1 = jb + (n1 ? __builtin_ctz(mm) : 0);
+                    mm &= mm - 1u;
+                    const EntryRec x0 = load_entry<CHUNK>(rec, k0), x1 = load_entry<CHUNK>(rec, k1);
                     Hit h0, h1;
                     float Tw0[3], Tw1[3], opa0, opa1;
-                    const bool e0 = eval_entry<CHUNK>(rec, j0, lx, ly, h0, Tw0, opa0) && has0;
-                    const bool e1 = eval_entry<CHUNK>(rec, j1, lx, ly, h1, Tw1, opa1) && has1;
+                    const bool e0 = eval_rec(c0, lx, ly, h0, Tw0, opa0) && has0;
+                    const bool e1 = eval_rec(c1, lx, ly, h1, Tw1, opa1) && has1;
                     if (v.dbg & 4u) {  // statistics: quad candidates, valid (pixel, entry) pairs
                         atomicAdd(&dbg_hdr[4], ((lane & 3) == 0) ? (unsigned)has0 + (unsigned)has1 : 0u);
                         atomicAdd(&dbg_hdr[5], (unsigned)e0 + (unsigned)e1);
@@ -249,6 +265,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     }
                     px.blend<CHUNK>(rec, j0, base, e0, h0);
                     px.blend<CHUNK>(rec, j1, base, e1, h1);
+                    c0 = x0; c1 = x1; j0 = k0; j1 = k1; has0 = n0; has1 = n1;
                 }
             }
         }
@@ -302,6 +319,68 @@ __device__ __forceinline__ void quad_reduce_scatter(const float g[22], float r[6
     r[5] = v1[10] + dpp_full<0x4E>(v1[10]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// packed butterfly reduction of 21 per-lane values over the 64 lanes of a wave
+// (v_permlane32_swap / v_permlane16_swap / DPP: ~55 VALU ops instead of 126 for 21 plain reductions)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float f_of(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned u_of(float f) { return __float_as_uint(f); }
+
+// lanes 0..31 <- a[l] + a[l+32] ; lanes 32..63 <- b[l-32] + b[l]
+__device__ __forceinline__ float pair32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(u_of(a), u_of(b), false, false);
+    return f_of(r[0]) + f_of(r[1]);
+}
+// rows 0,2 <- a summed over (row, row+1) ; rows 1,3 <- b summed over (row-1, row)
+__device__ __forceinline__ float pair16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(u_of(a), u_of(b), false, false);
+    return f_of(r[0]) + f_of(r[1]);
+}
+// lanes with bit3 clear <- a[l] + a[l^8] ; bit3 set <- b[l] + b[l^8]
+__device__ __forceinline__ float pair8(float a, float b, bool bit3) {
+    const float t = a + dpp_full<0x128>(a), u = b + dpp_full<0x128>(b);  // row_ror:8
+    return bit3 ? u : t;
+}
+// lanes with bit2 clear <- a[l] + a[l+4] ; bit2 set <- b[l] + b[l-4]
+__device__ __forceinline__ float pair4(float a, float b, bool bit2) {
+    int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0,2
+    y = __builtin_amdgcn_update_dpp(y, __float_as_int(b), 0x114, 0xf, 0xa, false);      // row_shr:4 -> banks 1,3
+    return (bit2 ? b : a) + __int_as_float(y);
+}
+// lanes with bit1 clear <- a[l] + a[l^2] ; bit1 set <- b[l] + b[l^2]
+__device__ __forceinline__ float pair2(float a, float b, bool bit1) {
+    const float t = a + dpp_full<0x4E>(a), u = b + dpp_full<0x4E>(b);  // quad_perm [2,3,0,1]
+    return bit1 ? u : t;
+}
+__device__ __forceinline__ float fold1(float a) { return a + dpp_full<0xB1>(a); }  // quad_perm [1,0,3,2]
+
+// After the call, lane l holds the full 64-lane sum of value slot_of_lane(l) (see below).
+__device__ __forceinline__ float butterfly21(const float v[21], const int lane) {
+    float r[11];
+#pragma unroll
+    for (int i = 0; i < 10; i++) r[i] = pair32(v[2 * i], v[2 * i + 1]);
+    r[10] = pair32(v[20], v[20]);
+    float q[6];
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = pair16(r[2 * i], r[2 * i + 1]);
+    q[5] = pair16(r[10], r[10]);
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    const float o0 = pair8(q[0], q[1], b3), o1 = pair8(q[2], q[3], b3), o2 = pair8(q[4], q[5], b3);
+    const float n0 = pair4(o0, o1, b2), n1 = pair4(o2, o2, b2);
+    return fold1(pair2(n0, n1, b1));
+}
+// which of the 21 values lane l ends up with (-1: duplicate holder, must not write)
+__device__ __forceinline__ int slot_of_lane(const int l) {
+    if (l & 1) return -1;
+    const int b1 = (l >> 1) & 1, b2 = (l >> 2) & 1, b3 = (l >> 3) & 1, b4 = (l >> 4) & 1, b5 = (l >> 5) & 1;
+    int o;  // index among o0..o2
+    if (b1) { if (b2) return -1; o = 2; } else o = b2;
+    const int q = 2 * o + b3;  // index among q0..q5
+    if (q == 5) return (b4 | b5) ? -1 : 20;
+    const int r = 2 * q + b4;  // index among r0..r9
+    return 2 * r + b5;
+}
+
 __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
     __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -317,17 +396,21 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                      float *__restrict__ grad) {
     constexpr int CHUNK = BWD_CHUNK;
-    // f64 accumulators: ds_add_f64 runs at 18 cycles per wave instruction on gfx950, ds_add_f32 at
-    // 169 (measured, tools/ubench/lds_atomic.hip) -- and the tile sums get double accumulation
+    // Per-wave result slices instead of LDS atomics: a wave visits an entry at most once per round,
+    // so it can park the entry's 21 sums with a plain ds_write; phase S2 adds the (<= 4) slices in
+    // a fixed order.  (LDS float atomics are slow on gfx950: ds_add_f32 169 / ds_add_f64 18 cycles
+    // per wave instruction with a long latency -- tools/ubench/lds_atomic.hip.)
     __shared__ float4 rec[REC4 * CHUNK];
-    __shared__ double acc[CHUNK * ACC_STRIDE];  // [entry][slot]
+    __shared__ float acc[4 * CHUNK * ACC_STRIDE];  // [wave][entry][slot]
+    __shared__ unsigned long long touched[4][CHUNK / 64];
     __shared__ uint32_t s_id[CHUNK];
     __shared__ uint32_t s_maxc;
     if (header[1]) return;
     const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int grp = lane >> 2, q4 = lane & 3;
+    const int grp = lane >> 2;
+    const int slot = slot_of_lane(lane);
     const int lxi = (wave & 1) * 8 + (grp & 3) * 2 + (lane & 1);
     const int lyi = (wave >> 1) * 8 + (grp >> 2) * 2 + ((lane >> 1) & 1);
     const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
@@ -379,117 +462,131 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         if ((int)threadIdx.x < CHUNK)
             stage_entry<CHUNK>(point_list, geom, cullbox, range.x + lo + threadIdx.x,
                                (int)threadIdx.x < cnt, X0, Y0, rec, s_id);
-        for (int k = threadIdx.x; k < CHUNK * ACC_STRIDE; k += 256) acc[k] = 0.0;
+        if (threadIdx.x < 4 * (CHUNK / 64)) (&touched[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
 
 #pragma unroll 1
         for (int sub = ((cnt - 1) >> 6) << 6; sub >= 0; sub -= 64) {
+            // The backward keeps ONE candidate stream per wave (8x8 quadrant): its per-entry sums
+            // must be reduced over all pixels anyway, and a wave-wide butterfly + one 22-lane
+            // ds_add_f64 is far cheaper than per-quad LDS atomics (which collide on the same entry).
             const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + sub + lane;
             const uint32_t bm = __float_as_uint((wave >> 1) ? mrec->z : mrec->w);
-            if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) == 0ull) continue;
-            const unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
-#pragma unroll 1
-            for (int half = 1; half >= 0; half--) {
-                uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-                const int jb = sub + 32 * half;
-                while (__ballot(mm != 0u) != 0ull) {  // every quad pops its own last entry
-                    const bool has = mm != 0u;
-                    const int b = has ? 31 - __builtin_clz(mm) : 0;
-                    mm &= ~(1u << b);  // mm == 0 stays 0 (b = 0, bit 0 clear)
-                    const int j = jb + b;
-                    const uint32_t contributor = (uint32_t)(lo + j);  // 0-based list position
-                    Hit h;
-                    float Tw[3], opa;
-                    const bool active = eval_entry<CHUNK>(rec, j, lx, ly, h, Tw, opa) && has && contributor < last_contributor;
-                    const unsigned long long amask = __ballot(active);
-                    if (amask == 0ull) continue;
-
-                    float g[22];
-#pragma unroll
-                    for (int k = 0; k < 22; k++) g[k] = 0.f;
-                    if (active) {
-                        const float4 r4 = rec[4 * CHUNK + j], r5 = rec[5 * CHUNK + j];
-                        const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
-                        const float alpha = h.alpha, G = h.G, c_d = h.depth;
-                        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T = T * inv_1ma;
-                        const float w = alpha * T;
-                        float dL_dalpha = 0.0f;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                            last_color[ch] = rgb[ch];
-                            dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
-                            g[18 + ch] = w * dpix[ch];
-                        }
-                        float dL_dz = 0.0f, dL_dweight = 0.0f;
-                        const float inv_cd = __builtin_amdgcn_rcpf(c_d);
-                        const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
-                        const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
-                        if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
-                        dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
-                        dL_dalpha += dL_dweight - last_dL_dT;
-                        last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                        dL_dz += dL_dmd * dmd_dd;
-
-                        accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                        last_depth = c_d;
-                        dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                        accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                        dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
-                            last_normal[ch] = nrm[ch];
-                            dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
-                            g[14 + ch] = w * dnrm[ch];
-                        }
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-
-                        const float dL_dG = opa * dL_dalpha;
-                        dL_dz += w * dL_ddepth;
-                        // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
-                        g[9] = dL_dz * h.sx; g[10] = dL_dz * h.sy; g[11] = dL_dz;
-                        if (h.use3d) {
-                            const float dL_dsx = dL_dG * -G * h.sx + dL_dz * Tw[0];
-                            const float dL_dsy = dL_dG * -G * h.sy + dL_dz * Tw[1];
-                            const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
-                            const float dpz = -(dpx * h.sx + dpy * h.sy);
-                            g[0] = dpx; g[1] = dpy; g[2] = dpz;
-                            g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
-                            g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
-                        } else {
-                            g[12] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddx);
-                            g[13] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddy);
-                        }
-                        g[17] = G * dL_dalpha;
-                        g[21] = 1.0f;  // touched marker
-                    }
-                    if (v.dbg & 2u) { float z = 0.f; for (int k = 0; k < 22; k++) z += g[k]; if (z == 123.456f) acc[0] = z; continue; }
-                    // quad reduce-scatter: lane q4 of the quad ends with the sums of values
-                    // k = 4i + q4 (i = 0..4) in r[i], and lanes 0/1 with value 20/21 in r[5]
-                    float r[6];
-                    quad_reduce_scatter(g, r, lane);
-                    if (((amask >> (lane & ~3)) & 0xfull) && !(v.dbg & 16u)) {  // some lane of my quad was active
-                        double *dst = acc + j * ACC_STRIDE + q4;
-#pragma unroll
-                        for (int i = 0; i < 5; i++) atomicAdd(dst + 4 * i, (double)r[i]);  // ds_add_f64
-                        if (q4 < 2) atomicAdd(dst + 20, (double)r[5]);
-                    }
+            unsigned long long m = __ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u);
+            if (m == 0ull) continue;
+            unsigned long long tmask = 0ull;  // entries of this sub-chunk this wave produced sums for
+            int jn = sub + 63 - __builtin_clzll(m);
+            m &= ~(1ull << (jn - sub));
+            EntryRec cur = load_entry<CHUNK>(rec, jn);
+            float4 cur4 = rec[4 * CHUNK + jn], cur5 = rec[5 * CHUNK + jn];
+            bool more = true;
+            while (more) {
+                const int j = jn;
+                const EntryRec ent = cur;
+                const float4 r4 = cur4, r5 = cur5;
+                more = m != 0ull;
+                if (more) {  // fetch the next entry before this one's ds_add_f64 enters the LDS queue
+                    jn = sub + 63 - __builtin_clzll(m);
+                    m &= ~(1ull << (jn - sub));
+                    cur = load_entry<CHUNK>(rec, jn);
+                    cur4 = rec[4 * CHUNK + jn]; cur5 = rec[5 * CHUNK + jn];
                 }
+                const uint32_t contributor = (uint32_t)(lo + j);  // 0-based list position
+                Hit h;
+                float Tw[3], opa;
+                const bool active = eval_rec(ent, lx, ly, h, Tw, opa) && contributor < last_contributor;
+                if (__ballot(active) == 0ull) continue;
+
+                float g[21];
+#pragma unroll
+                for (int k = 0; k < 21; k++) g[k] = 0.f;
+                if (active) {
+                    const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
+                    const float alpha = h.alpha, G = h.G, c_d = h.depth;
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * inv_1ma;
+                    const float w = alpha * T;
+                    float dL_dalpha = 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = rgb[ch];
+                        dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
+                        g[18 + ch] = w * dpix[ch];
+                    }
+                    float dL_dz = 0.0f, dL_dweight = 0.0f;
+                    const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
+                    const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
+                    if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
+                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                    dL_dz += dL_dmd * dmd_dd;
+
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = c_d;
+                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                        last_normal[ch] = nrm[ch];
+                        dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
+                        g[14 + ch] = w * dnrm[ch];
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+
+                    const float dL_dG = opa * dL_dalpha;
+                    dL_dz += w * dL_ddepth;
+                    // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
+                    g[9] = dL_dz * h.sx; g[10] = dL_dz * h.sy; g[11] = dL_dz;
+                    if (h.use3d) {
+                        const float dL_dsx = dL_dG * -G * h.sx + dL_dz * Tw[0];
+                        const float dL_dsy = dL_dG * -G * h.sy + dL_dz * Tw[1];
+                        const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
+                        const float dpz = -(dpx * h.sx + dpy * h.sy);
+                        g[0] = dpx; g[1] = dpy; g[2] = dpz;
+                        g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
+                        g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
+                    } else {
+                        g[12] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddx);
+                        g[13] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddy);
+                    }
+                    g[17] = G * dL_dalpha;
+                }
+                if (v.dbg & 2u) { float z = 0.f; for (int k = 0; k < 21; k++) z += g[k]; if (z == 123.456f) acc[0] = z; continue; }
+                const float sred = butterfly21(g, lane);
+                if (v.dbg & 16u) { if (sred == 123.456f) acc[0] = sred; continue; }
+                if (slot >= 0) acc[(wave * CHUNK + j) * ACC_STRIDE + slot] = sred;  // plain ds_write, 21 lanes
+                tmask |= 1ull << (j - sub);
             }
+            if (lane == 0) touched[wave][sub >> 6] = tmask;
         }
         __syncthreads();
 
         // phase S2: thread e turns its entry's 21 coefficient-space sums into dL/d(Tu,Tv,Tw,...)
         const int e = threadIdx.x;
-        if (e < cnt && acc[e * ACC_STRIDE + 21] > 0.0 && !(v.dbg & 1u)) {
-            float sacc[21];
+        bool any = false;
+        float sacc[21];
 #pragma unroll
-            for (int k = 0; k < 21; k++) sacc[k] = (float)acc[e * ACC_STRIDE + k];
+        for (int k = 0; k < 21; k++) sacc[k] = 0.f;
+        if (e < cnt) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if ((touched[w][e >> 6] >> (e & 63)) & 1ull) {
+                    any = true;
+                    const float *src = acc + (w * CHUNK + e) * ACC_STRIDE;
+#pragma unroll
+                    for (int k = 0; k < 21; k++) sacc[k] += src[k];
+                }
+            }
+        }
+        if (any && !(v.dbg & 1u)) {
             const uint32_t id = s_id[e];
             const float4 *gm = geom + (size_t)id * 5;
             const float4 g0 = gm[0], g1 = gm[1], g2 = gm[2];
