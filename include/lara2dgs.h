@@ -75,6 +75,9 @@ typedef struct lara2dgs_state_layout {
     int64_t ranges;      /* uint32[tiles][2]: [start, end) per 16x16 tile, (0,0) when empty */
     int64_t tile_order;  /* uint32[tiles]: tile ids sorted by list length, longest first: the composite
                           * kernels' workgroup -> tile map (load balance across the 256 CUs) */
+    int64_t pair_base;   /* uint32[P+1]: first (tile, surfel) pair of each surfel, surfel-major order */
+    int64_t pair_pos;    /* uint32[capacity]: surfel-major pair index -> position in point_list; lets the
+                          * backward gather per-surfel gradients deterministically, without atomics */
     int64_t final_T;     /* float[3][H][W]: T, M1, M2 */
     int64_t n_contrib;   /* uint32[2][H][W]: last contributor, median contributor */
     int64_t total;

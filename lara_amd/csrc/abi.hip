@@ -81,6 +81,8 @@ StateView carve_state(const ViewDev &v, void *state) {
     s.point_list = (uint32_t *)(b + L.point_list);
     s.ranges = (uint2 *)(b + L.ranges);
     s.tile_order = (uint32_t *)(b + L.tile_order);
+    s.pair_base = (uint32_t *)(b + L.pair_base);
+    s.pair_pos = (uint32_t *)(b + L.pair_pos);
     s.final_T = (float *)(b + L.final_T);
     s.n_contrib = (uint32_t *)(b + L.n_contrib);
     return s;
@@ -95,7 +97,9 @@ ScratchView carve_scratch(const ViewDev &v, void *scratch, ScratchLayout &L) {
     s.sub_start = (uint32_t *)(b + L.sub_start);
     s.rect = (uint4 *)(b + L.rect);
     s.keys = (uint64_t *)(b + L.keys);
-    s.grad = (float *)(b + L.grad);
+    s.block_tot = (uint32_t *)(b + L.block_tot);
+    s.pair_grad = (float4 *)(b + L.pair_grad);
+    s.pair_valid = (uint32_t *)(b + L.pair_valid);
     return s;
 }
 
@@ -192,7 +196,7 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
     StateView st = carve_state(v, const_cast<void *>(state));
     ScratchLayout SL;
     ScratchView sc = carve_scratch(v, scratch, SL);
-    hipError_t e = hipMemsetAsync(sc.grad, 0, (size_t)v.P * GRAD_F * sizeof(float), s);
+    hipError_t e = hipMemsetAsync(sc.pair_valid, 0, (size_t)(SL.total - SL.pair_valid), s);
     if (e != hipSuccess) { l2d_set_hip_error(e); return LARA2DGS_E_LAUNCH; }
     int rc = launch_composite_bwd(v, st, sc, dL_dcolor, dL_dallmap, s);
     if (rc) return rc;

@@ -49,7 +49,7 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, const uint32_t n, const uint
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ sub_start,
                  uint2 *__restrict__ ranges, uint32_t *__restrict__ header,
-                 uint32_t *__restrict__ tile_order) {
+                 uint32_t *__restrict__ tile_order, uint32_t *__restrict__ block_tot) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s, s_max;
     __shared__ uint32_t bcnt[64];
@@ -149,6 +149,30 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         const uint32_t b = 63u - (uint32_t)(((uint64_t)(rg.y - rg.x) * 64u) / denom);
         tile_order[atomicAdd(&bcnt[b], 1u)] = (uint32_t)i;
     }
+    // exclusive scan (in place) of the per-surfel-block pair totals -> surfel-major pair numbering
+    __syncthreads();
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    const int nblk = (v.P + 255) / 256;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + tid;
+        const uint32_t c = i < nblk ? block_tot[i] : 0u;
+        uint32_t x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wave_sums[wid] = x;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; w++) wave_off += wave_sums[w];
+        const uint32_t incl = carry_s + wave_off + x;
+        if (i < nblk) block_tot[i] = incl - c;
+        __syncthreads();
+        if (tid == 1023) carry_s = incl;
+        __syncthreads();
+    }
 }
 
 // ---- 3. scatter (depth bits, id) into the tile segments ----------------------------------------
@@ -157,6 +181,7 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
 // inside the run with LDS atomics.  (Order inside a tile segment is arbitrary by design.)
 __global__ void __launch_bounds__(256)
 scatter_kernel(ViewDev v, const uint4 *__restrict__ rect, const uint32_t *__restrict__ sub_start,
+               const uint32_t *__restrict__ block_base, uint32_t *__restrict__ pair_base,
                uint32_t *__restrict__ tile_fill, uint64_t *__restrict__ keys, const int use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,6 +192,9 @@ scatter_kernel(ViewDev v, const uint4 *__restrict__ rect, const uint32_t *__rest
         const uint4 r = rect[idx];
         rx0 = r.x & 0xffff; ry0 = r.x >> 16; rx1 = r.y & 0xffff; ry1 = r.y >> 16;
         word = ((uint64_t)r.z << 32) | (uint32_t)idx;
+        const uint32_t pb = block_base[blockIdx.x] + r.w;
+        pair_base[idx] = pb;
+        if (idx == v.P - 1) pair_base[v.P] = pb + (uint32_t)(rx1 - rx0) * (uint32_t)(ry1 - ry0);
     }
     if (use_lds) {
         for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) hist[t] = 0;
@@ -270,9 +298,23 @@ __device__ __forceinline__ void block_sort(uint64_t (&x)[E], uint64_t *lds) {
     }
 }
 
+// where (surfel id, this tile) sits in the surfel-major pair numbering
+struct PairMap {
+    const uint4 *rect;
+    const uint32_t *pair_base;
+    uint32_t *pair_pos;
+    int tx, ty;
+    uint32_t first;  // position of the tile's first entry in the sorted list
+    __device__ __forceinline__ void put(const uint32_t id, const uint32_t i) const {
+        const uint4 r = rect[id];
+        const int rx0 = r.x & 0xffff, ry0 = r.x >> 16, rx1 = r.y & 0xffff;
+        pair_pos[pair_base[id] + (uint32_t)((ty - ry0) * (rx1 - rx0) + (tx - rx0))] = first + i;
+    }
+};
+
 template <int E>
 __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ seg, const uint32_t n,
-                                          uint32_t *__restrict__ out, uint64_t *lds) {
+                                          uint32_t *__restrict__ out, uint64_t *lds, const PairMap &pm) {
     uint64_t x[E];
     const uint32_t i0 = threadIdx.x * E;
 #pragma unroll
@@ -280,7 +322,10 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ seg, cons
     block_sort<E>(x, lds);
 #pragma unroll
     for (int e = 0; e < E; e++)
-        if (i0 + e < n) out[i0 + e] = (uint32_t)x[e];
+        if (i0 + e < n) {
+            out[i0 + e] = (uint32_t)x[e];
+            pm.put((uint32_t)x[e], i0 + e);
+        }
 }
 
 // LARGE = false: tiles with n <= 2048 (16 KB LDS); LARGE = true: 2048 < n (64 KB LDS; lists longer
@@ -289,25 +334,31 @@ template <bool LARGE>
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ header,
                  const uint32_t *__restrict__ tile_order, uint64_t *__restrict__ keys,
-                 uint32_t *__restrict__ point_list) {
+                 uint32_t *__restrict__ point_list, const uint4 *__restrict__ rect,
+                 const uint32_t *__restrict__ pair_base, uint32_t *__restrict__ pair_pos) {
     __shared__ uint64_t lds[LARGE ? 8192 : 2048];
-    const uint2 rg = ranges[tile_order[blockIdx.x]];
+    const int tile = (int)tile_order[blockIdx.x];
+    const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
     if (header[1]) return;  // capacity overflow: lists are incomplete, outputs get poisoned instead
     if (n == 0 || (LARGE ? (n <= 2048u) : (n > 2048u))) return;  // the other kernel's tile
     uint64_t *seg = keys + rg.x;
     uint32_t *out = point_list + rg.x;
+    const PairMap pm{rect, pair_base, pair_pos, tile % v.gx, tile / v.gx, rg.x};
     if (!LARGE) {
-        if (n <= 256u) sort_tile<1>(seg, n, out, lds);
-        else if (n <= 512u) sort_tile<2>(seg, n, out, lds);
-        else if (n <= 1024u) sort_tile<4>(seg, n, out, lds);
-        else sort_tile<8>(seg, n, out, lds);
+        if (n <= 256u) sort_tile<1>(seg, n, out, lds, pm);
+        else if (n <= 512u) sort_tile<2>(seg, n, out, lds, pm);
+        else if (n <= 1024u) sort_tile<4>(seg, n, out, lds, pm);
+        else sort_tile<8>(seg, n, out, lds, pm);
     } else {
-        if (n <= 4096u) sort_tile<16>(seg, n, out, lds);
-        else if (n <= 8192u) sort_tile<32>(seg, n, out, lds);
+        if (n <= 4096u) sort_tile<16>(seg, n, out, lds, pm);
+        else if (n <= 8192u) sort_tile<32>(seg, n, out, lds, pm);
         else {
             bitonic_sort(seg, n, next_pow2(n));
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = (uint32_t)seg[i];
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                out[i] = (uint32_t)seg[i];
+                pm.put((uint32_t)seg[i], i);
+            }
         }
     }
 }
@@ -318,7 +369,7 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
     {
         L2D_PROF("tile_scan", s);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
-                           st.ranges, st.header, st.tile_order);
+                           st.ranges, st.header, st.tile_order, sc.block_tot);
     }
     L2D_CHECK_LAUNCH();
     if (v.P == 0) return LARA2DGS_OK;
@@ -326,20 +377,22 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
         L2D_PROF("scatter", s);
         const int use_lds = v.tiles <= L2D_LDS_HIST_TILES;
         hipLaunchKernelGGL(scatter_kernel, dim3((v.P + 255) / 256), dim3(256),
-                           use_lds ? (size_t)v.tiles * 4 : 0, s, v, sc.rect, sc.sub_start, sc.tile_fill,
-                           sc.keys, use_lds);
+                           use_lds ? (size_t)v.tiles * 4 : 0, s, v, sc.rect, sc.sub_start, sc.block_tot,
+                           st.pair_base, sc.tile_fill, sc.keys, use_lds);
     }
     L2D_CHECK_LAUNCH();
     {
         L2D_PROF("tile_sort_small", s);
         hipLaunchKernelGGL((tile_sort_kernel<false>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
-                           st.header, st.tile_order, sc.keys, st.point_list);
+                           st.header, st.tile_order, sc.keys, st.point_list, sc.rect, st.pair_base,
+                           st.pair_pos);
     }
     L2D_CHECK_LAUNCH();
     {
         L2D_PROF("tile_sort_large", s);
         hipLaunchKernelGGL((tile_sort_kernel<true>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
-                           st.header, st.tile_order, sc.keys, st.point_list);
+                           st.header, st.tile_order, sc.keys, st.point_list, sc.rect, st.pair_base,
+                           st.pair_pos);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

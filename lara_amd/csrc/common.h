@@ -32,6 +32,8 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     uint32_t *point_list; // [cap]
     uint2 *ranges;        // [tiles]
     uint32_t *tile_order; // [tiles] tile ids, longest list first (work-balanced launch order)
+    uint32_t *pair_base;  // [P+1] first pair index of each surfel (exclusive scan of tiles touched)
+    uint32_t *pair_pos;   // [cap] pair index (surfel-major) -> position in the sorted list
     float *final_T;       // [3][HW]
     uint32_t *n_contrib;  // [2][HW]
 };
@@ -42,7 +44,9 @@ struct ScratchView {
     uint32_t *sub_start;   // [tiles][L2D_SLICES]  first slot of each (tile, slice) sub-segment
     uint4 *rect;           // [P] tile rectangle (4 x u16 in .x,.y) + depth bits (.z)
     uint64_t *keys;        // [cap]  (depth bits << 32) | surfel id, grouped per tile, unsorted
-    float *grad;           // [P][GRAD_F] backward accumulators (aliases keys/rect region)
+    uint32_t *block_tot;   // [ceil(P/256)] pairs per surfel block, then (in place) their exclusive scan
+    float4 *pair_grad;     // [cap][5] backward: per (tile, surfel) gradient rows (aliases the forward region)
+    uint32_t *pair_valid;  // [cap/32] backward: bit p set <=> row p was written
 };
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -57,12 +61,14 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->point_list = o;  o = align_up(o + cap * 4, 256);
     L->ranges = o;      o = align_up(o + tiles * 8, 256);
     L->tile_order = o;  o = align_up(o + tiles * 4, 256);
+    L->pair_base = o;   o = align_up(o + ((int64_t)P + 1) * 4, 256);
+    L->pair_pos = o;    o = align_up(o + cap * 4, 256);
     L->final_T = o;     o = align_up(o + 3 * HW * 4, 256);
     L->n_contrib = o;   o = align_up(o + 2 * HW * 4, 256);
     L->total = o;
 }
 
-struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, rect, keys, grad, total; };
+struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, rect, keys, block_tot, pair_grad, pair_valid, total; };
 static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     int64_t o = 0;
@@ -72,9 +78,11 @@ static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayou
     const int64_t fwd0 = o;
     L->rect = o;        o = align_up(o + (int64_t)P * 16, 256);
     L->keys = o;        o = align_up(o + cap * 8, 256);
+    L->block_tot = o;   o = align_up(o + (((int64_t)P + 255) / 256 + 1) * 4, 256);
     const int64_t fwd_end = o;
-    L->grad = fwd0;     // backward reuses the forward-only region
-    const int64_t bwd_end = align_up(fwd0 + (int64_t)P * GRAD_F * 4, 256);
+    L->pair_grad = fwd0;  // backward reuses the forward-only region
+    L->pair_valid = align_up(fwd0 + cap * GRAD_F * 4, 256);
+    const int64_t bwd_end = align_up(L->pair_valid + (cap / 32 + 2) * 4, 256);
     L->total = fwd_end > bwd_end ? fwd_end : bwd_end;
 }
 

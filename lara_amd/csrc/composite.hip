@@ -394,7 +394,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
-                     float *__restrict__ grad) {
+                     float4 *__restrict__ pair_grad, uint32_t *__restrict__ pair_valid) {
     constexpr int CHUNK = BWD_CHUNK;
     // Per-wave result slices instead of LDS atomics: a wave visits an entry at most once per round,
     // so it can park the entry's 21 sums with a plain ds_write; phase S2 adds the (<= 4) slices in
@@ -586,7 +586,11 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 }
             }
         }
-        if (any && !(v.dbg & 1u)) {
+        // one 80-byte gradient row per touched (tile, surfel) pair, written exactly once, coalesced;
+        // a bitmap marks the rows that exist.  preprocess_bwd gathers each surfel's rows (no atomics
+        // on gradients, fixed summation order).
+        const uint32_t p = range.x + (uint32_t)(lo + e);
+        if (any) {
             const uint32_t id = s_id[e];
             const float4 *gm = geom + (size_t)id * 5;
             const float4 g0 = gm[0], g1 = gm[1], g2 = gm[2];
@@ -603,17 +607,24 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             for (int i = 0; i < 3; i++) dl0[i] = t1[i] + t2[i];
             cross3(l0, b, t1); cross3(cc, k0, t2);
             for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + sacc[9 + i];
-            float *dst = grad + (size_t)id * GRAD_F;
-            for (int i = 0; i < 3; i++) {
-                atomic_add_f32(dst + 0 + i, -dk0[i]);
-                atomic_add_f32(dst + 3 + i, -dl0[i]);
-                atomic_add_f32(dst + 6 + i, dTw[i]);
-            }
-            atomic_add_f32(dst + 9, sacc[12]);
-            atomic_add_f32(dst + 10, sacc[13]);
-            for (int i = 0; i < 3; i++) atomic_add_f32(dst + 11 + i, sacc[14 + i]);
-            atomic_add_f32(dst + 14, sacc[17]);
-            for (int i = 0; i < 3; i++) atomic_add_f32(dst + 15 + i, sacc[18 + i]);
+            float4 *row = pair_grad + (size_t)p * (GRAD_F / 4);
+            row[0] = make_float4(-dk0[0], -dk0[1], -dk0[2], -dl0[0]);
+            row[1] = make_float4(-dl0[1], -dl0[2], dTw[0], dTw[1]);
+            row[2] = make_float4(dTw[2], sacc[12], sacc[13], sacc[14]);
+            row[3] = make_float4(sacc[15], sacc[16], sacc[17], sacc[18]);
+            row[4] = make_float4(sacc[19], sacc[20], 0.f, 0.f);
+        }
+        // publish the wave's 64 validity bits with at most three atomic ORs
+        const unsigned long long bits = __ballot(any);
+        if (bits) {
+            const uint32_t p0 = range.x + (uint32_t)(lo + (e & ~63));  // position of lane 0's entry
+            const uint32_t sh = p0 & 31u, w0 = p0 >> 5;
+            const int l = e & 63;
+            uint32_t word = 0;
+            if (l == 0) word = (uint32_t)(bits << sh);
+            else if (l == 1) word = (uint32_t)(bits >> (32u - sh));
+            else if (l == 2) word = sh ? (uint32_t)(bits >> (64u - sh)) : 0u;
+            if (l < 3 && word) atomicOr(&pair_valid[w0 + l], word);
         }
     }
 }
@@ -651,7 +662,7 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
                            (const float4 *)st.cullbox, st.final_T, st.n_contrib, dL_dcolor, dL_dallmap,
-                           sc.grad);
+                           sc.pair_grad, sc.pair_valid);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -256,9 +256,10 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
                       const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
                       const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
                       float4 *__restrict__ cullbox, uint4 *__restrict__ rect_out,
-                      uint32_t *__restrict__ tile_count, int32_t *__restrict__ radii,
-                      const int use_lds) {
+                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ block_tot,
+                      int32_t *__restrict__ radii, const int use_lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    __shared__ uint32_t wsum[4];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int slice = blockIdx.x % L2D_SLICES;
     if (use_lds) {
@@ -266,13 +267,31 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
         __syncthreads();
     }
     ushort4 r = make_ushort4(0, 0, 0, 0);
-    if (idx < v.P) {
+    if (idx < v.P)
         r = surfel_forward<DEG>(v, idx, means3D, shs, colors_precomp, opacities, scales, rotations,
                                 transmat_precomp, geom, cullbox, radii);
-        // tile rectangle + depth key bits, 16 B per surfel, for the scatter pass
-        const float depth = (r.z > r.x && r.w > r.y) ? geom[(size_t)idx * 5 + 3].w : 0.f;
+    // exclusive scan of the tiles touched inside the workgroup: surfel-major pair numbering, used by
+    // the backward to gather a surfel's per-tile gradient rows without atomics
+    const uint32_t tt = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
+    uint32_t incl = tt;
+    {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    }
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += wsum[w];
+    if (threadIdx.x == 255) block_tot[blockIdx.x] = woff + incl;
+    if (idx < v.P) {
+        // tile rectangle + depth key bits + local pair offset, 16 B per surfel, for the scatter pass
+        const float depth = tt ? geom[(size_t)idx * 5 + 3].w : 0.f;
         rect_out[idx] = make_uint4((uint32_t)r.x | ((uint32_t)r.y << 16), (uint32_t)r.z | ((uint32_t)r.w << 16),
-                                   __float_as_uint(depth), 0u);
+                                   __float_as_uint(depth), woff + incl - tt);
     }
     for (int y = r.y; y < r.w; y++)
         for (int x = r.x; x < r.z; x++) {
@@ -310,7 +329,9 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
                       const float *__restrict__ colors_precomp, const float2 *__restrict__ scales,
                       const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
                       const int32_t *__restrict__ radii, const float4 *__restrict__ geom,
-                      const float4 *__restrict__ grad, float *__restrict__ dL_dmeans3D,
+                      const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_pos,
+                      const float4 *__restrict__ pair_grad, const uint32_t *__restrict__ pair_valid,
+                      float *__restrict__ dL_dmeans3D,
                       float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
                       float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
                       float2 *__restrict__ dL_dscales, float4 *__restrict__ dL_drots,
@@ -319,16 +340,22 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     if (idx >= v.P) return;
     const bool visible = radii[idx] > 0;
 
+    // sum the surfel's per-tile gradient rows in tile order (deterministic; no atomics anywhere)
     float gacc[GRAD_F];
+#pragma unroll
+    for (int k = 0; k < GRAD_F; k++) gacc[k] = 0.f;
     if (visible) {
+        const uint32_t q0 = pair_base[idx], q1 = pair_base[idx + 1];
+        for (uint32_t q = q0; q < q1; q++) {
+            const uint32_t pp = pair_pos[q];
+            if (!((pair_valid[pp >> 5] >> (pp & 31u)) & 1u)) continue;  // no pixel used this pair
+            const float4 *row = pair_grad + (size_t)pp * (GRAD_F / 4);
 #pragma unroll
-        for (int k = 0; k < GRAD_F / 4; k++) {
-            const float4 q = grad[(size_t)idx * (GRAD_F / 4) + k];
-            gacc[4 * k] = q.x; gacc[4 * k + 1] = q.y; gacc[4 * k + 2] = q.z; gacc[4 * k + 3] = q.w;
+            for (int k = 0; k < GRAD_F / 4; k++) {
+                const float4 w4 = row[k];
+                gacc[4 * k] += w4.x; gacc[4 * k + 1] += w4.y; gacc[4 * k + 2] += w4.z; gacc[4 * k + 3] += w4.w;
+            }
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < GRAD_F; k++) gacc[k] = 0.f;
     }
     dL_dopacities[idx] = gacc[14];
 
@@ -509,7 +536,7 @@ int launch_preprocess_fwd(const ViewDev &v, const float *means3D, const float *s
     hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, lds_bytes, s, v, means3D, shs,   \
                        colors_precomp, opacities, (const float2 *)scales,                        \
                        (const float4 *)rotations, transmat_precomp, st.geom, st.cullbox,         \
-                       sc.rect, sc.tile_count, radii, use_lds)
+                       sc.rect, sc.tile_count, sc.block_tot, radii, use_lds)
     {
         L2D_PROF("preprocess_fwd", s);
         switch (colors_precomp ? 0 : v.deg) {
@@ -535,7 +562,8 @@ int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *s
 #define L2D_PREB(DEG)                                                                            \
     hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, v, means3D, shs,           \
                        colors_precomp, (const float2 *)scales, (const float4 *)rotations,        \
-                       transmat_precomp, radii, (const float4 *)st.geom, (const float4 *)sc.grad, \
+                       transmat_precomp, radii, (const float4 *)st.geom, st.pair_base,           \
+                       st.pair_pos, (const float4 *)sc.pair_grad, sc.pair_valid,                 \
                        dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities,             \
                        (float2 *)dL_dscales, (float4 *)dL_drotations, dL_dtransmat)
     {

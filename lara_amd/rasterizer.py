@@ -46,7 +46,7 @@ class _View(ctypes.Structure):
 
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
-                ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "final_T", "n_contrib", "total")]
+                ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "pair_base", "pair_pos", "final_T", "n_contrib", "total")]
 
 
 _lib = None
