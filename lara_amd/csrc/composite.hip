@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int FWD_CHUNK = 256;  // list entries staged per round, forward
+constexpr int FWD_CHUNK = 512;  // list entries staged per round, forward
 constexpr int BWD_CHUNK = 128;  // backward (its LDS also holds the f64 accumulators)
 constexpr int REC4 = 6;        // float4 planes per staged entry (see stage_entry)
 constexpr int ACC_STRIDE = 22; // floats per (wave, entry) result slot in the backward (21 used)
@@ -46,27 +46,16 @@ __device__ __forceinline__ void cross3(const float a[3], const float b[3], float
 //   plane 0: A.xyz B.x   plane 1: B.yz C.xy   plane 2: C.z dx0 dy0 Tw.x
 //   plane 3: Tw.yz opacity mask_lo   plane 4: normal.xyz r   plane 5: g b mask_hi -
 //   mask bit (gy*8 + gx) <=> the 2x2 block (gx, gy) of the tile may see the surfel
+// `id` and its cull box `cb` (minx, maxx, miny, maxy of {alpha >= 1/255}, conservative) were fetched
+// one round ahead by the caller, so only the record gather sits on the round's critical path.
 template <int CHUNK>
-__device__ __forceinline__ void stage_entry(const uint32_t *__restrict__ point_list,
-                                            const float4 *__restrict__ geom,
-                                            const float4 *__restrict__ cullbox, const uint32_t pos,
-                                            const bool valid, const float X0, const float Y0,
-                                            float4 *rec, uint32_t *ids) {
-    const int e = threadIdx.x;
+__device__ __forceinline__ void stage_entry(const float4 *__restrict__ geom, const uint32_t id,
+                                            const float4 cb, const bool valid, const float X0,
+                                            const float Y0, float4 *rec, uint32_t *ids,
+                                            const int e = threadIdx.x) {
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
-    uint32_t mask_lo = 0, mask_hi = 0, id = 0;
+    uint32_t mask_lo = 0, mask_hi = 0;
     if (valid) {
-        id = point_list[pos];
-        const float4 *g = geom + (size_t)id * 5;
-        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
-        const float4 cb = cullbox[id];  // minx, maxx, miny, maxy of {alpha >= 1/255}, conservative
-        const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
-        const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
-        const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
-        float A[3], B[3], C[3];
-        cross3(k0, l0, A);
-        cross3(Tw, l0, B);
-        cross3(k0, Tw, C);
         // block gx covers pixels X0+2gx, X0+2gx+1: overlap <=> minx <= X0+2gx+1 and maxx >= X0+2gx
         const int gx0 = (int)ceilf(fminf(fmaxf((cb.x - X0 - 1.f) * 0.5f, 0.f), 8.f));
         const int gx1 = (int)floorf(fminf(fmaxf((cb.y - X0) * 0.5f, -1.f), 7.f));
@@ -80,6 +69,17 @@ __device__ __forceinline__ void stage_entry(const uint32_t *__restrict__ point_l
                 if (r + 4 >= gy0 && r + 4 <= gy1) mask_hi |= cols << (8 * r);
             }
         }
+    }
+    if (mask_lo | mask_hi) {  // the 80-byte record is only fetched for surfels the tile can see
+        const float4 *g = geom + (size_t)id * 5;
+        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
+        const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
+        const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
+        const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
+        float A[3], B[3], C[3];
+        cross3(k0, l0, A);
+        cross3(Tw, l0, B);
+        cross3(k0, Tw, C);
         r0 = make_float4(A[0], A[1], A[2], B[0]);
         r1 = make_float4(B[1], B[2], C[0], C[1]);
         r2 = make_float4(C[2], g2.y - X0, g2.z - Y0, Tw[0]);
@@ -89,7 +89,7 @@ __device__ __forceinline__ void stage_entry(const uint32_t *__restrict__ point_l
     }
     rec[0 * CHUNK + e] = r0; rec[1 * CHUNK + e] = r1; rec[2 * CHUNK + e] = r2;
     rec[3 * CHUNK + e] = r3; rec[4 * CHUNK + e] = r4; rec[5 * CHUNK + e] = r5;
-    if (ids) ids[e] = id;
+    if (ids) ids[e] = valid ? id : 0u;
 }
 
 struct Hit {
@@ -219,11 +219,35 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     FwdPixel px;
     px.done = !inside;
     uint32_t *dbg_hdr = const_cast<uint32_t *>(header);
+    const long long dbg_t0 = (v.dbg & 32u) ? (long long)__builtin_readcyclecounter() : 0ll;
+    int dbg_rounds = 0;
 
+    // software pipeline of the list walk: ids two rounds ahead, cull boxes one round ahead
+    const int tid = threadIdx.x;
+    constexpr int SPT = CHUNK / 256;  // list entries staged per thread and round
+    uint32_t id1[SPT], id2[SPT];
+    float4 cb1[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+        const int o = q * 256 + tid;
+        id1[q] = o < total ? point_list[range.x + o] : 0u;
+        id2[q] = CHUNK + o < total ? point_list[range.x + CHUNK + o] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < SPT; q++) cb1[q] = q * 256 + tid < total ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < total; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
-        stage_entry<CHUNK>(point_list, geom, cullbox, range.x + base + threadIdx.x,
-                           base + (int)threadIdx.x < total, X0, Y0, rec, nullptr);
+        dbg_rounds++;
+#pragma unroll
+        for (int q = 0; q < SPT; q++) {
+            const int o = q * 256 + tid;
+            const uint32_t id0 = id1[q];
+            const float4 cb0 = cb1[q];
+            id1[q] = id2[q];
+            id2[q] = base + 2 * CHUNK + o < total ? point_list[range.x + base + 2 * CHUNK + o] : 0u;
+            cb1[q] = base + CHUNK + o < total ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            stage_entry<CHUNK>(geom, id0, cb0, base + o < total, X0, Y0, rec, nullptr, o);
+        }
         __syncthreads();
         if (__ballot(!px.done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
 #pragma unroll 1
@@ -237,6 +261,8 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             for (int half = 0; half < 2; half++) {
                 uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
                 const int jb = sub + 32 * half;
+                // a quad whose four pixels are finished stops consuming its list
+                if (((__ballot(px.done) >> (lane & ~3)) & 0xfull) == 0xfull) mm = 0u;
                 // each quad pops its own next entries; two per trip (independent evaluations),
                 // blended strictly in list order; records are fetched one trip ahead
                 bool has0 = mm != 0u;
@@ -266,6 +292,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     px.blend<CHUNK>(rec, j0, base, e0, h0);
                     px.blend<CHUNK>(rec, j1, base, e1, h1);
                     c0 = x0; c1 = x1; j0 = k0; j1 = k1; has0 = n0; has1 = n1;
+                    if (((__ballot(px.done) >> (lane & ~3)) & 0xfull) == 0xfull) { mm = 0u; has0 = false; has1 = false; }
                 }
             }
         }
@@ -288,6 +315,10 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         out_allmap[4 * HW + pix] = px.N2;
         out_allmap[5 * HW + pix] = px.median_depth;
         out_allmap[6 * HW + pix] = px.distortion;
+        if ((v.dbg & 32u) && lane == 0) {  // per-wave cycle count / rounds, debug only (clobbers two outputs)
+            out_allmap[6 * HW + pix] = (float)((long long)__builtin_readcyclecounter() - dbg_t0);
+            out_allmap[5 * HW + pix] = (float)dbg_rounds;
+        }
     }
 }
 
@@ -455,13 +486,24 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 
     // back to front, CHUNK entries at a time: chunk c covers list positions [lo, lo + cnt)
     const int nchunks = (total + CHUNK - 1) / CHUNK;
+    // software pipeline of the list walk (threads 0..CHUNK-1 stage): ids two rounds ahead, cull
+    // boxes one round ahead
+    const int tid = threadIdx.x;
+    const bool stager = tid < CHUNK;
+    auto in_chunk = [&](int c) { return stager && c >= 0 && c * CHUNK + tid < total; };
+    uint32_t id1 = in_chunk(nchunks - 1) ? point_list[range.x + (nchunks - 1) * CHUNK + tid] : 0u;
+    uint32_t id2 = in_chunk(nchunks - 2) ? point_list[range.x + (nchunks - 2) * CHUNK + tid] : 0u;
+    float4 cb1 = in_chunk(nchunks - 1) ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = nchunks - 1; c >= 0; c--) {
         const int lo = c * CHUNK;
         const int cnt = min(CHUNK, total - lo);
+        const uint32_t id0 = id1;
+        const float4 cb0 = cb1;
+        id1 = id2;
+        id2 = in_chunk(c - 2) ? point_list[range.x + (c - 2) * CHUNK + tid] : 0u;
+        cb1 = in_chunk(c - 1) ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();  // previous chunk's phase S2 is done with rec / acc / s_id
-        if ((int)threadIdx.x < CHUNK)
-            stage_entry<CHUNK>(point_list, geom, cullbox, range.x + lo + threadIdx.x,
-                               (int)threadIdx.x < cnt, X0, Y0, rec, s_id);
+        if (stager) stage_entry<CHUNK>(geom, id0, cb0, tid < cnt, X0, Y0, rec, s_id);
         if (threadIdx.x < 4 * (CHUNK / 64)) (&touched[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
 
