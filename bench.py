@@ -143,6 +143,37 @@ def measure_roofline(scenes, settings, gc, ga, args):
     return roof, table, D
 
 
+def attention_leg(device, scenes):
+    """Group cross-attention step of one transformer layer for this rank's scenes (forward, bf16
+    MFMA): time and FLOP rate against the 2.5 PFLOP/s dense bf16 peak.  Reported beside the raster;
+    not part of `value`."""
+    from torch import nn
+    from lara_amd import rasterizer
+    from lara_amd.attention import GroupCrossAttention
+    torch.manual_seed(0)
+    mod = GroupCrossAttention.from_modules(
+        nn.LayerNorm(256), nn.MultiheadAttention(256, 16, kdim=800, vdim=800, bias=False, batch_first=True)).to(device)
+    G = 4096 * scenes
+    x = torch.randn(G, 8, 256, device=device)
+    cond = torch.randn(G, 4, 800, device=device)
+    with torch.no_grad():
+        for _ in range(2):
+            mod(x, cond)
+        torch.cuda.synchronize()
+        rasterizer.profile_enable(True)
+        for _ in range(5):
+            mod(x, cond)
+        torch.cuda.synchronize()
+    rec = rasterizer.profile_collect()
+    rasterizer.profile_enable(False)
+    us = 1e3 * sum(ms for _, ms in rec) / 5
+    flops = G * (2 * 8 * 256 * 256 * 2 + 2 * 4 * 800 * 512 + 2 * 2 * 8 * 4 * 16 * 16)
+    return {"workload": f"GroupAttBlock attention step (LN, q/k/v/out projections, QK^T, softmax, AV), "
+                        f"{scenes} scenes = {G} groups, forward, bf16 MFMA / fp32 accumulate",
+            "us_per_layer": round(us, 1), "achieved": round(flops / us / 1e6, 1), "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 2500.0, 4), "bound": "mfma"}
+
+
 def cpu_baseline(args):
     """The CPU oracle (fp32 restatement, OpenMP over tiles) on a bounded sample of the same
     workload: the 8 views of scene 0, forward + backward each (about 10-30 s of CPU work)."""
@@ -254,6 +285,8 @@ def main():
         out["roofline"] = roof
         out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
                               "alg_GBs": round(v["alg_GBs"], 1)} for k, v in table.items()}
+    if rank == 0 and not args.no_roofline:
+        out["attention"] = attention_leg(device, args.scenes)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
