@@ -56,25 +56,54 @@ ln_cast_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
 }
 
 // ---- C[M,N] = A[M,K] . W[N,K]^T, bf16 in, fp32 accumulate ------------------------------------------
-// Workgroup tile 128x128, four waves as 2x2, wave tile 64x64 = 2x2 MFMA tiles of 32x32 (K step 16).
-// Both operands have K contiguous, so a lane's 8-element fragment is one 16-byte load; fragments go
-// straight from L2/L1 to VGPRs (the A and W panels of a workgroup are re-read by its two wave
-// columns / rows through L1).  MFMA 32x32x16 operand map: A[i = lane&31][k = 8*(lane>>5) + e],
+// Workgroup tile 128x128, K step 32, four waves as 2x2, wave tile 64x64 = 2x2 MFMA tiles of 32x32.
+// Operand panels are staged through LDS (double buffered, register staging: the next K tile is
+// loaded into VGPRs while the current one feeds the matrix cores).  Both operands have K contiguous,
+// so a fragment is one ds_read_b128; LDS rows are padded from 64 to 80 bytes, which spreads the 16
+// rows a ds_read_b128 lane group touches over all 16 sixteen-byte slots of the 256-byte bank row
+// (conflict free).  MFMA 32x32x16 operand map: A[i = lane&31][k = 8*(lane>>5) + e],
 // B[k = 8*(lane>>5) + e][j = lane&31]; C/D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+constexpr int GM = 128, GN = 128, GK = 32;
+constexpr int LROW = GK * 2 + 16;  // padded LDS row, bytes
+
 template <int EPI>  // 0: bf16 store   1: fp32 store of acc + resid
 __global__ void __launch_bounds__(256)
 gemm_bf16_nt_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ W,
                     void *__restrict__ Cout, const float *__restrict__ resid, const int M, const int N,
                     const int K) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = blockIdx.x * 128 + (wave >> 1) * 64, n0 = blockIdx.y * 128 + (wave & 1) * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][(GM + GN) * LROW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bm0 = blockIdx.x * GM, bn0 = blockIdx.y * GN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int r = lane & 31, kh = lane >> 5;
-    const unsigned short *ap[2], *bp[2];
+
+    // staging map: 256 rows (128 of A, 128 of W) x 4 sixteen-byte chunks per K tile; thread t moves
+    // chunk (t & 3) of rows (t >> 2) + 64 i, i = 0..3
+    const int srow = tid >> 2, schunk = tid & 3;
+    const unsigned short *gsrc[4];
+    int loff[4];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        ap[i] = A + (size_t)min(m0 + i * 32 + r, M - 1) * K + 8 * kh;
-        bp[i] = W + (size_t)min(n0 + i * 32 + r, N - 1) * K + 8 * kh;
+    for (int i = 0; i < 4; i++) {
+        const int row = srow + 64 * i;  // 0..255: A rows then W rows
+        const unsigned short *base = row < GM ? A + (size_t)min(bm0 + row, M - 1) * K
+                                              : W + (size_t)min(bn0 + row - GM, N - 1) * K;
+        gsrc[i] = base + schunk * 8;
+        loff[i] = row * LROW + schunk * 16;
     }
+    const int ktiles = (K + GK - 1) / GK;
+    uint4 stage[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = kt * GK + schunk * 8;
+            stage[i] = k < K ? *(const uint4 *)(gsrc[i] + (size_t)kt * GK) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) *(uint4 *)(&lds[buf][loff[i]]) = stage[i];
+    };
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -83,42 +112,62 @@ gemm_bf16_nt_kernel(const unsigned short *__restrict__ A, const unsigned short *
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        bf16x8 a[4][2], b[4][2];
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) gload(kt + 1);  // in flight while this tile is multiplied
+        const unsigned char *la = &lds[buf][(wm + r) * LROW + kh * 16];
+        const unsigned char *lb = &lds[buf][(GM + wn + r) * LROW + kh * 16];
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < GK / 16; s++) {
+            bf16x8 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const int k = k0 + 16 * s;
-                if (k < K) {
-                    a[s][i] = *(const bf16x8 *)(ap[i] + k);
-                    b[s][i] = *(const bf16x8 *)(bp[i] + k);
-                }
+                a[i] = *(const bf16x8 *)(la + i * 32 * LROW + s * 32);
+                b[i] = *(const bf16x8 *)(lb + i * 32 * LROW + s * 32);
             }
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            if (k0 + 16 * s < K) {
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (kt + 1 < ktiles) lstore(buf ^ 1);  // the other buffer was last read one iteration ago
+        __syncthreads();
     }
+    // Epilogue through LDS: the accumulator layout gives every lane one element of 16 different
+    // rows (4-byte stores, issue bound); bouncing a 32x64 block per wave through LDS turns that into
+    // 16-byte row-contiguous loads of the residual and 16-byte stores.
+    float *ep = (float *)&lds[0][0] + wave * (32 * 68);  // 32 rows x (64 + 4 pad) floats per wave
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh, col = n0 + j * 32 + r;
-                if (row < M && col < N) {
-                    const size_t o = (size_t)row * N + col;
-                    if (EPI == 0) ((unsigned short *)Cout)[o] = f2bf(acc[i][j][e]);
-                    else ((float *)Cout)[o] = acc[i][j][e] + resid[o];
+            for (int e = 0; e < 16; e++)
+                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
+            const int row = bm0 + wm + i * 32 + lr, col = bn0 + wn + c4;
+            if (row < M && col < N) {
+                const float4 v = *(const float4 *)(ep + lr * 68 + c4);
+                const size_t o = (size_t)row * N + col;
+                if (EPI == 0) {
+                    ushort4 h;
+                    h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
+                    *(ushort4 *)((unsigned short *)Cout + o) = h;
+                } else {
+                    const float4 rs = *(const float4 *)(resid + o);
+                    *(float4 *)((float *)Cout + o) = make_float4(v.x + rs.x, v.y + rs.y, v.z + rs.z, v.w + rs.w);
                 }
             }
+        }
+    }
 }
 
 // ---- per-group softmax attention on 16x16x16 bf16 MFMA ---------------------------------------------
