@@ -32,7 +32,7 @@
 namespace {
 
 constexpr int FWD_CHUNK = 512;  // list entries staged per round, forward
-constexpr int BWD_CHUNK = 128;  // backward (its LDS also holds the f64 accumulators)
+constexpr int BWD_CHUNK = 128;  // backward (its LDS also holds the per-wave result slices)
 constexpr int REC4 = 6;        // float4 planes per staged entry (see stage_entry)
 constexpr int ACC_STRIDE = 22; // floats per (wave, entry) result slot in the backward (21 used)
 
@@ -253,8 +253,8 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 #pragma unroll 1
         for (int sub = 0; sub < CHUNK; sub += 64) {
             if (base + sub >= total) break;
-            const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + sub + lane;
-            const uint32_t bm = __float_as_uint((wave >> 1) ? mrec->z : mrec->w);
+            const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + min(sub + lane, CHUNK - 1);
+            const uint32_t bm = sub + lane < CHUNK ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
             if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) == 0ull) continue;
             const unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
 #pragma unroll 1
@@ -433,7 +433,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     // per wave instruction with a long latency -- tools/ubench/lds_atomic.hip.)
     __shared__ float4 rec[REC4 * CHUNK];
     __shared__ float acc[4 * CHUNK * ACC_STRIDE];  // [wave][entry][slot]
-    __shared__ unsigned long long touched[4][CHUNK / 64];
+    __shared__ unsigned long long touched[4][(CHUNK + 63) / 64];
     __shared__ uint32_t s_id[CHUNK];
     __shared__ uint32_t s_maxc;
     if (header[1]) return;
@@ -504,7 +504,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         cb1 = in_chunk(c - 1) ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();  // previous chunk's phase S2 is done with rec / acc / s_id
         if (stager) stage_entry<CHUNK>(geom, id0, cb0, tid < cnt, X0, Y0, rec, s_id);
-        if (threadIdx.x < 4 * (CHUNK / 64)) (&touched[0][0])[threadIdx.x] = 0ull;
+        if (threadIdx.x < 4 * ((CHUNK + 63) / 64)) (&touched[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
 
 #pragma unroll 1
@@ -512,8 +512,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             // The backward keeps ONE candidate stream per wave (8x8 quadrant): its per-entry sums
             // must be reduced over all pixels anyway, and a wave-wide butterfly + one 22-lane
             // ds_add_f64 is far cheaper than per-quad LDS atomics (which collide on the same entry).
-            const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + sub + lane;
-            const uint32_t bm = __float_as_uint((wave >> 1) ? mrec->z : mrec->w);
+            const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + min(sub + lane, CHUNK - 1);
+            const uint32_t bm = sub + lane < CHUNK ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
             unsigned long long m = __ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u);
             if (m == 0ull) continue;
             unsigned long long tmask = 0ull;  // entries of this sub-chunk this wave produced sums for
