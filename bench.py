@@ -136,8 +136,17 @@ def measure_roofline(scenes, settings, gc, ga, args):
              for k, (n, t) in agg.items()}
     dom = max(table, key=lambda k: table[k]["avg_us"] * table[k]["launches"])
     t = table[dom]
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE): they need rocprofv3 passes of
+    # their own, so they are collected by tools/gpu_traffic.sh and committed under profiles/
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        if args.regime == "init" and args.grid == 64 and args.res == 512:
+            traffic = tj["bytes_per_launch"][dom]["total"]
+    except Exception:
+        traffic = None
     roof = {"kernel": dom, "bound": "hbm", "achieved": round(t["alg_GBs"], 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(t["alg_GBs"] / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(t["alg_GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
             "avg_launch_us": round(t["avg_us"], 2), "alg_bytes_per_launch": t["alg_bytes"],
             "pairs_per_frame_D": D}
     return roof, table, D
@@ -213,13 +222,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    local = local % torch.cuda.device_count()  # (several ranks on one GPU only in the gloo self-test)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("LARA_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; gloo for plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from lara_amd import rasterizer
     rasterizer.load_library()
