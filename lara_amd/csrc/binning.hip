@@ -247,7 +247,7 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t x, int src_lane) {
 
 // compare-exchange every key with partner thread pt's key (REVERSED: its key E-1-e, the mirror
 // step that opens a merge); the lower-numbered thread keeps the minima
-template <int E, bool REVERSED>
+template <int E, int NT, bool REVERSED>
 __device__ __forceinline__ void xchg(uint64_t (&x)[E], const int t, const int pt, uint64_t *lds) {
     uint64_t o[E];
     if ((t ^ pt) < 64) {  // partner in the same wave (uniform: the xor distance is common to all t)
@@ -255,10 +255,10 @@ __device__ __forceinline__ void xchg(uint64_t (&x)[E], const int t, const int pt
         for (int e = 0; e < E; e++) o[e] = shfl64(x[REVERSED ? E - 1 - e : e], pt & 63);
     } else {
 #pragma unroll
-        for (int e = 0; e < E; e++) lds[e * 256 + t] = x[e];
+        for (int e = 0; e < E; e++) lds[e * NT + t] = x[e];
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < E; e++) o[e] = lds[(REVERSED ? E - 1 - e : e) * 256 + pt];
+        for (int e = 0; e < E; e++) o[e] = lds[(REVERSED ? E - 1 - e : e) * NT + pt];
         __syncthreads();
     }
     const bool keep_min = t < pt;
@@ -269,7 +269,7 @@ __device__ __forceinline__ void xchg(uint64_t (&x)[E], const int t, const int pt
     }
 }
 
-template <int E>
+template <int E, int NT>
 __device__ __forceinline__ void block_sort(uint64_t (&x)[E], uint64_t *lds) {
     const int t = threadIdx.x;
 #pragma unroll
@@ -286,10 +286,10 @@ __device__ __forceinline__ void block_sort(uint64_t (&x)[E], uint64_t *lds) {
                 if ((e & j) == 0) ce(x[e], x[e | j]);
     }
 #pragma unroll 1
-    for (int kt = 2; kt <= 256; kt <<= 1) {  // merges of kt threads' worth of keys
-        xchg<E, true>(x, t, t ^ (kt - 1), lds);
+    for (int kt = 2; kt <= NT; kt <<= 1) {  // merges of kt threads' worth of keys
+        xchg<E, NT, true>(x, t, t ^ (kt - 1), lds);
 #pragma unroll 1
-        for (int jt = kt >> 2; jt >= 1; jt >>= 1) xchg<E, false>(x, t, t ^ jt, lds);
+        for (int jt = kt >> 2; jt >= 1; jt >>= 1) xchg<E, NT, false>(x, t, t ^ jt, lds);
 #pragma unroll
         for (int j = E >> 1; j >= 1; j >>= 1)
 #pragma unroll
@@ -312,14 +312,14 @@ struct PairMap {
     }
 };
 
-template <int E>
+template <int E, int NT>
 __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ seg, const uint32_t n,
                                           uint32_t *__restrict__ out, uint64_t *lds, const PairMap &pm) {
     uint64_t x[E];
     const uint32_t i0 = threadIdx.x * E;
 #pragma unroll
     for (int e = 0; e < E; e++) x[e] = (i0 + e < n) ? seg[i0 + e] : ~0ull;
-    block_sort<E>(x, lds);
+    block_sort<E, NT>(x, lds);
 #pragma unroll
     for (int e = 0; e < E; e++)
         if (i0 + e < n) {
@@ -331,7 +331,7 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ seg, cons
 // LARGE = false: tiles with n <= 2048 (16 KB LDS); LARGE = true: 2048 < n (64 KB LDS; lists longer
 // than 8192 fall back to the generic network run directly on the global segment)
 template <bool LARGE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LARGE ? 1024 : 512)
 tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ header,
                  const uint32_t *__restrict__ tile_order, uint64_t *__restrict__ keys,
                  uint32_t *__restrict__ point_list, const uint4 *__restrict__ rect,
@@ -346,13 +346,12 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
     uint32_t *out = point_list + rg.x;
     const PairMap pm{rect, pair_base, pair_pos, tile % v.gx, tile / v.gx, rg.x};
     if (!LARGE) {
-        if (n <= 256u) sort_tile<1>(seg, n, out, lds, pm);
-        else if (n <= 512u) sort_tile<2>(seg, n, out, lds, pm);
-        else if (n <= 1024u) sort_tile<4>(seg, n, out, lds, pm);
-        else sort_tile<8>(seg, n, out, lds, pm);
-    } else {
-        if (n <= 4096u) sort_tile<16>(seg, n, out, lds, pm);
-        else if (n <= 8192u) sort_tile<32>(seg, n, out, lds, pm);
+        if (n <= 512u) sort_tile<1, 512>(seg, n, out, lds, pm);
+        else if (n <= 1024u) sort_tile<2, 512>(seg, n, out, lds, pm);
+        else sort_tile<4, 512>(seg, n, out, lds, pm);
+    } else {  // 1024 threads: long lists are few, give each of them 16 waves
+        if (n <= 4096u) sort_tile<4, 1024>(seg, n, out, lds, pm);
+        else if (n <= 8192u) sort_tile<8, 1024>(seg, n, out, lds, pm);
         else {
             bitonic_sort(seg, n, next_pow2(n));
             for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -383,14 +382,14 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
     L2D_CHECK_LAUNCH();
     {
         L2D_PROF("tile_sort_small", s);
-        hipLaunchKernelGGL((tile_sort_kernel<false>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
+        hipLaunchKernelGGL((tile_sort_kernel<false>), dim3(v.tiles), dim3(512), 0, s, v, st.ranges,
                            st.header, st.tile_order, sc.keys, st.point_list, sc.rect, st.pair_base,
                            st.pair_pos);
     }
     L2D_CHECK_LAUNCH();
     {
         L2D_PROF("tile_sort_large", s);
-        hipLaunchKernelGGL((tile_sort_kernel<true>), dim3(v.tiles), dim3(256), 0, s, v, st.ranges,
+        hipLaunchKernelGGL((tile_sort_kernel<true>), dim3(v.tiles), dim3(1024), 0, s, v, st.ranges,
                            st.header, st.tile_order, sc.keys, st.point_list, sc.rect, st.pair_base,
                            st.pair_pos);
     }
