@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LARA2DGS_ABI_VERSION 1
+#define LARA2DGS_ABI_VERSION 2
 
 #define LARA2DGS_OK 0
 #define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
@@ -67,7 +67,8 @@ typedef struct lara2dgs_view {
 /* Byte offsets of the sections of the `state` buffer (for tests, debugging and tooling; the
  * integer sections are the bit-exact parity surface: SURVEY.md section 8a R2-R7). */
 typedef struct lara2dgs_state_layout {
-    int64_t header;      /* uint32[16]: [0]=num_rendered, [1]=overflow flag, [2]=max tile list length */
+    int64_t header;      /* uint32[16]: [0]=num_rendered, [1]=overflow flag, [2]=max tile list length,
+                          * [3]=number of full segments (interior boundaries) */
     int64_t geom;        /* float[P][20]: Tu(3) Tv(3) Tw(3) xy(2) opacity normal(3) depth rgb(3) clamp-bits */
     int64_t cullbox;     /* float[P][4]: min x, max x, min y, max y of the pixels a surfel can reach with
                           * alpha >= 1/255 (conservative; lets the composite skip 8x8 quadrants) */
@@ -78,8 +79,14 @@ typedef struct lara2dgs_state_layout {
     int64_t pair_base;   /* uint32[P+1]: first (tile, surfel) pair of each surfel, surfel-major order */
     int64_t pair_pos;    /* uint32[capacity]: surfel-major pair index -> position in point_list; lets the
                           * backward gather per-surfel gradients deterministically, without atomics */
-    int64_t final_T;     /* float[3][H][W]: T, M1, M2 */
+    int64_t final_T;     /* float[10][H][W]: end-of-walk T, M1, M2, colour(3), depth, normal(3) sums */
     int64_t n_contrib;   /* uint32[2][H][W]: last contributor, median contributor */
+    int64_t seg_base;    /* uint32[tiles+1]: exclusive scan of floor((len-1)/1024) = interior boundaries when a
+                          * tile's list is cut into 1024-entry segments (the backward's unit of work) */
+    int64_t bwd_order;   /* uint32[tiles]: tile ids by length of the last (partial) segment, longest first */
+    int64_t bwd_items;   /* uint32[capacity/1024+1][2]: (tile, segment) of every full segment */
+    int64_t ckpt;        /* float[capacity/1024+1][10][256]: the ten per-pixel running sums as the forward walk
+                          * crosses a segment boundary; lets segments of one tile run on different CUs */
     int64_t total;
 } lara2dgs_state_layout;
 

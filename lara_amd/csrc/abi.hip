@@ -85,6 +85,10 @@ StateView carve_state(const ViewDev &v, void *state) {
     s.pair_pos = (uint32_t *)(b + L.pair_pos);
     s.final_T = (float *)(b + L.final_T);
     s.n_contrib = (uint32_t *)(b + L.n_contrib);
+    s.seg_base = (uint32_t *)(b + L.seg_base);
+    s.bwd_order = (uint32_t *)(b + L.bwd_order);
+    s.bwd_items = (uint2 *)(b + L.bwd_items);
+    s.ckpt = (float *)(b + L.ckpt);
     return s;
 }
 

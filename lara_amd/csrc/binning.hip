@@ -49,7 +49,9 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, const uint32_t n, const uint
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ sub_start,
                  uint2 *__restrict__ ranges, uint32_t *__restrict__ header,
-                 uint32_t *__restrict__ tile_order, uint32_t *__restrict__ block_tot) {
+                 uint32_t *__restrict__ tile_order, uint32_t *__restrict__ block_tot,
+                 uint32_t *__restrict__ seg_base, uint32_t *__restrict__ bwd_order,
+                 uint2 *__restrict__ bwd_items) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s, s_max;
     __shared__ uint32_t bcnt[64];
@@ -148,6 +150,59 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         const uint2 rg = ranges[i];
         const uint32_t b = 63u - (uint32_t)(((uint64_t)(rg.y - rg.x) * 64u) / denom);
         tile_order[atomicAdd(&bcnt[b], 1u)] = (uint32_t)i;
+    }
+    // Backward work list.  A tile's list is cut into L2D_SEG-entry segments; nb = floor((len-1)/SEG)
+    // of them are full and get an entry in bwd_items (and a checkpoint row, seg_base[tile] + s, at
+    // their upper boundary); the last, partial one is launched per tile in bwd_order (longest first).
+    __syncthreads();
+    if (tid == 0) carry_s = 0;
+    if (tid < 64) bcnt[tid] = 0;
+    __syncthreads();
+    const bool overflow = header[1] != 0u;  // then the lists are unusable and bwd_items may not fit
+    for (int base = 0; base < v.tiles; base += 1024) {
+        const int i = base + tid;
+        uint32_t len = 0;
+        if (i < v.tiles) { const uint2 rg = ranges[i]; len = rg.y - rg.x; }
+        const uint32_t nb = len ? (len - 1u) / L2D_SEG : 0u;
+        uint32_t x = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wave_sums[wid] = x;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; w++) wave_off += wave_sums[w];
+        const uint32_t incl = carry_s + wave_off + x;
+        if (i < v.tiles) {
+            seg_base[i] = incl - nb;
+            if (!overflow)
+                for (uint32_t q = 0; q < nb; q++) bwd_items[incl - nb + q] = make_uint2((uint32_t)i, q);
+            const uint32_t pl = len - nb * L2D_SEG;  // 0 .. L2D_SEG
+            atomicAdd(&bcnt[63u - (pl * 64u) / (L2D_SEG + 1u)], 1u);
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = incl;
+        __syncthreads();
+    }
+    if (tid == 0) { seg_base[v.tiles] = carry_s; header[3] = carry_s; }
+    if (tid < 64) {
+        const uint32_t c = bcnt[tid];
+        uint32_t x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        bcnt[tid] = x - c;
+    }
+    __syncthreads();
+    for (int i = tid; i < v.tiles; i += 1024) {
+        const uint2 rg = ranges[i];
+        const uint32_t len = rg.y - rg.x;
+        const uint32_t pl = len - (len ? (len - 1u) / L2D_SEG : 0u) * L2D_SEG;
+        bwd_order[atomicAdd(&bcnt[63u - (pl * 64u) / (L2D_SEG + 1u)], 1u)] = (uint32_t)i;
     }
     // exclusive scan (in place) of the per-surfel-block pair totals -> surfel-major pair numbering
     __syncthreads();
@@ -368,7 +423,8 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
     {
         L2D_PROF("tile_scan", s);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
-                           st.ranges, st.header, st.tile_order, sc.block_tot);
+                           st.ranges, st.header, st.tile_order, sc.block_tot, st.seg_base, st.bwd_order,
+                           st.bwd_items);
     }
     L2D_CHECK_LAUNCH();
     if (v.P == 0) return LARA2DGS_OK;

@@ -15,6 +15,8 @@
 #define L2D_SLICES 16            // per-tile counters are split 16 ways to shorten same-address atomic chains
 #define L2D_LDS_HIST_TILES 8192  // per-workgroup LDS tile histogram up to this many tiles (32 KB)
 #define GRAD_F 20          // floats per surfel in the backward accumulator (18 used)
+#define L2D_SEG 1024       // backward work unit: a tile's list is cut into segments of this many entries
+#define L2D_CKPT_F 10      // floats per pixel in a segment-boundary checkpoint / in the per-pixel finals
 
 // Everything a kernel needs to know about the view, passed by value (lands in SGPRs / kernarg).
 struct ViewDev {
@@ -34,8 +36,12 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     uint32_t *tile_order; // [tiles] tile ids, longest list first (work-balanced launch order)
     uint32_t *pair_base;  // [P+1] first pair index of each surfel (exclusive scan of tiles touched)
     uint32_t *pair_pos;   // [cap] pair index (surfel-major) -> position in the sorted list
-    float *final_T;       // [3][HW]
+    float *final_T;       // [L2D_CKPT_F][HW] end-of-walk T, M1, M2, C(3), D, N(3)
     uint32_t *n_contrib;  // [2][HW]
+    uint32_t *seg_base;   // [tiles+1] exclusive scan of interior segment boundaries per tile
+    uint32_t *bwd_order;  // [tiles] tile ids by length of their last (partial) segment, longest first
+    uint2 *bwd_items;     // [cap/L2D_SEG+1] (tile, segment) of every full segment
+    float *ckpt;          // [cap/L2D_SEG+1][L2D_CKPT_F][256] per-pixel prefix sums at segment boundaries
 };
 
 struct ScratchView {
@@ -63,8 +69,13 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->tile_order = o;  o = align_up(o + tiles * 4, 256);
     L->pair_base = o;   o = align_up(o + ((int64_t)P + 1) * 4, 256);
     L->pair_pos = o;    o = align_up(o + cap * 4, 256);
-    L->final_T = o;     o = align_up(o + 3 * HW * 4, 256);
+    L->final_T = o;     o = align_up(o + L2D_CKPT_F * HW * 4, 256);
     L->n_contrib = o;   o = align_up(o + 2 * HW * 4, 256);
+    const int64_t nseg = cap / L2D_SEG + 1;
+    L->seg_base = o;    o = align_up(o + (tiles + 1) * 4, 256);
+    L->bwd_order = o;   o = align_up(o + tiles * 4, 256);
+    L->bwd_items = o;   o = align_up(o + nseg * 8, 256);
+    L->ckpt = o;        o = align_up(o + nseg * L2D_CKPT_F * 256 * 4, 256);
     L->total = o;
 }
 

@@ -32,9 +32,7 @@
 namespace {
 
 constexpr int FWD_CHUNK = 512;  // list entries staged per round, forward
-constexpr int BWD_CHUNK = 128;  // backward (its LDS also holds the per-wave result slices)
 constexpr int REC4 = 6;        // float4 planes per staged entry (see stage_entry)
-constexpr int ACC_STRIDE = 22; // floats per (wave, entry) result slot in the backward (21 used)
 
 __device__ __forceinline__ void cross3(const float a[3], const float b[3], float o[3]) {
     o[0] = a[1] * b[2] - a[2] * b[1];
@@ -48,29 +46,24 @@ __device__ __forceinline__ void cross3(const float a[3], const float b[3], float
 //   mask bit (gy*8 + gx) <=> the 2x2 block (gx, gy) of the tile may see the surfel
 // `id` and its cull box `cb` (minx, maxx, miny, maxy of {alpha >= 1/255}, conservative) were fetched
 // one round ahead by the caller, so only the record gather sits on the round's critical path.
+// Returns the candidate block rectangle packed as gx0 | gx1 << 4 | gy0 << 8 | gy1 << 12 | 1 << 16
+// (0 when the tile cannot see the surfel).
 template <int CHUNK>
-__device__ __forceinline__ void stage_entry(const float4 *__restrict__ geom, const uint32_t id,
-                                            const float4 cb, const bool valid, const float X0,
-                                            const float Y0, float4 *rec, uint32_t *ids,
-                                            const int e = threadIdx.x) {
+__device__ __forceinline__ uint32_t stage_entry(const float4 *__restrict__ geom, const uint32_t id,
+                                                const float4 cb, const bool valid, const float X0,
+                                                const float Y0, float4 *rec, uint32_t *ids,
+                                                const int e = threadIdx.x) {
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
-    uint32_t mask_lo = 0, mask_hi = 0;
+    uint32_t mask_lo = 0, mask_hi = 0, rectpack = 0;
+    int gx0 = 0, gx1 = -1, gy0 = 0, gy1 = -1;
     if (valid) {
         // block gx covers pixels X0+2gx, X0+2gx+1: overlap <=> minx <= X0+2gx+1 and maxx >= X0+2gx
-        const int gx0 = (int)ceilf(fminf(fmaxf((cb.x - X0 - 1.f) * 0.5f, 0.f), 8.f));
-        const int gx1 = (int)floorf(fminf(fmaxf((cb.y - X0) * 0.5f, -1.f), 7.f));
-        const int gy0 = (int)ceilf(fminf(fmaxf((cb.z - Y0 - 1.f) * 0.5f, 0.f), 8.f));
-        const int gy1 = (int)floorf(fminf(fmaxf((cb.w - Y0) * 0.5f, -1.f), 7.f));
-        if (gx0 <= gx1 && gy0 <= gy1) {
-            const uint32_t cols = ((1u << (gx1 - gx0 + 1)) - 1u) << gx0;  // 8 bits
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (r >= gy0 && r <= gy1) mask_lo |= cols << (8 * r);
-                if (r + 4 >= gy0 && r + 4 <= gy1) mask_hi |= cols << (8 * r);
-            }
-        }
+        gx0 = (int)ceilf(fminf(fmaxf((cb.x - X0 - 1.f) * 0.5f, 0.f), 8.f));
+        gx1 = (int)floorf(fminf(fmaxf((cb.y - X0) * 0.5f, -1.f), 7.f));
+        gy0 = (int)ceilf(fminf(fmaxf((cb.z - Y0 - 1.f) * 0.5f, 0.f), 8.f));
+        gy1 = (int)floorf(fminf(fmaxf((cb.w - Y0) * 0.5f, -1.f), 7.f));
     }
-    if (mask_lo | mask_hi) {  // the 80-byte record is only fetched for surfels the tile can see
+    if (gx0 <= gx1 && gy0 <= gy1) {  // the 80-byte record is only fetched for surfels the tile can see
         const float4 *g = geom + (size_t)id * 5;
         const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
         const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
@@ -80,16 +73,69 @@ __device__ __forceinline__ void stage_entry(const float4 *__restrict__ geom, con
         cross3(k0, l0, A);
         cross3(Tw, l0, B);
         cross3(k0, Tw, C);
-        r0 = make_float4(A[0], A[1], A[2], B[0]);
-        r1 = make_float4(B[1], B[2], C[0], C[1]);
-        r2 = make_float4(C[2], g2.y - X0, g2.z - Y0, Tw[0]);
-        r3 = make_float4(Tw[1], Tw[2], g2.w, __uint_as_float(mask_lo));
-        r4 = make_float4(g3.x, g3.y, g3.z, g4.x);
-        r5 = make_float4(g4.y, g4.z, __uint_as_float(mask_hi), 0.f);
+        const float cx = g2.y - X0, cy = g2.z - Y0, opa = g2.w;
+        // Scan-convert {alpha >= 1/255} onto the tile, one pixel row at a time.  alpha >= 1/255 <=>
+        // rho <= tau = 2 ln(255 o) with rho = min(rho3d, rho2d):
+        //   rho3d <= tau  <=>  px^2 + py^2 - tau pz^2 <= 0, a conic; on a row p = u + lx B, so the
+        //                      row's pixels lie between the roots of qa lx^2 + 2 qb lx + qc;
+        //   rho2d <= tau  <=>  (lx - cx)^2 <= tau/2 - (ly - cy)^2, the low-pass disc.
+        // The span kept is the hull of the two intervals, widened by 0.01 px, with tau inflated
+        // (the evaluation uses v_rcp / v_exp approximations): conservative, never exact-or-under.
+        // A conic that is not an ellipse on this row pencil (qa <= 0) falls back to the cull box.
+        const float tau = 2.0f * __logf(255.0f * opa) * 1.001f + 0.01f;
+        const float nb = B[0] * B[0] + B[1] * B[1], qa = nb - tau * B[2] * B[2];
+        const bool ellipse = qa > 1e-5f * (nb + tau * B[2] * B[2]);
+        const float inv_qa = ellipse ? 1.0f / qa : 0.f;
+        const float bx0 = (float)(2 * gx0), bx1 = (float)(2 * gx1 + 1);
+        uint32_t colsum = 0;
+        for (int by = gy0; by <= gy1; by++) {
+            float lo = 1e9f, hi = -1e9f;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float y = (float)(2 * by + q);
+                const float u0 = A[0] + y * C[0], u1 = A[1] + y * C[1], u2 = A[2] + y * C[2];
+                const float qb = u0 * B[0] + u1 * B[1] - tau * (u2 * B[2]);
+                const float qc = u0 * u0 + u1 * u1 - tau * (u2 * u2);
+                const float disc = qb * qb - qa * qc + 4e-6f * (qb * qb);
+                if (!ellipse) {
+                    lo = bx0; hi = bx1;
+                } else if (disc >= 0.f) {
+                    const float sq = sqrtf(disc);
+                    lo = fminf(lo, (-qb - sq) * inv_qa);
+                    hi = fmaxf(hi, (-qb + sq) * inv_qa);
+                }
+                const float h = 0.5f * tau - (y - cy) * (y - cy);
+                if (h >= 0.f) {
+                    const float sh = sqrtf(h);
+                    lo = fminf(lo, cx - sh);
+                    hi = fmaxf(hi, cx + sh);
+                }
+            }
+            const int ilo = (int)ceilf(fmaxf(lo - 0.01f, bx0)), ihi = (int)floorf(fminf(hi + 0.01f, bx1));
+            if (ilo <= ihi) {
+                const uint32_t cols = ((2u << (ihi >> 1)) - 1u) & ~((1u << (ilo >> 1)) - 1u);  // 8 bits
+                colsum |= cols;
+                if (by < 4) mask_lo |= cols << (8 * by);
+                else mask_hi |= cols << (8 * (by - 4));
+            }
+        }
+        if (colsum) {
+            const int rx0 = __builtin_ctz(colsum), rx1 = 31 - __builtin_clz(colsum);
+            const int ry0 = mask_lo ? (__builtin_ctz(mask_lo) >> 3) : 4 + (__builtin_ctz(mask_hi) >> 3);
+            const int ry1 = mask_hi ? 4 + ((31 - __builtin_clz(mask_hi)) >> 3) : ((31 - __builtin_clz(mask_lo)) >> 3);
+            rectpack = (uint32_t)rx0 | ((uint32_t)rx1 << 4) | ((uint32_t)ry0 << 8) | ((uint32_t)ry1 << 12) | (1u << 16);
+            r0 = make_float4(A[0], A[1], A[2], B[0]);
+            r1 = make_float4(B[1], B[2], C[0], C[1]);
+            r2 = make_float4(C[2], cx, cy, Tw[0]);
+            r3 = make_float4(Tw[1], Tw[2], opa, __uint_as_float(mask_lo));
+            r4 = make_float4(g3.x, g3.y, g3.z, g4.x);
+            r5 = make_float4(g4.y, g4.z, __uint_as_float(mask_hi), 0.f);
+        }
     }
     rec[0 * CHUNK + e] = r0; rec[1 * CHUNK + e] = r1; rec[2 * CHUNK + e] = r2;
     rec[3 * CHUNK + e] = r3; rec[4 * CHUNK + e] = r4; rec[5 * CHUNK + e] = r5;
     if (ids) ids[e] = valid ? id : 0u;
+    return rectpack;
 }
 
 struct Hit {
@@ -187,8 +233,10 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                     const uint32_t *__restrict__ seg_base, float *__restrict__ ckpt,
                      float *__restrict__ out_color, float *__restrict__ out_allmap) {
     constexpr int CHUNK = FWD_CHUNK;
+    static_assert(L2D_SEG % FWD_CHUNK == 0, "segment boundaries must fall on round boundaries");
     __shared__ float4 rec[REC4 * CHUNK];
     const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
@@ -208,7 +256,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             const float qnan = __uint_as_float(0x7fc00000u);
             for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = qnan;
             for (int ch = 0; ch < 7; ch++) out_allmap[ch * HW + pix] = qnan;
-            final_T[pix] = qnan; final_T[pix + HW] = qnan; final_T[pix + 2 * HW] = qnan;
+            for (int ch = 0; ch < L2D_CKPT_F; ch++) final_T[pix + ch * HW] = qnan;
             n_contrib[pix] = 0; n_contrib[pix + HW] = 0;
         }
         return;
@@ -238,6 +286,14 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     for (int base = 0; base < total; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
         dbg_rounds++;
+        if (base && base % L2D_SEG == 0 && !px.done) {
+            // crossing a segment boundary: park the running sums over entries [0, base) so that the
+            // backward can start a walk here (pixels that are done never read theirs)
+            float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)(base / L2D_SEG - 1)) * (L2D_CKPT_F * 256) + tid;
+            ck[0 * 256] = px.T; ck[1 * 256] = px.M1; ck[2 * 256] = px.M2;
+            ck[3 * 256] = px.C0; ck[4 * 256] = px.C1; ck[5 * 256] = px.C2;
+            ck[6 * 256] = px.Dd; ck[7 * 256] = px.N0; ck[8 * 256] = px.N1; ck[9 * 256] = px.N2;
+        }
 #pragma unroll
         for (int q = 0; q < SPT; q++) {
             const int o = q * 256 + tid;
@@ -303,6 +359,9 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         final_T[pix] = T;
         final_T[pix + HW] = px.M1;
         final_T[pix + 2 * HW] = px.M2;
+        final_T[pix + 3 * HW] = px.C0; final_T[pix + 4 * HW] = px.C1; final_T[pix + 5 * HW] = px.C2;
+        final_T[pix + 6 * HW] = px.Dd;
+        final_T[pix + 7 * HW] = px.N0; final_T[pix + 8 * HW] = px.N1; final_T[pix + 9 * HW] = px.N2;
         n_contrib[pix] = px.last_contributor;
         n_contrib[pix + HW] = px.median_contributor;
         out_color[0 * HW + pix] = px.C0 + T * v.bg[0];
@@ -350,68 +409,6 @@ __device__ __forceinline__ void quad_reduce_scatter(const float g[22], float r[6
     r[5] = v1[10] + dpp_full<0x4E>(v1[10]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// packed butterfly reduction of 21 per-lane values over the 64 lanes of a wave
-// (v_permlane32_swap / v_permlane16_swap / DPP: ~55 VALU ops instead of 126 for 21 plain reductions)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float f_of(unsigned u) { return __uint_as_float(u); }
-__device__ __forceinline__ unsigned u_of(float f) { return __float_as_uint(f); }
-
-// lanes 0..31 <- a[l] + a[l+32] ; lanes 32..63 <- b[l-32] + b[l]
-__device__ __forceinline__ float pair32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(u_of(a), u_of(b), false, false);
-    return f_of(r[0]) + f_of(r[1]);
-}
-// rows 0,2 <- a summed over (row, row+1) ; rows 1,3 <- b summed over (row-1, row)
-__device__ __forceinline__ float pair16(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(u_of(a), u_of(b), false, false);
-    return f_of(r[0]) + f_of(r[1]);
-}
-// lanes with bit3 clear <- a[l] + a[l^8] ; bit3 set <- b[l] + b[l^8]
-__device__ __forceinline__ float pair8(float a, float b, bool bit3) {
-    const float t = a + dpp_full<0x128>(a), u = b + dpp_full<0x128>(b);  // row_ror:8
-    return bit3 ? u : t;
-}
-// lanes with bit2 clear <- a[l] + a[l+4] ; bit2 set <- b[l] + b[l-4]
-__device__ __forceinline__ float pair4(float a, float b, bool bit2) {
-    int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x104, 0xf, 0x5, false);  // row_shl:4 -> banks 0,2
-    y = __builtin_amdgcn_update_dpp(y, __float_as_int(b), 0x114, 0xf, 0xa, false);      // row_shr:4 -> banks 1,3
-    return (bit2 ? b : a) + __int_as_float(y);
-}
-// lanes with bit1 clear <- a[l] + a[l^2] ; bit1 set <- b[l] + b[l^2]
-__device__ __forceinline__ float pair2(float a, float b, bool bit1) {
-    const float t = a + dpp_full<0x4E>(a), u = b + dpp_full<0x4E>(b);  // quad_perm [2,3,0,1]
-    return bit1 ? u : t;
-}
-__device__ __forceinline__ float fold1(float a) { return a + dpp_full<0xB1>(a); }  // quad_perm [1,0,3,2]
-
-// After the call, lane l holds the full 64-lane sum of value slot_of_lane(l) (see below).
-__device__ __forceinline__ float butterfly21(const float v[21], const int lane) {
-    float r[11];
-#pragma unroll
-    for (int i = 0; i < 10; i++) r[i] = pair32(v[2 * i], v[2 * i + 1]);
-    r[10] = pair32(v[20], v[20]);
-    float q[6];
-#pragma unroll
-    for (int i = 0; i < 5; i++) q[i] = pair16(r[2 * i], r[2 * i + 1]);
-    q[5] = pair16(r[10], r[10]);
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-    const float o0 = pair8(q[0], q[1], b3), o1 = pair8(q[2], q[3], b3), o2 = pair8(q[4], q[5], b3);
-    const float n0 = pair4(o0, o1, b2), n1 = pair4(o2, o2, b2);
-    return fold1(pair2(n0, n1, b1));
-}
-// which of the 21 values lane l ends up with (-1: duplicate holder, must not write)
-__device__ __forceinline__ int slot_of_lane(const int l) {
-    if (l & 1) return -1;
-    const int b1 = (l >> 1) & 1, b2 = (l >> 2) & 1, b3 = (l >> 3) & 1, b4 = (l >> 4) & 1, b5 = (l >> 5) & 1;
-    int o;  // index among o0..o2
-    if (b1) { if (b2) return -1; o = 2; } else o = b2;
-    const int q = 2 * o + b3;  // index among q0..q5
-    if (q == 5) return (b4 | b5) ? -1 : 20;
-    const int r = 2 * q + b4;  // index among r0..r9
-    return 2 * r + b5;
-}
-
 __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
     __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -419,29 +416,60 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// Quad-SIMT reverse traversal + deferred, atomic-free reduction.
+//
+// Phase P (lane = pixel, each DPP quad walks its own candidate list back to front) only runs the
+// per-pixel recurrences of the reference's backward (T, the accum_rec family, the distortion
+// terms) and leaves, per contributing (pixel, entry), three scalars: w = alpha*T, dL/dalpha and
+// dL/dz.  They are parked in an LDS *slab pool*: phase S gives every staged entry a slab the size
+// of its candidate block rectangle (typically 6x6 pixels), so each (pixel, entry) owns one slot --
+// plain ds_write, no atomics, no collisions.  Phase S2 (4 lanes per entry) walks the entry's slab,
+// re-evaluates the splat geometry for the pixels that contributed, forms the 21 coefficient-space
+// partial derivatives and accumulates them in registers; a 2-step DPP reduce and the entry has
+// its sums.  Versus reducing per entry across the wave inside the traversal (one candidate stream
+// per wave, a 55-instruction butterfly and a 64-lane gradient evaluation for 11 useful lanes) this
+// needs ~3x fewer wave instructions, and it keeps the backward free of floating-point atomics.
+// A round takes as many list entries (from the back) as fit the pool, at most SLAB_CHUNK.
+constexpr int SLAB_WIN = 256;     // list entries staged per window (one per thread)
+constexpr int SLAB_CHUNK = 64;    // entries per slab round (<= 64: one ballot word)
+constexpr int SLAB_POOL = 3072;   // (pixel, entry) slots per round: 36 KB as three fp32 planes
+
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                     const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ bwd_order,
+                     const uint2 *__restrict__ bwd_items, const float *__restrict__ ckpt,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                      float4 *__restrict__ pair_grad, uint32_t *__restrict__ pair_valid) {
-    constexpr int CHUNK = BWD_CHUNK;
-    // Per-wave result slices instead of LDS atomics: a wave visits an entry at most once per round,
-    // so it can park the entry's 21 sums with a plain ds_write; phase S2 adds the (<= 4) slices in
-    // a fixed order.  (LDS float atomics are slow on gfx950: ds_add_f32 169 / ds_add_f64 18 cycles
-    // per wave instruction with a long latency -- tools/ubench/lds_atomic.hip.)
-    __shared__ float4 rec[REC4 * CHUNK];
-    __shared__ float acc[4 * CHUNK * ACC_STRIDE];  // [wave][entry][slot]
-    __shared__ unsigned long long touched[4][(CHUNK + 63) / 64];
-    __shared__ uint32_t s_id[CHUNK];
+    constexpr int WIN = SLAB_WIN;
+    __shared__ float4 rec[REC4 * WIN];
+    __shared__ float pool_w[SLAB_POOL], pool_a[SLAB_POOL], pool_z[SLAB_POOL];
+    __shared__ float gpix[256 * 6];      // per pixel: dL/dcolor (3), dL/dnormal (3)
+    __shared__ unsigned long long occ[SLAB_CHUNK][4];  // which slots of an entry's slab were written
+    __shared__ uint32_t s_rect[WIN];     // candidate block rectangle of each staged entry (stage_entry)
+    __shared__ uint32_t s_desc[SLAB_CHUNK];  // slab: base | x0 << 12 | y0 << 16 | (w-1) << 20 | (h-1) << 24 | has << 28
+    __shared__ uint32_t s_id[WIN];
     __shared__ uint32_t s_maxc;
+    __shared__ int s_nfit;
     if (header[1]) return;
-    const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
+    const unsigned long long dbg_t0 = (v.dbg & 32u) ? wall_clock64() : 0ull;
+    // work item = (tile, segment): the full segments first, then every tile's last segment
+    const uint32_t n_full = header[3];
+    int tile, seg;
+    if (blockIdx.x < n_full) {
+        const uint2 it = bwd_items[blockIdx.x];
+        tile = (int)it.x; seg = (int)it.y;
+    } else if (blockIdx.x - n_full < (uint32_t)v.tiles) {
+        tile = (int)bwd_order[blockIdx.x - n_full];
+        seg = (int)(seg_base[tile + 1] - seg_base[tile]);
+    } else {
+        return;
+    }
     const int tx = tile % v.gx, ty = tile / v.gx;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int grp = lane >> 2;
-    const int slot = slot_of_lane(lane);
     const int lxi = (wave & 1) * 8 + (grp & 3) * 2 + (lane & 1);
     const int lyi = (wave >> 1) * 8 + (grp >> 2) * 2 + ((lane >> 1) & 1);
     const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
@@ -451,6 +479,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const float lx = (float)lxi, ly = (float)lyi;
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
     const uint2 range = ranges[tile];
+    const int seg_lo = seg * L2D_SEG, seg_hi = min(seg_lo + L2D_SEG, (int)(range.y - range.x));
 
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
@@ -469,6 +498,11 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         final_D = final_T[pix + HW];
         final_D2 = final_T[pix + 2 * HW];
     }
+    {
+        float *gp = gpix + (lyi * 16 + lxi) * 6;
+        gp[0] = dpix[0]; gp[1] = dpix[1]; gp[2] = dpix[2];
+        gp[3] = dnrm[0]; gp[4] = dnrm[1]; gp[5] = dnrm[2];
+    }
     const float final_A = 1.0f - T_final;
     const float bg_dot_dpixel = v.bg[0] * dpix[0] + v.bg[1] * dpix[1] + v.bg[2] * dpix[2];
 
@@ -478,196 +512,250 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     float last_dL_dT = 0.f;
 
     // the tile only needs entries [0, max over pixels of last_contributor)
-    if (threadIdx.x == 0) s_maxc = 0;
+    if (tid == 0) s_maxc = 0;
     __syncthreads();
     atomicMax(&s_maxc, last_contributor);
     __syncthreads();
-    const int total = (int)s_maxc;
+    const int total = min((int)s_maxc, seg_hi);
+    const int lo = seg_lo;
+    if (total <= lo) return;
 
-    // back to front, CHUNK entries at a time: chunk c covers list positions [lo, lo + cnt)
-    const int nchunks = (total + CHUNK - 1) / CHUNK;
-    // software pipeline of the list walk (threads 0..CHUNK-1 stage): ids two rounds ahead, cull
-    // boxes one round ahead
-    const int tid = threadIdx.x;
-    const bool stager = tid < CHUNK;
-    auto in_chunk = [&](int c) { return stager && c >= 0 && c * CHUNK + tid < total; };
-    uint32_t id1 = in_chunk(nchunks - 1) ? point_list[range.x + (nchunks - 1) * CHUNK + tid] : 0u;
-    uint32_t id2 = in_chunk(nchunks - 2) ? point_list[range.x + (nchunks - 2) * CHUNK + tid] : 0u;
-    float4 cb1 = in_chunk(nchunks - 1) ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = nchunks - 1; c >= 0; c--) {
-        const int lo = c * CHUNK;
-        const int cnt = min(CHUNK, total - lo);
+    // A pixel whose walk began above this segment resumes from the forward's checkpoint at seg_hi:
+    // with F the running sum of f_k * w_k over entries < seg_hi and T_b the transmittance there,
+    // the "what lies behind" recurrences equal (F_final - F) / T_b, entered with last_alpha = 0.
+    if ((int)last_contributor > seg_hi) {
+        const float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)seg) * (L2D_CKPT_F * 256) + tid;
+        const float Tb = ck[0], inv_Tb = 1.0f / Tb;
+        T = Tb;
+        const float s_alpha = (Tb - T_final) * inv_Tb;
+        const float s_m1 = (final_D - ck[1 * 256]) * inv_Tb, s_m2 = (final_D2 - ck[2 * 256]) * inv_Tb;
+        for (int ch = 0; ch < 3; ch++) accum_rec[ch] = (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * inv_Tb;
+        accum_depth_rec = (final_T[pix + 6 * HW] - ck[6 * 256]) * inv_Tb;
+        for (int ch = 0; ch < 3; ch++) accum_normal_rec[ch] = (final_T[pix + (7 + ch) * HW] - ck[(7 + ch) * 256]) * inv_Tb;
+        accum_alpha_rec = s_alpha;
+        last_dL_dT = (final_D2 * s_alpha + final_A * s_m2 - 2.0f * final_D * s_m1) * dL_dreg;
+    }
+
+    // Windows of WIN entries, back to front; window slot e <-> list position whi - 1 - e.  Surfel
+    // ids are fetched two windows ahead, cull boxes one window ahead.
+    uint32_t id1 = total - 1 - tid >= lo ? point_list[range.x + total - 1 - tid] : 0u;
+    uint32_t id2 = total - WIN - 1 - tid >= lo ? point_list[range.x + total - WIN - 1 - tid] : 0u;
+    float4 cb1 = total - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int whi = total; whi > lo; whi -= WIN) {
+        const int wcnt = min(WIN, whi - lo);
         const uint32_t id0 = id1;
         const float4 cb0 = cb1;
         id1 = id2;
-        id2 = in_chunk(c - 2) ? point_list[range.x + (c - 2) * CHUNK + tid] : 0u;
-        cb1 = in_chunk(c - 1) ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();  // previous chunk's phase S2 is done with rec / acc / s_id
-        if (stager) stage_entry<CHUNK>(geom, id0, cb0, tid < cnt, X0, Y0, rec, s_id);
-        if (threadIdx.x < 4 * ((CHUNK + 63) / 64)) (&touched[0][0])[threadIdx.x] = 0ull;
-        __syncthreads();
+        id2 = whi - 2 * WIN - 1 - tid >= lo ? point_list[range.x + whi - 2 * WIN - 1 - tid] : 0u;
+        cb1 = whi - WIN - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();  // the previous window's last round is done with rec / s_rect / s_id
+        s_rect[tid] = stage_entry<WIN>(geom, id0, cb0, tid < wcnt, X0, Y0, rec, s_id);
 
-#pragma unroll 1
-        for (int sub = ((cnt - 1) >> 6) << 6; sub >= 0; sub -= 64) {
-            // The backward keeps ONE candidate stream per wave (8x8 quadrant): its per-entry sums
-            // must be reduced over all pixels anyway, and a wave-wide butterfly + one 22-lane
-            // ds_add_f64 is far cheaper than per-quad LDS atomics (which collide on the same entry).
-            const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * CHUNK + min(sub + lane, CHUNK - 1);
-            const uint32_t bm = sub + lane < CHUNK ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
-            unsigned long long m = __ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u);
-            if (m == 0ull) continue;
-            unsigned long long tmask = 0ull;  // entries of this sub-chunk this wave produced sums for
-            int jn = sub + 63 - __builtin_clzll(m);
-            m &= ~(1ull << (jn - sub));
-            EntryRec cur = load_entry<CHUNK>(rec, jn);
-            float4 cur4 = rec[4 * CHUNK + jn], cur5 = rec[5 * CHUNK + jn];
-            bool more = true;
-            while (more) {
-                const int j = jn;
-                const EntryRec ent = cur;
-                const float4 r4 = cur4, r5 = cur5;
-                more = m != 0ull;
-                if (more) {  // fetch the next entry before this one's ds_add_f64 enters the LDS queue
-                    jn = sub + 63 - __builtin_clzll(m);
-                    m &= ~(1ull << (jn - sub));
-                    cur = load_entry<CHUNK>(rec, jn);
-                    cur4 = rec[4 * CHUNK + jn]; cur5 = rec[5 * CHUNK + jn];
+        // slab rounds over the window: each takes as many entries as fit the pool, at most 64
+        for (int s0 = 0; s0 < wcnt;) {
+            __syncthreads();  // window staged / previous round's phase S2 done with pool, occ, s_desc
+            if (wave == 0) {
+                const int slot = s0 + lane;
+                const bool valid = slot < wcnt;
+                const uint32_t rp = valid ? s_rect[slot] : 0u;
+                uint32_t area = 0, x0 = 0, y0 = 0, w = 2, h = 2;
+                if (rp) {
+                    const uint32_t gx0 = rp & 15u, gx1 = (rp >> 4) & 15u, gy0 = (rp >> 8) & 15u, gy1 = (rp >> 12) & 15u;
+                    x0 = 2 * gx0; y0 = 2 * gy0; w = 2 * (gx1 - gx0 + 1); h = 2 * (gy1 - gy0 + 1);
+                    area = w * h;
                 }
-                const uint32_t contributor = (uint32_t)(lo + j);  // 0-based list position
-                Hit h;
-                float Tw[3], opa;
-                const bool active = eval_rec(ent, lx, ly, h, Tw, opa) && contributor < last_contributor;
-                if (__ballot(active) == 0ull) continue;
+                uint32_t incl = area;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += y;
+                }
+                const bool fits = valid && incl <= (uint32_t)SLAB_POOL;
+                const unsigned long long fm = __ballot(fits);
+                // entries that fit form a prefix; at least one fits (an area is at most 256)
+                if (lane == 0) s_nfit = fm == ~0ull ? 64 : __builtin_ctzll(~fm);
+                s_desc[lane] = (incl - area) | (x0 << 12) | (y0 << 16) | ((w - 1) << 20) | ((h - 1) << 24) |
+                               ((rp && fits) ? (1u << 28) : 0u);
+            }
+            (&occ[0][0])[tid] = 0ull;  // 64 entries x 4 words = 256 words
+            __syncthreads();
+            const int nfit = s_nfit;
 
+            // ---- phase P: every quad walks its own candidates, last list position first (window
+            //      slots ascend as list positions descend)
+            {
+                const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * WIN + min(s0 + lane, WIN - 1);
+                const uint32_t bm = lane < nfit ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
+                if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) != 0ull) {
+                    const unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
+#pragma unroll 1
+                    for (int half = 0; half < 2; half++) {
+                        uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+                        const int jb = 32 * half;
+                        while (__ballot(mm != 0u) != 0ull) {
+                            const bool has = mm != 0u;
+                            const int j = jb + (has ? __builtin_ctz(mm) : 0);  // entry of this round
+                            mm &= mm - 1u;
+                            const int ws = s0 + j;                               // window slot
+                            const uint32_t contributor = (uint32_t)(whi - 1 - ws);  // 0-based list position
+                            const EntryRec ent = load_entry<WIN>(rec, ws);
+                            Hit h;
+                            float Tw[3], opa;
+                            const bool active = eval_rec(ent, lx, ly, h, Tw, opa) && has && contributor < last_contributor;
+                            if (__ballot(active) == 0ull || (v.dbg & 16u)) continue;
+                            if (active) {
+                                const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
+                                const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
+                                const float alpha = h.alpha, c_d = h.depth;
+                                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                                T = T * inv_1ma;
+                                const float w = alpha * T;
+                                float dL_dalpha = 0.0f;
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++) {
+                                    accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                                    last_color[ch] = rgb[ch];
+                                    dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
+                                }
+                                float dL_dz = 0.0f, dL_dweight = 0.0f;
+                                const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                                const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
+                                const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
+                                if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
+                                dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
+                                dL_dalpha += dL_dweight - last_dL_dT;
+                                last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                                const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                                dL_dz += dL_dmd * dmd_dd;
+
+                                accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                                last_depth = c_d;
+                                dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                                accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                                dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++) {
+                                    accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                                    last_normal[ch] = nrm[ch];
+                                    dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
+                                }
+                                dL_dalpha *= T;
+                                last_alpha = alpha;
+                                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                                dL_dz += w * dL_ddepth;
+                                // park (w, dL/dalpha, dL/dz) in this pixel's slot of the entry's slab
+                                const uint32_t d = s_desc[j];
+                                const int sl = (lyi - (int)((d >> 16) & 15u)) * (int)(((d >> 20) & 15u) + 1u) +
+                                               (lxi - (int)((d >> 12) & 15u));
+                                const int slot = (int)(d & 0xfffu) + sl;
+                                pool_w[slot] = w; pool_a[slot] = dL_dalpha; pool_z[slot] = dL_dz;
+                                atomicOr(&occ[j][sl >> 6], 1ull << (sl & 63));  // ds_or_b64
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- phase S2: four lanes per entry visit the occupied slots of its slab and
+            //      accumulate the 21 coefficient-space sums in registers
+            {
+                const int e = tid >> 2, sub = tid & 3;
+                const uint32_t d = s_desc[e];
+                const bool has = e < nfit && ((d >> 28) & 1u) && !(v.dbg & 2u);
                 float g[21];
 #pragma unroll
                 for (int k = 0; k < 21; k++) g[k] = 0.f;
-                if (active) {
-                    const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
-                    const float alpha = h.alpha, G = h.G, c_d = h.depth;
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * inv_1ma;
-                    const float w = alpha * T;
-                    float dL_dalpha = 0.0f;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                        last_color[ch] = rgb[ch];
-                        dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
-                        g[18 + ch] = w * dpix[ch];
+                bool touched = false;
+                if (has) {
+                    const int base = (int)(d & 0xfffu), x0 = (int)((d >> 12) & 15u), y0 = (int)((d >> 16) & 15u);
+                    const int w = (int)((d >> 20) & 15u) + 1;
+                    const float inv_w = 1.0f / (float)w;
+                    const int ws = s0 + e;
+                    const EntryRec ent = load_entry<WIN>(rec, ws);
+#pragma unroll 1
+                    for (int wd = 0; wd < 4; wd++) {
+                        unsigned long long om = occ[e][wd];
+                        touched = touched || om != 0ull;
+                        om &= 0x1111111111111111ull << sub;  // lane `sub` takes slots = sub (mod 4)
+                        while (om) {
+                            const int bit = __builtin_ctzll(om);
+                            om &= om - 1ull;
+                            const int s2 = wd * 64 + bit;
+                            const float ww = pool_w[base + s2], da = pool_a[base + s2], dz = pool_z[base + s2];
+                            const int row = (int)(((float)s2 + 0.5f) * inv_w), col = s2 - row * w;
+                            const int plx = x0 + col, ply = y0 + row;
+                            const float flx = (float)plx, fly = (float)ply;
+                            Hit h;
+                            float Tw[3], opa;
+                            (void)eval_rec(ent, flx, fly, h, Tw, opa);  // same arithmetic as phase P
+                            const float *gp = gpix + (ply * 16 + plx) * 6;
+                            g[18] += ww * gp[0]; g[19] += ww * gp[1]; g[20] += ww * gp[2];
+                            g[14] += ww * gp[3]; g[15] += ww * gp[4]; g[16] += ww * gp[5];
+                            // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
+                            g[9] += dz * h.sx; g[10] += dz * h.sy; g[11] += dz;
+                            const float dL_dG = opa * da;
+                            if (h.use3d) {
+                                const float dL_dsx = dL_dG * -h.G * h.sx + dz * Tw[0];
+                                const float dL_dsy = dL_dG * -h.G * h.sy + dz * Tw[1];
+                                const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
+                                const float dpz = -(dpx * h.sx + dpy * h.sy);
+                                g[0] += dpx; g[1] += dpy; g[2] += dpz;
+                                g[3] += flx * dpx; g[4] += flx * dpy; g[5] += flx * dpz;
+                                g[6] += fly * dpx; g[7] += fly * dpy; g[8] += fly * dpz;
+                            } else {
+                                g[12] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddx);
+                                g[13] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddy);
+                            }
+                            g[17] += h.G * da;
+                        }
                     }
-                    float dL_dz = 0.0f, dL_dweight = 0.0f;
-                    const float inv_cd = __builtin_amdgcn_rcpf(c_d);
-                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
-                    const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
-                    if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
-                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
-                    dL_dalpha += dL_dweight - last_dL_dT;
-                    last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                    dL_dz += dL_dmd * dmd_dd;
-
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                    last_depth = c_d;
-                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
-                        last_normal[ch] = nrm[ch];
-                        dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
-                        g[14 + ch] = w * dnrm[ch];
-                    }
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-
-                    const float dL_dG = opa * dL_dalpha;
-                    dL_dz += w * dL_ddepth;
-                    // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
-                    g[9] = dL_dz * h.sx; g[10] = dL_dz * h.sy; g[11] = dL_dz;
-                    if (h.use3d) {
-                        const float dL_dsx = dL_dG * -G * h.sx + dL_dz * Tw[0];
-                        const float dL_dsy = dL_dG * -G * h.sy + dL_dz * Tw[1];
-                        const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
-                        const float dpz = -(dpx * h.sx + dpy * h.sy);
-                        g[0] = dpx; g[1] = dpy; g[2] = dpz;
-                        g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
-                        g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
-                    } else {
-                        g[12] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddx);
-                        g[13] = dL_dG * (-G * FILTER_INV_SQUARE * h.ddy);
-                    }
-                    g[17] = G * dL_dalpha;
                 }
-                if (v.dbg & 2u) { float z = 0.f; for (int k = 0; k < 21; k++) z += g[k]; if (z == 123.456f) acc[0] = z; continue; }
-                const float sred = butterfly21(g, lane);
-                if (v.dbg & 16u) { if (sred == 123.456f) acc[0] = sred; continue; }
-                if (slot >= 0) acc[(wave * CHUNK + j) * ACC_STRIDE + slot] = sred;  // plain ds_write, 21 lanes
-                tmask |= 1ull << (j - sub);
-            }
-            if (lane == 0) touched[wave][sub >> 6] = tmask;
-        }
-        __syncthreads();
-
-        // phase S2: thread e turns its entry's 21 coefficient-space sums into dL/d(Tu,Tv,Tw,...)
-        const int e = threadIdx.x;
-        bool any = false;
-        float sacc[21];
+                // sum over the 4 lanes of the entry (every lane ends with the total)
 #pragma unroll
-        for (int k = 0; k < 21; k++) sacc[k] = 0.f;
-        if (e < cnt) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                if ((touched[w][e >> 6] >> (e & 63)) & 1ull) {
-                    any = true;
-                    const float *src = acc + (w * CHUNK + e) * ACC_STRIDE;
-#pragma unroll
-                    for (int k = 0; k < 21; k++) sacc[k] += src[k];
+                for (int k = 0; k < 21; k++) {
+                    g[k] += dpp_full<0xB1>(g[k]);
+                    g[k] += dpp_full<0x4E>(g[k]);
+                }
+                if (has && sub == 0 && touched) {
+                    const int ws = s0 + e;
+                    const uint32_t p = range.x + (uint32_t)(whi - 1 - ws);
+                    const uint32_t id = s_id[ws];
+                    const float4 *gm = geom + (size_t)id * 5;
+                    const float4 g0 = gm[0], g1 = gm[1], g2 = gm[2];
+                    const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
+                    const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
+                    const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
+                    const float a[3] = {g[0], g[1], g[2]}, b[3] = {g[3], g[4], g[5]}, cc[3] = {g[6], g[7], g[8]};
+                    // A = k0 x l0, B = Tw x l0, C = k0 x Tw ; for y = u x v: dL/du = v x dL/dy, dL/dv = dL/dy x u
+                    float t1[3], t2[3], dk0[3], dl0[3], dTw[3];
+                    cross3(l0, a, t1); cross3(Tw, cc, t2);
+                    for (int i = 0; i < 3; i++) dk0[i] = t1[i] + t2[i];
+                    cross3(a, k0, t1); cross3(b, Tw, t2);
+                    for (int i = 0; i < 3; i++) dl0[i] = t1[i] + t2[i];
+                    cross3(l0, b, t1); cross3(cc, k0, t2);
+                    for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + g[9 + i];
+                    // one 80-byte gradient row per touched (tile, surfel) pair, written exactly once; a
+                    // bitmap marks the rows that exist; preprocess_bwd sums each surfel's rows
+                    float4 *row = pair_grad + (size_t)p * (GRAD_F / 4);
+                    row[0] = make_float4(-dk0[0], -dk0[1], -dk0[2], -dl0[0]);
+                    row[1] = make_float4(-dl0[1], -dl0[2], dTw[0], dTw[1]);
+                    row[2] = make_float4(dTw[2], g[12], g[13], g[14]);
+                    row[3] = make_float4(g[15], g[16], g[17], g[18]);
+                    row[4] = make_float4(g[19], g[20], 0.f, 0.f);
+                    atomicOr(&pair_valid[p >> 5], 1u << (p & 31u));
                 }
             }
+            s0 += nfit;
         }
-        // one 80-byte gradient row per touched (tile, surfel) pair, written exactly once, coalesced;
-        // a bitmap marks the rows that exist.  preprocess_bwd gathers each surfel's rows (no atomics
-        // on gradients, fixed summation order).
-        const uint32_t p = range.x + (uint32_t)(lo + e);
-        if (any) {
-            const uint32_t id = s_id[e];
-            const float4 *gm = geom + (size_t)id * 5;
-            const float4 g0 = gm[0], g1 = gm[1], g2 = gm[2];
-            const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
-            const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
-            const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
-            const float a[3] = {sacc[0], sacc[1], sacc[2]}, b[3] = {sacc[3], sacc[4], sacc[5]},
-                        cc[3] = {sacc[6], sacc[7], sacc[8]};
-            // A = k0 x l0, B = Tw x l0, C = k0 x Tw ; for y = u x v: dL/du = v x dL/dy, dL/dv = dL/dy x u
-            float t1[3], t2[3], dk0[3], dl0[3], dTw[3];
-            cross3(l0, a, t1); cross3(Tw, cc, t2);
-            for (int i = 0; i < 3; i++) dk0[i] = t1[i] + t2[i];
-            cross3(a, k0, t1); cross3(b, Tw, t2);
-            for (int i = 0; i < 3; i++) dl0[i] = t1[i] + t2[i];
-            cross3(l0, b, t1); cross3(cc, k0, t2);
-            for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + sacc[9 + i];
-            float4 *row = pair_grad + (size_t)p * (GRAD_F / 4);
-            row[0] = make_float4(-dk0[0], -dk0[1], -dk0[2], -dl0[0]);
-            row[1] = make_float4(-dl0[1], -dl0[2], dTw[0], dTw[1]);
-            row[2] = make_float4(dTw[2], sacc[12], sacc[13], sacc[14]);
-            row[3] = make_float4(sacc[15], sacc[16], sacc[17], sacc[18]);
-            row[4] = make_float4(sacc[19], sacc[20], 0.f, 0.f);
-        }
-        // publish the wave's 64 validity bits with at most three atomic ORs
-        const unsigned long long bits = __ballot(any);
-        if (bits) {
-            const uint32_t p0 = range.x + (uint32_t)(lo + (e & ~63));  // position of lane 0's entry
-            const uint32_t sh = p0 & 31u, w0 = p0 >> 5;
-            const int l = e & 63;
-            uint32_t word = 0;
-            if (l == 0) word = (uint32_t)(bits << sh);
-            else if (l == 1) word = (uint32_t)(bits >> (32u - sh));
-            else if (l == 2) word = sh ? (uint32_t)(bits >> (64u - sh)) : 0u;
-            if (l < 3 && word) atomicOr(&pair_valid[w0 + l], word);
-        }
+    }
+    if ((v.dbg & 32u) && tid == 0) {  // work-group residency in 100 MHz ticks: max, sum, first start, last end
+        uint32_t *h = const_cast<uint32_t *>(header);
+        const unsigned long long t1 = wall_clock64();
+        atomicMax(&h[8], (uint32_t)(t1 - dbg_t0));
+        atomicAdd(&h[9], (uint32_t)(t1 - dbg_t0));
+        atomicMax(&h[10], ~(uint32_t)dbg_t0);
+        atomicMax(&h[11], (uint32_t)t1);
     }
 }
 
@@ -691,7 +779,8 @@ int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float
         L2D_PROF("composite_fwd", s);
         hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
-                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, out_color, out_allmap);
+                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.ckpt,
+                           out_color, out_allmap);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
@@ -701,10 +790,13 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
                          const float *dL_dallmap, hipStream_t s) {
     {
         L2D_PROF("composite_bwd", s);
-        hipLaunchKernelGGL(composite_bwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
+        // one workgroup per (tile, segment); the count lives on the device (header[3]), so launch
+        // the upper bound -- surplus workgroups exit on their first instruction
+        const unsigned grid = (unsigned)v.tiles + v.cap / L2D_SEG;
+        hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
-                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, dL_dcolor, dL_dallmap,
-                           sc.pair_grad, sc.pair_valid);
+                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.bwd_order,
+                           st.bwd_items, st.ckpt, dL_dcolor, dL_dallmap, sc.pair_grad, sc.pair_valid);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

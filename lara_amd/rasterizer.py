@@ -29,7 +29,7 @@ from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class _View(ctypes.Structure):
@@ -46,7 +46,8 @@ class _View(ctypes.Structure):
 
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
-                ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "pair_base", "pair_pos", "final_T", "n_contrib", "total")]
+                ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "pair_base", "pair_pos", "final_T", "n_contrib",
+                 "seg_base", "bwd_order", "bwd_items", "ckpt", "total")]
 
 
 _lib = None
@@ -403,8 +404,11 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
         point_list=sec(L.point_list, cap * 4, torch.int32, (cap,)),
         ranges=sec(L.ranges, tiles * 8, torch.int32, (tiles, 2)),
         tile_order=sec(L.tile_order, tiles * 4, torch.int32, (tiles,)),
-        final_T=sec(L.final_T, 3 * H * W * 4, torch.float32, (3, H, W)),
+        final_T=sec(L.final_T, 10 * H * W * 4, torch.float32, (10, H, W)),
         n_contrib=sec(L.n_contrib, 2 * H * W * 4, torch.int32, (2, H, W)),
+        seg_base=sec(L.seg_base, (tiles + 1) * 4, torch.int32, (tiles + 1,)),
+        bwd_order=sec(L.bwd_order, tiles * 4, torch.int32, (tiles,)),
+        bwd_items=sec(L.bwd_items, (cap // 1024 + 1) * 8, torch.int32, (cap // 1024 + 1, 2)),
     )
 
 

@@ -36,7 +36,7 @@ def test_bucketed_all_reduce_and_timing_over_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = out.get(timeout=120)
+    res = out.get(timeout=600)  # a cold container spends minutes importing torch in the spawned ranks
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

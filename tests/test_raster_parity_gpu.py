@@ -150,6 +150,18 @@ def test_backward_big_splats_low_pass_and_sh3(hip_lib):
     _grad_check(act, cams[2], (1.0, 1.0, 1.0))
 
 
+def test_backward_deep_lists_cross_segment_boundaries(hip_lib):
+    """The backward cuts a tile's list into 1024-entry segments that run as independent workgroups
+    and resume from the forward's checkpoints: make lists several segments deep, with pixels that
+    walk through all of them."""
+    act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)
+    cam, bg = cams[1], (1.0, 1.0, 1.0)
+    ref = run_oracle(oracle_view(cam, bg), to_numpy(act))
+    assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 3 * 1024
+    assert ref.n_contrib[0].max() > 2 * 1024 + 100
+    _grad_check(act, cam, bg)
+
+
 def test_precomputed_colour_and_transmat(hip_lib):
     from lara_amd import GaussianRasterizer
     act, cams = small_scene(grid=10, size=96, seed=9)

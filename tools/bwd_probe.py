@@ -1,0 +1,32 @@
+"""Work-group residency statistics of composite_bwd (LARA2DGS_DEBUG_FLAGS=32): is the kernel bound
+by its heaviest tile or by aggregate work?  Run on the GPU box."""
+import sys, math, os
+os.environ["LARA2DGS_DEBUG_FLAGS"] = str(32 | int(os.environ.get("EXTRA_FLAGS", "0")))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lara_amd import cameras, synthetic, rasterizer, GaussianRasterizer, GaussianRasterizationSettings
+dev = torch.device('cuda:0')
+cams = cameras.make_cameras(cameras.turntable_c2w(8), 512, 512, 0.75, 0.75, 1.106, 2.706, device=dev)
+for regime in ('init', 'trained'):
+    sc = synthetic.make_scene(grid=64, K=2, regime=regime, seed=0, device=dev)
+    act = {k: v.requires_grad_(True) for k, v in synthetic.activate(sc).items()}
+    gc = torch.randn(3, 512, 512, device=dev) / 512 ** 2
+    ga = torch.randn(7, 512, 512, device=dev) / 512 ** 2 * 0.1
+    for ci in (0, 3):
+        cam = cams[ci]
+        rs = GaussianRasterizationSettings(512, 512, math.tan(0.375), math.tan(0.375), torch.ones(3, device=dev), 1.0,
+                                           cam.world_view_transform.contiguous(), cam.full_proj_transform.contiguous(),
+                                           1, cam.camera_center, False, False)
+        for rep in range(2):
+            color, radii, allmap = GaussianRasterizer(rs)(means3D=act["means3D"], means2D=torch.zeros_like(act["means3D"]),
+                                                          shs=act["shs"], opacities=act["opacities"],
+                                                          scales=act["scales"], rotations=act["rotations"])
+            state = [t for t in color.grad_fn.saved_tensors if t is not None and t.dtype == torch.uint8 and t.numel() > 1 << 20][0]
+            torch.autograd.backward([color, allmap], [gc, ga])
+            torch.cuda.synchronize()
+        P = act["means3D"].shape[0]
+        cap = rasterizer.binning_capacity(P)
+        h = rasterizer.state_views(state, P, 512, 512, cap)["header"].cpu().numpy().astype('uint32')
+        span = (int(h[11]) - (~int(h[10]) & 0xffffffff)) & 0xffffffff
+        print(f"{regime} view {ci}: pairs {h[0]} max_list {h[2]}  WG max {h[8]/100:.0f} us  sum {h[9]/100:.0f} us "
+              f"(/512 = {h[9]/100/512:.0f} us)  span {span/100:.0f} us")
