@@ -166,7 +166,7 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
     ScratchLayout SL;
     ScratchView sc = carve_scratch(v, scratch, SL);
     // header + tile_count + tile_fill start at zero
-    hipError_t e = hipMemsetAsync(st.header, 0, 64, s);
+    hipError_t e = hipMemsetAsync(st.header, 0, 256, s);
     if (e == hipSuccess) e = hipMemsetAsync(sc.tile_count, 0, (size_t)(SL.sub_start - SL.tile_count), s);
     if (e != hipSuccess) { l2d_set_hip_error(e); return LARA2DGS_E_LAUNCH; }
     int rc = launch_preprocess_fwd(v, means3D, shs, colors_precomp, opacities, scales, rotations,

@@ -61,7 +61,7 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const int64_t HW = (int64_t)H * W;
     int64_t o = 0;
-    L->header = o;      o = align_up(o + 64, 256);
+    L->header = o;      o = align_up(o + 256, 256);
     L->geom = o;        o = align_up(o + (int64_t)P * GEOM_F * 4, 256);
     L->cullbox = o;     o = align_up(o + (int64_t)P * 16, 256);
     L->point_list = o;  o = align_up(o + cap * 4, 256);

@@ -79,13 +79,13 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 *__restrict__ geom,
         //   rho3d <= tau  <=>  px^2 + py^2 - tau pz^2 <= 0, a conic; on a row p = u + lx B, so the
         //                      row's pixels lie between the roots of qa lx^2 + 2 qb lx + qc;
         //   rho2d <= tau  <=>  (lx - cx)^2 <= tau/2 - (ly - cy)^2, the low-pass disc.
-        // The span kept is the hull of the two intervals, widened by 0.01 px, with tau inflated
+        // The span kept is the hull of the two intervals, widened by 0.02 px, with tau inflated
         // (the evaluation uses v_rcp / v_exp approximations): conservative, never exact-or-under.
         // A conic that is not an ellipse on this row pencil (qa <= 0) falls back to the cull box.
         const float tau = 2.0f * __logf(255.0f * opa) * 1.001f + 0.01f;
         const float nb = B[0] * B[0] + B[1] * B[1], qa = nb - tau * B[2] * B[2];
         const bool ellipse = qa > 1e-5f * (nb + tau * B[2] * B[2]);
-        const float inv_qa = ellipse ? 1.0f / qa : 0.f;
+        const float inv_qa = ellipse ? __builtin_amdgcn_rcpf(qa) : 0.f;
         const float bx0 = (float)(2 * gx0), bx1 = (float)(2 * gx1 + 1);
         uint32_t colsum = 0;
         for (int by = gy0; by <= gy1; by++) {
@@ -100,18 +100,18 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 *__restrict__ geom,
                 if (!ellipse) {
                     lo = bx0; hi = bx1;
                 } else if (disc >= 0.f) {
-                    const float sq = sqrtf(disc);
+                    const float sq = __builtin_amdgcn_sqrtf(disc);
                     lo = fminf(lo, (-qb - sq) * inv_qa);
                     hi = fmaxf(hi, (-qb + sq) * inv_qa);
                 }
                 const float h = 0.5f * tau - (y - cy) * (y - cy);
                 if (h >= 0.f) {
-                    const float sh = sqrtf(h);
+                    const float sh = __builtin_amdgcn_sqrtf(h);
                     lo = fminf(lo, cx - sh);
                     hi = fmaxf(hi, cx + sh);
                 }
             }
-            const int ilo = (int)ceilf(fmaxf(lo - 0.01f, bx0)), ihi = (int)floorf(fminf(hi + 0.01f, bx1));
+            const int ilo = (int)ceilf(fmaxf(lo - 0.02f, bx0)), ihi = (int)floorf(fminf(hi + 0.02f, bx1));
             if (ilo <= ihi) {
                 const uint32_t cols = ((2u << (ihi >> 1)) - 1u) & ~((1u << (ilo >> 1)) - 1u);  // 8 bits
                 colsum |= cols;
@@ -455,6 +455,11 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __shared__ int s_nfit;
     if (header[1]) return;
     const unsigned long long dbg_t0 = (v.dbg & 32u) ? wall_clock64() : 0ull;
+    int dbg_rounds = 0;
+    unsigned long long dbg_tp = 0ull;            // phase timers (LARA2DGS_DEBUG_FLAGS & 64), thread 0 only
+    uint32_t dbg_ph[5] = {0u, 0u, 0u, 0u, 0u};   // prologue, stage, setup, phase P, phase S2 (shader clocks)
+#define DBG_PHASE(k) do { if (v.dbg & 64u) { const unsigned long long t__ = __builtin_readcyclecounter(); dbg_ph[k] += (uint32_t)(t__ - dbg_tp); dbg_tp = t__; } } while (0)
+    if (v.dbg & 64u) dbg_tp = __builtin_readcyclecounter();
     // work item = (tile, segment): the full segments first, then every tile's last segment
     const uint32_t n_full = header[3];
     int tile, seg;
@@ -506,9 +511,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const float final_A = 1.0f - T_final;
     const float bg_dot_dpixel = v.bg[0] * dpix[0] + v.bg[1] * dpix[1] + v.bg[2] * dpix[2];
 
-    float accum_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f};
-    float accum_normal_rec[3] = {0.f, 0.f, 0.f}, last_normal[3] = {0.f, 0.f, 0.f};
-    float accum_depth_rec = 0.f, accum_alpha_rec = 0.f, last_depth = 0.f, last_alpha = 0.f;
+    float accum_g = 0.f, last_g = 0.f, last_alpha = 0.f;
     float last_dL_dT = 0.f;
 
     // the tile only needs entries [0, max over pixels of last_contributor)
@@ -518,6 +521,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __syncthreads();
     const int total = min((int)s_maxc, seg_hi);
     const int lo = seg_lo;
+    uint32_t quad_last = last_contributor;  // max over the 2x2 block
+    quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0xB1, 0xf, 0xf, false));
+    quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0x4E, 0xf, 0xf, false));
     if (total <= lo) return;
 
     // A pixel whose walk began above this segment resumes from the forward's checkpoint at seg_hi:
@@ -529,10 +535,11 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         T = Tb;
         const float s_alpha = (Tb - T_final) * inv_Tb;
         const float s_m1 = (final_D - ck[1 * 256]) * inv_Tb, s_m2 = (final_D2 - ck[2 * 256]) * inv_Tb;
-        for (int ch = 0; ch < 3; ch++) accum_rec[ch] = (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * inv_Tb;
-        accum_depth_rec = (final_T[pix + 6 * HW] - ck[6 * 256]) * inv_Tb;
-        for (int ch = 0; ch < 3; ch++) accum_normal_rec[ch] = (final_T[pix + (7 + ch) * HW] - ck[(7 + ch) * 256]) * inv_Tb;
-        accum_alpha_rec = s_alpha;
+        float sg = (Tb - T_final) * dL_daccum + (final_T[pix + 6 * HW] - ck[6 * 256]) * dL_ddepth;
+        for (int ch = 0; ch < 3; ch++)
+            sg += (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * dpix[ch] +
+                  (final_T[pix + (7 + ch) * HW] - ck[(7 + ch) * 256]) * dnrm[ch];
+        accum_g = sg * inv_Tb;
         last_dL_dT = (final_D2 * s_alpha + final_A * s_m2 - 2.0f * final_D * s_m1) * dL_dreg;
     }
 
@@ -549,11 +556,14 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         id2 = whi - 2 * WIN - 1 - tid >= lo ? point_list[range.x + whi - 2 * WIN - 1 - tid] : 0u;
         cb1 = whi - WIN - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();  // the previous window's last round is done with rec / s_rect / s_id
+        DBG_PHASE(whi == total ? 0 : 4);
         s_rect[tid] = stage_entry<WIN>(geom, id0, cb0, tid < wcnt, X0, Y0, rec, s_id);
 
         // slab rounds over the window: each takes as many entries as fit the pool, at most 64
         for (int s0 = 0; s0 < wcnt;) {
+            dbg_rounds++;
             __syncthreads();  // window staged / previous round's phase S2 done with pool, occ, s_desc
+            DBG_PHASE(s0 == 0 ? 1 : 4);
             if (wave == 0) {
                 const int slot = s0 + lane;
                 const bool valid = slot < wcnt;
@@ -579,6 +589,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             }
             (&occ[0][0])[tid] = 0ull;  // 64 entries x 4 words = 256 words
             __syncthreads();
+            DBG_PHASE(2);
             const int nfit = s_nfit;
 
             // ---- phase P: every quad walks its own candidates, last list position first (window
@@ -587,7 +598,10 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * WIN + min(s0 + lane, WIN - 1);
                 const uint32_t bm = lane < nfit ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
                 if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) != 0ull) {
-                    const unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
+                    unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
+                    // entries at or beyond the last contributor of all four pixels are not this quad's
+                    const int jmin = whi - s0 - (int)quad_last;
+                    m = jmin >= 64 ? 0ull : (jmin > 0 ? m & (~0ull << jmin) : m);
 #pragma unroll 1
                     for (int half = 0; half < 2; half++) {
                         uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
@@ -610,13 +624,16 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                                 const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                                 T = T * inv_1ma;
                                 const float w = alpha * T;
-                                float dL_dalpha = 0.0f;
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++) {
-                                    accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                                    last_color[ch] = rgb[ch];
-                                    dL_dalpha += (rgb[ch] - accum_rec[ch]) * dpix[ch];
-                                }
+                                // The colour, depth, alpha and normal channels share one recurrence
+                                // ("what lies behind this entry") and enter dL/dalpha only through
+                                // their dot product with the pixel's incoming gradient, so the eight
+                                // channel recurrences of the published kernel collapse into one.
+                                const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2] +
+                                                   nrm[0] * dnrm[0] + nrm[1] * dnrm[1] + nrm[2] * dnrm[2] +
+                                                   c_d * dL_ddepth + dL_daccum;
+                                accum_g = last_alpha * last_g + (1.f - last_alpha) * accum_g;
+                                last_g = gval;
+                                float dL_dalpha = gval - accum_g;
                                 float dL_dz = 0.0f, dL_dweight = 0.0f;
                                 const float inv_cd = __builtin_amdgcn_rcpf(c_d);
                                 const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
@@ -627,18 +644,6 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                                 last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
                                 const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
                                 dL_dz += dL_dmd * dmd_dd;
-
-                                accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                                last_depth = c_d;
-                                dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                                accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                                dL_dalpha += (1.f - accum_alpha_rec) * dL_daccum;
-#pragma unroll
-                                for (int ch = 0; ch < 3; ch++) {
-                                    accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
-                                    last_normal[ch] = nrm[ch];
-                                    dL_dalpha += (nrm[ch] - accum_normal_rec[ch]) * dnrm[ch];
-                                }
                                 dL_dalpha *= T;
                                 last_alpha = alpha;
                                 dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
@@ -656,6 +661,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 }
             }
             __syncthreads();
+            DBG_PHASE(3);
 
             // ---- phase S2: four lanes per entry visit the occupied slots of its slab and
             //      accumulate the 21 coefficient-space sums in registers
@@ -666,22 +672,34 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 float g[21];
 #pragma unroll
                 for (int k = 0; k < 21; k++) g[k] = 0.f;
-                bool touched = false;
+                unsigned long long ow[4] = {0ull, 0ull, 0ull, 0ull};
                 if (has) {
+#pragma unroll
+                    for (int wd = 0; wd < 4; wd++) ow[wd] = occ[e][wd];
+                }
+                const bool touched = (ow[0] | ow[1] | ow[2] | ow[3]) != 0ull;
+                // the entry's T rows are needed at the very end: fetch them now, behind the slot loop
+                float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0, gq2 = gq0;
+                if (touched && sub == 0) {
+                    const float4 *gm = geom + (size_t)s_id[s0 + e] * 5;
+                    gq0 = gm[0]; gq1 = gm[1]; gq2 = gm[2];
+                }
+                if (touched) {
                     const int base = (int)(d & 0xfffu), x0 = (int)((d >> 12) & 15u), y0 = (int)((d >> 16) & 15u);
                     const int w = (int)((d >> 20) & 15u) + 1;
                     const float inv_w = 1.0f / (float)w;
                     const int ws = s0 + e;
                     const EntryRec ent = load_entry<WIN>(rec, ws);
-#pragma unroll 1
-                    for (int wd = 0; wd < 4; wd++) {
-                        unsigned long long om = occ[e][wd];
-                        touched = touched || om != 0ull;
-                        om &= 0x1111111111111111ull << sub;  // lane `sub` takes slots = sub (mod 4)
+                    // lane `sub` takes the slots = sub (mod 4): one bit in four of every word, so the
+                    // four words interleave into a single 64-bit work mask (bit 4i + wd <-> slot 64 wd + 4i + sub)
+                    unsigned long long om = 0ull;
+#pragma unroll
+                    for (int wd = 0; wd < 4; wd++) om |= ((ow[wd] >> sub) & 0x1111111111111111ull) << wd;
+                    {
                         while (om) {
                             const int bit = __builtin_ctzll(om);
                             om &= om - 1ull;
-                            const int s2 = wd * 64 + bit;
+                            const int s2 = (bit & 3) * 64 + (bit & ~3) + sub;
                             const float ww = pool_w[base + s2], da = pool_a[base + s2], dz = pool_z[base + s2];
                             const int row = (int)(((float)s2 + 0.5f) * inv_w), col = s2 - row * w;
                             const int plx = x0 + col, ply = y0 + row;
@@ -717,12 +735,10 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     g[k] += dpp_full<0xB1>(g[k]);
                     g[k] += dpp_full<0x4E>(g[k]);
                 }
-                if (has && sub == 0 && touched) {
+                if (sub == 0 && touched) {
                     const int ws = s0 + e;
                     const uint32_t p = range.x + (uint32_t)(whi - 1 - ws);
-                    const uint32_t id = s_id[ws];
-                    const float4 *gm = geom + (size_t)id * 5;
-                    const float4 g0 = gm[0], g1 = gm[1], g2 = gm[2];
+                    const float4 g0 = gq0, g1 = gq1, g2 = gq2;
                     const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
                     const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
                     const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
@@ -743,16 +759,38 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     row[2] = make_float4(dTw[2], g[12], g[13], g[14]);
                     row[3] = make_float4(g[15], g[16], g[17], g[18]);
                     row[4] = make_float4(g[19], g[20], 0.f, 0.f);
-                    atomicOr(&pair_valid[p >> 5], 1u << (p & 31u));
+                }
+                // publish the wave's 16 validity bits (consecutive list positions) with <= 2 atomic ORs
+                {
+                    const unsigned long long bal = __ballot(touched);
+                    const uint32_t m16 = (uint32_t)__ballot(lane < 16 && ((bal >> (4 * (lane & 15))) & 1ull)) & 0xffffu;
+                    if (m16) {
+                        // entry k of the wave sits at list position p0 - k: bit-reverse so that bits ascend with p
+                        const long long p_lo = (long long)range.x + (whi - 1 - s0 - 16 * wave) - 15;
+                        unsigned long long bits = (unsigned long long)(__builtin_bitreverse32(m16) >> 16);
+                        long long pb = p_lo;
+                        if (pb < 0) { bits >>= (unsigned)(-pb); pb = 0; }
+                        bits <<= (unsigned)(pb & 31);
+                        const uint32_t w0 = (uint32_t)(pb >> 5);
+                        if (lane == 0 && (uint32_t)bits) atomicOr(&pair_valid[w0], (uint32_t)bits);
+                        if (lane == 1 && (uint32_t)(bits >> 32)) atomicOr(&pair_valid[w0 + 1], (uint32_t)(bits >> 32));
+                    }
                 }
             }
             s0 += nfit;
         }
     }
+    if ((v.dbg & 64u) && tid == 0) {
+        DBG_PHASE(4);
+        uint32_t *h = const_cast<uint32_t *>(header);
+        for (int k = 0; k < 5; k++) atomicAdd(&h[16 + k], dbg_ph[k] >> 6);  // units of 64 clocks
+    }
     if ((v.dbg & 32u) && tid == 0) {  // work-group residency in 100 MHz ticks: max, sum, first start, last end
         uint32_t *h = const_cast<uint32_t *>(header);
         const unsigned long long t1 = wall_clock64();
         atomicMax(&h[8], (uint32_t)(t1 - dbg_t0));
+        atomicMax((unsigned long long *)&h[12], ((unsigned long long)(uint32_t)(t1 - dbg_t0) << 32) |
+                                                    ((unsigned long long)dbg_rounds << 16) | (unsigned long long)blockIdx.x);
         atomicAdd(&h[9], (uint32_t)(t1 - dbg_t0));
         atomicMax(&h[10], ~(uint32_t)dbg_t0);
         atomicMax(&h[11], (uint32_t)t1);

@@ -396,7 +396,7 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
     def sec(off, nbytes, dtype, shape):
         return state[off:off + nbytes].view(dtype).view(shape)
 
-    hdr = sec(L.header, 64, torch.int32, (16,))
+    hdr = sec(L.header, 256, torch.int32, (64,))
     return dict(
         header=hdr,
         geom=sec(L.geom, P * 80, torch.float32, (P, 20)),

@@ -1,7 +1,7 @@
 """Work-group residency statistics of composite_bwd (LARA2DGS_DEBUG_FLAGS=32): is the kernel bound
 by its heaviest tile or by aggregate work?  Run on the GPU box."""
 import sys, math, os
-os.environ["LARA2DGS_DEBUG_FLAGS"] = str(32 | int(os.environ.get("EXTRA_FLAGS", "0")))
+os.environ["LARA2DGS_DEBUG_FLAGS"] = str(32 | 64 | int(os.environ.get("EXTRA_FLAGS", "0")))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lara_amd import cameras, synthetic, rasterizer, GaussianRasterizer, GaussianRasterizationSettings
@@ -28,5 +28,19 @@ for regime in ('init', 'trained'):
         cap = rasterizer.binning_capacity(P)
         h = rasterizer.state_views(state, P, 512, 512, cap)["header"].cpu().numpy().astype('uint32')
         span = (int(h[11]) - (~int(h[10]) & 0xffffffff)) & 0xffffffff
+        v = rasterizer.state_views(state, P, 512, 512, cap)
+        blk = int(h[12]) & 0xffff; rounds = int(h[12]) >> 16; nfull = int(h[3])
+        if blk < nfull:
+            tile, seg = [int(x) for x in v["bwd_items"][blk].cpu()]
+        else:
+            tile = int(v["bwd_order"][blk - nfull]); seg = int(v["seg_base"][tile + 1] - v["seg_base"][tile])
+        rg = v["ranges"][tile].cpu().numpy(); ids = v["point_list"][int(rg[0]) + seg * 1024: min(int(rg[0]) + seg * 1024 + 1024, int(rg[1]))].long()
+        cb = v["cullbox"][ids].cpu().numpy(); nonempty = int(((cb[:, 1] >= cb[:, 0]) & (cb[:, 3] >= cb[:, 2])).sum())
+        ty, tx = divmod(tile, 32)
+        ncb = v["n_contrib"][0][ty*16:ty*16+16, tx*16:tx*16+16]
+        print(f"   slowest WG: {int(h[13])/100:.0f} us, block {blk} tile {tile} seg {seg} list {int(rg[1]-rg[0])} rounds {rounds} "
+              f"entries {len(ids)} non-empty cull boxes {nonempty}, mean box {float((cb[:,1]-cb[:,0]).clip(0).mean()):.1f} x {float((cb[:,3]-cb[:,2]).clip(0).mean()):.1f}, tile n_contrib max {int(ncb.max())}")
+        ph = [int(x) * 64 / 2.4e3 for x in h[16:21]]  # us at 2.4 GHz, summed over workgroups
+        print("   phase time summed over WGs (us): prologue %.0f stage %.0f setup %.0f P %.0f S2 %.0f" % tuple(ph))
         print(f"{regime} view {ci}: pairs {h[0]} max_list {h[2]}  WG max {h[8]/100:.0f} us  sum {h[9]/100:.0f} us "
               f"(/512 = {h[9]/100/512:.0f} us)  span {span/100:.0f} us")
