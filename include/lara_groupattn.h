@@ -36,6 +36,57 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
                            const uint16_t *wq, const uint16_t *wkv, const uint16_t *wo, float *y,
                            void *workspace, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The whole GroupAttBlock and the VolTransformer tail (rows A2 / A3 of SURVEY.md section 8).
+ *
+ * Activations live as fp32 *token rows* x[M, 256], M = scenes * R^3, in GROUP-MAJOR order: row
+ *   m = ((((b * R/2 + gd) * R/2 + gh) * R/2 + gw) * 8 + (z*4 + y*2 + x)   <->  voxel (2gd+z, 2gh+y, 2gw+x)
+ * which is the order `GroupAttBlock.forward` unfolds the volume into for attention
+ * (network.py:82-86, block_size 2).  The reference converts volume <-> patches twice per layer
+ * (network.py:82-86, 96-98); here the 3x3x3 convolution reads its neighbours through the token
+ * order instead, so the layout never changes between layers.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Weights of one GroupAttBlock (network.py:57-79), device pointers.  bf16 matrices keep torch's
+ * [out, in] layout; wconv is cnn.weight [256, 256, 3, 3, 3] re-laid as [out][kd][kh][kw][in]. */
+typedef struct lara_groupblock_weights {
+    const float *ln1_w, *ln1_b;        /* norm1                          [256]            */
+    const uint16_t *wq, *wkv, *wo;     /* cross_attn (see above)                          */
+    const float *ln2_w, *ln2_b;        /* norm2                                           */
+    const uint16_t *w1;                /* mlp[0].weight                  [512, 256] bf16  */
+    const float *b1;                   /* mlp[0].bias                    [512]            */
+    const uint16_t *w2;                /* mlp[3].weight                  [256, 512] bf16  */
+    const float *b2;                   /* mlp[3].bias                    [256]            */
+    const float *ln3_w, *ln3_b;        /* norm3                                           */
+    const uint16_t *wconv;             /* cnn.weight re-laid             [256, 27, 256]   */
+    float eps;                         /* LayerNorm eps (all three norms)                 */
+} lara_groupblock_weights;
+
+int64_t lara_groupblock_workspace_bytes(int32_t scenes, int32_t R);
+
+/* In place: x <- GroupAttBlock(x, cond) for block_size 2, i.e. (network.py:88-100)
+ *     x = x + cross_attn(norm1(x), cond, cond);  x = x + mlp(norm2(x));
+ *     x = norm3(x);                               x = x + cnn(x)        (3x3x3, padding 1, no bias)
+ * x fp32 [scenes * R^3, 256] group-major; cond_bf16 [scenes * (R/2)^3, 4, cond_dim]. */
+int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *x,
+                            const uint16_t *cond_bf16, const lara_groupblock_weights *w,
+                            void *workspace, void *stream);
+
+/* VolTransformer tail (network.py:156-163): out = deconv(norm(x)) as channels-last
+ * [scenes, 2R, 2R, 2R, Cout] fp32.  wdeconv = deconv.weight [256, Cout, 2, 2, 2] re-laid as
+ * [(i*2+j)*2+k][Cout][256] bf16; bias fp32 [Cout]; Cout % 4 == 0.  Workspace: scenes*R^3*512 bytes. */
+int lara_voltrans_head_forward(int32_t scenes, int32_t R, const float *x, const float *ln_w,
+                               const float *ln_b, float eps, const uint16_t *wdeconv,
+                               const float *bias, int32_t Cout, float *out, void *workspace,
+                               void *stream);
+
+/* Layout converters between the reference's volume tensor [scenes, C, R, R, R] (fp32) and token
+ * rows [scenes * R^3, C] in group-major order (used once for pos_embed and by the tests). */
+int lara_tokens_from_volume(int32_t scenes, int32_t R, int32_t C, const float *volume, float *tokens,
+                            void *stream);
+int lara_volume_from_tokens(int32_t scenes, int32_t R, int32_t C, const float *tokens, float *volume,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,237 @@
+// mfma_gemm.h -- bf16 MFMA building blocks shared by the attention and encoder-block kernels:
+// LayerNorm+cast, and an LDS-tiled NT GEMM with fused epilogues / implicit 3x3x3 convolution.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// ---- LayerNorm(C = 256) + bf16 cast: one wave per token, 4 channels per lane ---------------------
+__global__ void __launch_bounds__(256)
+ln_cast_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+               const float *__restrict__ beta, const float eps, unsigned short *__restrict__ out,
+               float2 *__restrict__ stats, const int tokens) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tok >= tokens) return;
+    const float4 v = ((const float4 *)(x + (size_t)tok * 256))[lane];
+    float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float mean = s * (1.0f / 256.0f);
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d4 = v.w - mean;
+    float q = a * a + b * b + c * c + d4 * d4;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + eps);
+    const float4 g = ((const float4 *)gamma)[lane], be = ((const float4 *)beta)[lane];
+    ushort4 o;
+    o.x = f2bf(a * rstd * g.x + be.x); o.y = f2bf(b * rstd * g.y + be.y);
+    o.z = f2bf(c * rstd * g.z + be.z); o.w = f2bf(d4 * rstd * g.w + be.w);
+    ((ushort4 *)(out + (size_t)tok * 256))[lane] = o;
+    if (stats && lane == 0) stats[tok] = make_float2(mean, rstd);  // lets a later epilogue redo the LN in fp32
+}
+
+// ---- C[M,N] = A[M,K] . W[N,K]^T, bf16 in, fp32 accumulate ------------------------------------------
+// Workgroup tile 128x128, K step 32, four waves as 2x2, wave tile 64x64 = 2x2 MFMA tiles of 32x32.
+// Operand panels are staged through LDS (double buffered, register staging: the next K tile is
+// loaded into VGPRs while the current one feeds the matrix cores).  Both operands have K contiguous,
+// so a fragment is one ds_read_b128; LDS rows are padded from 64 to 80 bytes, which spreads the 16
+// rows a ds_read_b128 lane group touches over all 16 sixteen-byte slots of the 256-byte bank row
+// (conflict free).  MFMA 32x32x16 operand map: A[i = lane&31][k = 8*(lane>>5) + e],
+// B[k = 8*(lane>>5) + e][j = lane&31]; C/D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//
+// AMODE 1 turns the A operand into the im2col view of a 3x3x3, padding-1 convolution without ever
+// materialising it: activations are channels-last rows of a volume of edge R whose rows are ordered
+// group-major (2x2x2 voxel blocks, the order the attention works in), K = 27 * Cin, and K tile kt
+// reads channels [32 kc, 32 kc + 32) of the row of the voxel's (dz, dy, dx) neighbour (zeros outside
+// the volume); W is the weight re-laid as [Cout][tap][Cin], i.e. still K-contiguous.
+constexpr int GM = 128, GN = 128, GK = 32;
+constexpr int LROW = GK * 2 + 16;  // padded LDS row, bytes
+
+struct GemmP {
+    const unsigned short *A, *W;
+    void *C;
+    const float *resid;  // EPI 1, 3, 4: fp32 [M, N]
+    const float *bias;   // EPI 2, 3, 5: fp32 [N] (EPI 5: [Cout])
+    int M, N, K;
+    int R, Cin;          // AMODE 1 / EPI 5: volume edge, input channels
+    const float2 *stats; // EPI 4: per-row (mean, rstd) of resid
+    const float *gamma, *beta;
+    int Cout;            // EPI 5
+};
+
+// row of the group-major token order <-> voxel (b, d, h, w); Gd = R / 2 blocks per edge
+__device__ __forceinline__ void token_to_voxel(const int m, const int R, int &b, int &d, int &h, int &w) {
+    const int Gd = R >> 1, l = m & 7;
+    int g = m >> 3;
+    const int gw = g % Gd; g /= Gd;
+    const int gh = g % Gd; g /= Gd;
+    const int gd = g % Gd; b = g / Gd;
+    d = 2 * gd + (l >> 2); h = 2 * gh + ((l >> 1) & 1); w = 2 * gw + (l & 1);
+}
+__device__ __forceinline__ int voxel_to_token(const int b, const int d, const int h, const int w, const int R) {
+    const int Gd = R >> 1;
+    return ((((b * Gd + (d >> 1)) * Gd + (h >> 1)) * Gd + (w >> 1)) << 3) | ((d & 1) << 2) | ((h & 1) << 1) | (w & 1);
+}
+
+// EPI 0: bf16 store            1: fp32 store of acc + resid        2: bf16 store of gelu(acc + bias)
+//     3: fp32 acc + bias + resid   4: fp32 LN(resid row) + acc (LN redone from stats, gamma, beta)
+//     5: fp32 acc + bias scattered as a stride-2, kernel-2 transposed convolution (N = 8 * Cout)
+template <int AMODE, int EPI>
+__global__ void __launch_bounds__(256)
+gemm_bf16_nt_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][(GM + GN) * LROW];
+    const unsigned short *__restrict__ A = p.A, *__restrict__ W = p.W;
+    const int M = p.M, N = p.N, K = p.K;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bm0 = blockIdx.x * GM, bn0 = blockIdx.y * GN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r = lane & 31, kh = lane >> 5;
+
+    // staging map: 256 rows (128 of A, 128 of W) x 4 sixteen-byte chunks per K tile; thread t moves
+    // chunk (t & 3) of rows (t >> 2) + 64 i, i = 0..3 (i < 2: A rows, i >= 2: W rows)
+    const int srow = tid >> 2, schunk = tid & 3;
+    const unsigned short *gsrc[4];
+    int loff[4];
+    int vb[2], vd[2], vh[2], vw[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = srow + 64 * i;  // 0..255: A rows then W rows
+        const unsigned short *base = row < GM ? A + (size_t)min(bm0 + row, M - 1) * (AMODE ? p.Cin : K)
+                                              : W + (size_t)min(bn0 + row - GM, N - 1) * K;
+        gsrc[i] = base + schunk * 8;
+        loff[i] = row * LROW + schunk * 16;
+        if (AMODE == 1 && i < 2) token_to_voxel(min(bm0 + row, M - 1), p.R, vb[i], vd[i], vh[i], vw[i]);
+    }
+    const int ktiles = (K + GK - 1) / GK;
+    const int kpt = AMODE ? p.Cin / GK : 1;  // K tiles per filter tap
+    uint4 stage[4];
+    auto gload = [&](int kt) {
+        if (AMODE == 1) {
+            const int tap = kt / kpt, kc = kt - tap * kpt;
+            const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int nd = vd[i] + dz, nh = vh[i] + dy, nw = vw[i] + dx;
+                const bool in = (unsigned)nd < (unsigned)p.R && (unsigned)nh < (unsigned)p.R && (unsigned)nw < (unsigned)p.R;
+                const int tok = in ? voxel_to_token(vb[i], nd, nh, nw, p.R) : 0;
+                stage[i] = in ? *(const uint4 *)(A + (size_t)tok * p.Cin + kc * GK + schunk * 8) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 2; i < 4; i++) stage[i] = *(const uint4 *)(gsrc[i] + (size_t)kt * GK);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = kt * GK + schunk * 8;
+                stage[i] = k < K ? *(const uint4 *)(gsrc[i] + (size_t)kt * GK) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) *(uint4 *)(&lds[buf][loff[i]]) = stage[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) gload(kt + 1);  // in flight while this tile is multiplied
+        const unsigned char *la = &lds[buf][(wm + r) * LROW + kh * 16];
+        const unsigned char *lb = &lds[buf][(GM + wn + r) * LROW + kh * 16];
+#pragma unroll
+        for (int s = 0; s < GK / 16; s++) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                a[i] = *(const bf16x8 *)(la + i * 32 * LROW + s * 32);
+                b[i] = *(const bf16x8 *)(lb + i * 32 * LROW + s * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < ktiles) lstore(buf ^ 1);  // the other buffer was last read one iteration ago
+        __syncthreads();
+    }
+    // Epilogue through LDS: the accumulator layout gives every lane one element of 16 different
+    // rows (4-byte stores, issue bound); bouncing a 32x64 block per wave through LDS turns that into
+    // 16-byte row-contiguous loads of the residual and 16-byte stores.
+    float *ep = (float *)&lds[0][0] + wave * (32 * 68);  // 32 rows x (64 + 4 pad) floats per wave
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
+            const int row = bm0 + wm + i * 32 + lr, col = bn0 + wn + c4;
+            if (row < M && col < N) {
+                float4 v = *(const float4 *)(ep + lr * 68 + c4);
+                const size_t o = (size_t)row * N + col;
+                if (EPI == 2 || EPI == 3) {
+                    const float4 bs = *(const float4 *)(p.bias + col);
+                    v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+                }
+                if (EPI == 0 || EPI == 2) {
+                    if (EPI == 2) {  // exact (erf) GELU, nn.GELU's default
+                        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678f));
+                        v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678f));
+                        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678f));
+                        v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678f));
+                    }
+                    ushort4 h;
+                    h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
+                    *(ushort4 *)((unsigned short *)p.C + o) = h;
+                } else if (EPI == 1 || EPI == 3) {
+                    const float4 rs = *(const float4 *)(p.resid + o);
+                    *(float4 *)((float *)p.C + o) = make_float4(v.x + rs.x, v.y + rs.y, v.z + rs.z, v.w + rs.w);
+                } else if (EPI == 4) {
+                    const float4 rs = *(const float4 *)(p.resid + o);
+                    const float2 st = p.stats[row];
+                    const float4 ga = *(const float4 *)(p.gamma + col), be = *(const float4 *)(p.beta + col);
+                    *(float4 *)((float *)p.C + o) =
+                        make_float4(v.x + (rs.x - st.x) * st.y * ga.x + be.x, v.y + (rs.y - st.x) * st.y * ga.y + be.y,
+                                    v.z + (rs.z - st.x) * st.y * ga.z + be.z, v.w + (rs.w - st.x) * st.y * ga.w + be.w);
+                } else {  // EPI 5: column = tap * Cout + co, tap = (i*2 + j)*2 + k of the 2x2x2 kernel
+                    int b, d, h, w;
+                    token_to_voxel(row, p.R, b, d, h, w);
+                    const int tap = col / p.Cout, co = col - tap * p.Cout, R2 = 2 * p.R;
+                    const size_t oo = ((((size_t)b * R2 + 2 * d + (tap >> 2)) * R2 + 2 * h + ((tap >> 1) & 1)) * R2 +
+                                       2 * w + (tap & 1)) * p.Cout + co;
+                    const float4 bs = *(const float4 *)(p.bias + co);
+                    *(float4 *)((float *)p.C + oo) = make_float4(v.x + bs.x, v.y + bs.y, v.z + bs.z, v.w + bs.w);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace

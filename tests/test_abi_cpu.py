@@ -12,9 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    text = open(os.path.join(ROOT, "include", "lara2dgs.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lara2dgs_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for hdr in ("lara2dgs.h", "lara_groupattn.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(lara2dgs_[a-z0-9_]+|lara_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_declares_the_three_reference_entry_points():
