@@ -183,6 +183,42 @@ def attention_leg(device, scenes):
             "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 2500.0, 4), "bound": "mfma"}
 
 
+def encoder_leg(device, scenes):
+    """The whole volume transformer (12 GroupAttBlocks on a 32^3 x 256 volume + the x2 deconvolution,
+    network.py:105-164) for this rank's scenes, forward, random-init weights of the reference's shapes:
+    time and FLOP rate against the 2.5 PFLOP/s dense bf16 peak.  Reported beside the raster."""
+    from lara_amd import rasterizer
+    from lara_amd.encoder import VolTransformer
+    torch.manual_seed(0)
+    vt = VolTransformer(256, 800, [16], 32, 64, 80, 12, 16).to(device)
+    with torch.no_grad():
+        for n, p in list(vt.named_parameters()) + list(vt.named_buffers()):
+            if p.dtype == torch.bfloat16:
+                p.copy_((torch.randn(p.shape, device=device) * (p.shape[-1] ** -0.5)).to(torch.bfloat16))
+            elif n.endswith("_w"):
+                p.fill_(1.0)
+        vt.pos_embed.normal_(0, 1 / 16)
+        feats = torch.randn(scenes, 4, 800, 16, 16, 16, device=device)
+        vt(feats)
+        torch.cuda.synchronize()
+        rasterizer.profile_enable(True)
+        for _ in range(2):
+            vt(feats)
+        torch.cuda.synchronize()
+    rec = rasterizer.profile_collect()
+    rasterizer.profile_enable(False)
+    M, G = scenes * 32 ** 3, scenes * 4096
+    ms = sum(t for _, t in rec) / 2
+    conv_us = 1e3 * sum(t for k, t in rec if k == "gb_conv3d") / 24
+    per_layer = 2 * M * 256 * 256 * 2 + 2 * G * 4 * 800 * 512 + 2 * 2 * 8 * 4 * 16 * 16 * G + 2 * M * 256 * 512 * 2 + 2 * M * 27 * 256 * 256
+    flops = 12 * per_layer + 2 * M * 256 * 640
+    return {"workload": f"VolTransformer forward (12 x [attention, MLP, LayerNorms, Conv3d 3x3x3] + deconv), {scenes} scenes "
+                        f"x 32^3 voxels, bf16 MFMA / fp32 accumulate, random-init weights",
+            "ms_per_forward": round(ms, 2), "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(flops / ms / 1e9 / 2500.0, 4), "bound": "mfma",
+            "conv3d_us": round(conv_us, 1), "conv3d_TFLOPs": round(2 * M * 27 * 256 * 256 / conv_us / 1e6, 1)}
+
+
 def cpu_baseline(args):
     """The CPU oracle (fp32 restatement, OpenMP over tiles) on a bounded sample of the same
     workload: the 8 views of scene 0, forward + backward each (about 10-30 s of CPU work)."""
@@ -301,6 +337,7 @@ def main():
                               "alg_GBs": round(v["alg_GBs"], 1)} for k, v in table.items()}
     if rank == 0 and not args.no_roofline:
         out["attention"] = attention_leg(device, args.scenes)
+        out["encoder"] = encoder_leg(device, args.scenes)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -43,7 +43,10 @@ ln_cast_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
 }
 
 // ---- C[M,N] = A[M,K] . W[N,K]^T, bf16 in, fp32 accumulate ------------------------------------------
-// Workgroup tile 128x128, K step 32, four waves as 2x2, wave tile 64x64 = 2x2 MFMA tiles of 32x32.
+// Workgroup tile TM x 128 (TM = 128 or 256), K step 32, four waves as 2x2, wave tile (TM/2) x 64 =
+// (TM/64) x 2 MFMA tiles of 32x32.  TM = 256 halves the operand re-reads through L2 (the implicit
+// convolution at 128x128 moved 10.8 GB per launch through L2 for 0.46 TFLOP of work) and needs six
+// instead of eight ds_read_b128 per eight MFMAs.
 // Operand panels are staged through LDS (double buffered, register staging: the next K tile is
 // loaded into VGPRs while the current one feeds the matrix cores).  Both operands have K contiguous,
 // so a fragment is one ds_read_b128; LDS rows are padded from 64 to 80 bytes, which spreads the 16
@@ -56,7 +59,7 @@ ln_cast_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
 // group-major (2x2x2 voxel blocks, the order the attention works in), K = 27 * Cin, and K tile kt
 // reads channels [32 kc, 32 kc + 32) of the row of the voxel's (dz, dy, dx) neighbour (zeros outside
 // the volume); W is the weight re-laid as [Cout][tap][Cin], i.e. still K-contiguous.
-constexpr int GM = 128, GN = 128, GK = 32;
+constexpr int GN = 128, GK = 32;
 constexpr int LROW = GK * 2 + 16;  // padded LDS row, bytes
 
 struct GemmP {
@@ -70,6 +73,15 @@ struct GemmP {
     const float *gamma, *beta;
     int Cout;            // EPI 5
 };
+
+// 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_exp / v_rcp
+__device__ __forceinline__ float gelu_erf(const float x) {
+    const float z = fabsf(x) * 0.70710678f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 // row of the group-major token order <-> voxel (b, d, h, w); Gd = R / 2 blocks per edge
 __device__ __forceinline__ void token_to_voxel(const int m, const int R, int &b, int &d, int &h, int &w) {
@@ -88,51 +100,64 @@ __device__ __forceinline__ int voxel_to_token(const int b, const int d, const in
 // EPI 0: bf16 store            1: fp32 store of acc + resid        2: bf16 store of gelu(acc + bias)
 //     3: fp32 acc + bias + resid   4: fp32 LN(resid row) + acc (LN redone from stats, gamma, beta)
 //     5: fp32 acc + bias scattered as a stride-2, kernel-2 transposed convolution (N = 8 * Cout)
-template <int AMODE, int EPI>
+template <int AMODE, int EPI, int GM = 128>
 __global__ void __launch_bounds__(256)
 gemm_bf16_nt_kernel(const GemmP p) {
+    constexpr int MI = GM / 64;         // 32-row MFMA tiles per wave along M
+    constexpr int NA = GM / 64;         // staging passes that carry A rows
+    constexpr int NS = (GM + GN) / 64;  // staging passes per K tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][(GM + GN) * LROW];
     const unsigned short *__restrict__ A = p.A, *__restrict__ W = p.W;
     const int M = p.M, N = p.N, K = p.K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bm0 = blockIdx.x * GM, bn0 = blockIdx.y * GN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (GM / 2), wn = (wave & 1) * 64;
     const int r = lane & 31, kh = lane >> 5;
 
-    // staging map: 256 rows (128 of A, 128 of W) x 4 sixteen-byte chunks per K tile; thread t moves
-    // chunk (t & 3) of rows (t >> 2) + 64 i, i = 0..3 (i < 2: A rows, i >= 2: W rows)
-    const int srow = tid >> 2, schunk = tid & 3;
-    const unsigned short *gsrc[4];
-    int loff[4];
-    int vb[2], vd[2], vh[2], vw[2];
+    // staging map: GM + 128 rows (A rows, then W rows) x 4 sixteen-byte chunks per K tile; thread t
+    // moves chunk (t & 3) of rows (t >> 2) + 64 i, i = 0..NS-1 (i < NA: A rows, else W rows)
+    // rows are dealt so that the 16 lanes of a store group hit rows {0, 4, 8, 12} + c: with 80-byte rows
+    // those start 0, 64, 128, 192 bytes into the 256-byte bank row (rows 0..3 would wrap onto each other)
+    const int sq = tid >> 2, schunk = tid & 3;
+    const int srow = (sq & ~15) | ((sq & 3) << 2) | ((sq >> 2) & 3);
+    const unsigned short *gsrc[NS];
+    int loff[NS];
+    int vb[NA], vd[NA], vh[NA], vw[NA];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NS; i++) {
         const int row = srow + 64 * i;  // 0..255: A rows then W rows
         const unsigned short *base = row < GM ? A + (size_t)min(bm0 + row, M - 1) * (AMODE ? p.Cin : K)
                                               : W + (size_t)min(bn0 + row - GM, N - 1) * K;
         gsrc[i] = base + schunk * 8;
         loff[i] = row * LROW + schunk * 16;
-        if (AMODE == 1 && i < 2) token_to_voxel(min(bm0 + row, M - 1), p.R, vb[i], vd[i], vh[i], vw[i]);
+        if (AMODE == 1 && i < NA) token_to_voxel(min(bm0 + row, M - 1), p.R, vb[i < NA ? i : 0], vd[i < NA ? i : 0], vh[i < NA ? i : 0], vw[i < NA ? i : 0]);
     }
     const int ktiles = (K + GK - 1) / GK;
     const int kpt = AMODE ? p.Cin / GK : 1;  // K tiles per filter tap
-    uint4 stage[4];
+    uint4 stage[NS];
+    const unsigned short *nrow[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) nrow[i] = nullptr;
     auto gload = [&](int kt) {
         if (AMODE == 1) {
             const int tap = kt / kpt, kc = kt - tap * kpt;
-            const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+            if (kc == 0) {  // a new filter tap: resolve this thread's neighbour rows once for its kpt K tiles
+                const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int nd = vd[i] + dz, nh = vh[i] + dy, nw = vw[i] + dx;
-                const bool in = (unsigned)nd < (unsigned)p.R && (unsigned)nh < (unsigned)p.R && (unsigned)nw < (unsigned)p.R;
-                const int tok = in ? voxel_to_token(vb[i], nd, nh, nw, p.R) : 0;
-                stage[i] = in ? *(const uint4 *)(A + (size_t)tok * p.Cin + kc * GK + schunk * 8) : make_uint4(0, 0, 0, 0);
+                for (int i = 0; i < NA; i++) {
+                    const int nd = vd[i] + dz, nh = vh[i] + dy, nw = vw[i] + dx;
+                    const bool in = (unsigned)nd < (unsigned)p.R && (unsigned)nh < (unsigned)p.R && (unsigned)nw < (unsigned)p.R;
+                    nrow[i] = in ? A + (size_t)voxel_to_token(vb[i], nd, nh, nw, p.R) * p.Cin + schunk * 8 : nullptr;
+                }
             }
 #pragma unroll
-            for (int i = 2; i < 4; i++) stage[i] = *(const uint4 *)(gsrc[i] + (size_t)kt * GK);
+            for (int i = 0; i < NA; i++)
+                stage[i] = nrow[i] ? *(const uint4 *)(nrow[i] + kc * GK) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = NA; i < NS; i++) stage[i] = *(const uint4 *)(gsrc[i] + (size_t)kt * GK);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NS; i++) {
                 const int k = kt * GK + schunk * 8;
                 stage[i] = k < K ? *(const uint4 *)(gsrc[i] + (size_t)kt * GK) : make_uint4(0, 0, 0, 0);
             }
@@ -140,12 +165,12 @@ gemm_bf16_nt_kernel(const GemmP p) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) *(uint4 *)(&lds[buf][loff[i]]) = stage[i];
+        for (int i = 0; i < NS; i++) *(uint4 *)(&lds[buf][loff[i]]) = stage[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -161,14 +186,13 @@ gemm_bf16_nt_kernel(const GemmP p) {
         const unsigned char *lb = &lds[buf][(GM + wn + r) * LROW + kh * 16];
 #pragma unroll
         for (int s = 0; s < GK / 16; s++) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[MI], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                a[i] = *(const bf16x8 *)(la + i * 32 * LROW + s * 32);
-                b[i] = *(const bf16x8 *)(lb + i * 32 * LROW + s * 32);
-            }
+            for (int i = 0; i < MI; i++) a[i] = *(const bf16x8 *)(la + i * 32 * LROW + s * 32);
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) b[j] = *(const bf16x8 *)(lb + j * 32 * LROW + s * 32);
+#pragma unroll
+            for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -180,14 +204,21 @@ gemm_bf16_nt_kernel(const GemmP p) {
     // rows (4-byte stores, issue bound); bouncing a 32x64 block per wave through LDS turns that into
     // 16-byte row-contiguous loads of the residual and 16-byte stores.
     float *ep = (float *)&lds[0][0] + wave * (32 * 68);  // 32 rows x (64 + 4 pad) floats per wave
+    unsigned long long *rowbase = (unsigned long long *)((float *)&lds[0][0] + 4 * (32 * 68)) + wave * 32;  // EPI 5
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < MI; i++) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][j][e];
+        if (EPI == 5 && lane < 32) {  // output offset of the voxel (2d, 2h, 2w) of each of the wave's 32 rows
+            int b, d, h, w;
+            token_to_voxel(min(bm0 + wm + i * 32 + lane, M - 1), p.R, b, d, h, w);
+            const size_t R2 = 2 * (size_t)p.R;
+            rowbase[lane] = (((size_t)b * R2 + 2 * d) * R2 + 2 * h) * R2 + 2 * w;
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -201,11 +232,8 @@ gemm_bf16_nt_kernel(const GemmP p) {
                     v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
                 }
                 if (EPI == 0 || EPI == 2) {
-                    if (EPI == 2) {  // exact (erf) GELU, nn.GELU's default
-                        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678f));
-                        v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678f));
-                        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678f));
-                        v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678f));
+                    if (EPI == 2) {  // erf GELU (nn.GELU's default); the result is rounded to bf16 anyway
+                        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                     }
                     ushort4 h;
                     h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
@@ -221,11 +249,9 @@ gemm_bf16_nt_kernel(const GemmP p) {
                         make_float4(v.x + (rs.x - st.x) * st.y * ga.x + be.x, v.y + (rs.y - st.x) * st.y * ga.y + be.y,
                                     v.z + (rs.z - st.x) * st.y * ga.z + be.z, v.w + (rs.w - st.x) * st.y * ga.w + be.w);
                 } else {  // EPI 5: column = tap * Cout + co, tap = (i*2 + j)*2 + k of the 2x2x2 kernel
-                    int b, d, h, w;
-                    token_to_voxel(row, p.R, b, d, h, w);
-                    const int tap = col / p.Cout, co = col - tap * p.Cout, R2 = 2 * p.R;
-                    const size_t oo = ((((size_t)b * R2 + 2 * d + (tap >> 2)) * R2 + 2 * h + ((tap >> 1) & 1)) * R2 +
-                                       2 * w + (tap & 1)) * p.Cout + co;
+                    const int tap = col / p.Cout, co = col - tap * p.Cout;
+                    const size_t R2 = 2 * (size_t)p.R;
+                    const size_t oo = (rowbase[lr] + ((size_t)(tap >> 2) * R2 + ((tap >> 1) & 1)) * R2 + (tap & 1)) * p.Cout + co;
                     const float4 bs = *(const float4 *)(p.bias + co);
                     *(float4 *)((float *)p.C + oo) = make_float4(v.x + bs.x, v.y + bs.y, v.z + bs.z, v.w + bs.w);
                 }
