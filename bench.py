@@ -16,10 +16,17 @@ all-reduce of the encoder parameters (train_lightning.py:72); the encoder is out
 ranks all-reduce a stand-in fp32 buffer of the encoder's size (126.3 M parameters, SURVEY.md
 section 2 #12) in 25 MB buckets on a side stream, overlapped with the raster backward.
 
+The scenes of a step are independent, so they are spread over `--streams` HIP streams (default 2: the
+composite kernels end in a tail of a few heavy tiles and the binning has single-workgroup steps; a
+second stream fills those holes).  "single_stream" repeats the measurement with every call on the
+current stream, i.e. exactly as the reference's Python loop would issue it.
+
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed, algorithmic bytes
-from DESIGN.md / SURVEY.md section 8d) and "cpu_baseline" (the CPU oracle on a bounded sample).
+from DESIGN.md / SURVEY.md section 8d), "cpu_baseline" (the CPU oracle on a bounded sample),
+"single_stream", "attention" and "encoder" (MFMA legs, reported beside the raster).
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -46,6 +53,8 @@ def parse():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--grid", type=int, default=64, help="surfels = grid^3 * 2 (64 -> 524288)")
     ap.add_argument("--regime", default="init", choices=["init", "trained"])
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the independent scenes of a step are spread over (1 = the reference's sequential loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-res", type=int, default=512)
@@ -76,12 +85,26 @@ def build_batch(args, device, rank):
     return scenes, settings, gc, ga
 
 
-def step(scenes, settings, gc, ga):
-    """All forwards of the batch, then one backward through every view (as loss.backward() does)."""
+_streams = []
+
+
+def step(scenes, settings, gc, ga, n_streams=1):
+    """All forwards of the batch, then one backward through every view (as loss.backward() does).
+    Scenes are independent (the unit the north star data-parallelises over), so scene i is enqueued on
+    HIP stream i % n_streams; autograd replays each view's backward on its forward's stream.  The
+    composite kernels end with a tail of a few heavy tiles and the binning has single-workgroup
+    steps: a second stream fills those holes with the next scene's work."""
     from lara_amd import GaussianRasterizer
     outs, grads = [], []
-    for sc in scenes:
-        for rs in settings:
+    cur = torch.cuda.current_stream()
+    while len(_streams) < n_streams and n_streams > 1:
+        _streams.append(torch.cuda.Stream())
+    for i, sc in enumerate(scenes):
+        side = _streams[i % n_streams] if n_streams > 1 else None
+        if side is not None:
+            side.wait_stream(cur)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+          for rs in settings:
             # the reference's activations, applied per view (renderer_2dgs.py:181-189)
             opac = torch.sigmoid(sc["opacity"])
             scales = torch.exp(sc["scales"])
@@ -92,7 +115,11 @@ def step(scenes, settings, gc, ga):
                 scales=scales, rotations=rots, cov3D_precomp=None)
             outs += [color, allmap]
             grads += [gc, ga]
+    for side in _streams[:n_streams if n_streams > 1 else 0]:
+        cur.wait_stream(side)
     torch.autograd.backward(outs, grads)
+    for side in _streams[:n_streams if n_streams > 1 else 0]:
+        cur.wait_stream(side)
     for sc in scenes:
         for v in sc.values():
             v.grad = None
@@ -284,7 +311,7 @@ def main():
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 dp.bucketed_all_reduce(grad_buf)
-        step(scenes, settings, gc, ga)
+        step(scenes, settings, gc, ga, args.streams)
         if world > 1:
             torch.cuda.current_stream().wait_stream(comm_stream)
 
@@ -326,10 +353,23 @@ def main():
                         f"SH degree 1, regime={args.regime}",
             "frames_per_step": frames_per_step,
             "parallelism": f"dp{world} (per-scene; raster not sharded)",
+            "hip_streams": args.streams,
             "grad_allreduce": (f"{ENCODER_PARAMS * 4 / 1e6:.0f} MB fp32 stand-in for the encoder's DDP "
                                "gradient, 25 MB buckets, RCCL, overlapped") if world > 1 else None,
         },
     }
+    if rank == 0 and world == 1 and args.streams != 1 and not args.no_roofline:
+        # the same step as the reference's loop would issue it: every scene on the current stream
+        for _ in range(2):
+            step(scenes, settings, gc, ga, 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(scenes, settings, gc, ga, 1)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        out["single_stream"] = {"value": round(frames_per_step * args.steps / dt1, 3), "unit": "frames/s",
+                                "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
     if rank == 0 and not args.no_roofline:
         roof, table, D = measure_roofline(scenes, settings, gc, ga, args)
         out["roofline"] = roof
