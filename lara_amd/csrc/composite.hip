@@ -438,7 +438,7 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 // needs ~3x fewer wave instructions, and it keeps the backward free of floating-point atomics.
 // A round takes as many list entries (from the back) as fit the pool, at most SLAB_CHUNK.
 constexpr int SLAB_WIN = 256;     // list entries staged per window (one per thread)
-constexpr int SLAB_CHUNK = 64;    // entries per slab round (<= 64: one ballot word)
+constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
 constexpr int SLAB_POOL = 3072;   // (pixel, entry) slots per round: 36 KB as three fp32 planes
 
 __global__ void __launch_bounds__(256)
@@ -454,9 +454,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __shared__ float4 rec[REC4 * WIN];
     __shared__ float pool_w[SLAB_POOL], pool_a[SLAB_POOL], pool_z[SLAB_POOL];
     __shared__ float gpix[256 * 6];      // per pixel: dL/dcolor (3), dL/dnormal (3)
-    __shared__ unsigned long long occ[SLAB_CHUNK][4];  // which slots of an entry's slab were written
-    __shared__ uint32_t s_rect[WIN];     // candidate block rectangle of each staged entry (stage_entry)
-    __shared__ uint32_t s_desc[SLAB_CHUNK];  // slab: base | x0 << 12 | y0 << 16 | (w-1) << 20 | (h-1) << 24 | has << 28
+    __shared__ uint32_t s_base[SLAB_CHUNK];  // first pool slot of each entry of the round
     __shared__ uint32_t s_id[WIN];
     __shared__ uint32_t s_maxc;
     __shared__ int s_nfit;
@@ -528,6 +526,10 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __syncthreads();
     const int total = min((int)s_maxc, seg_hi);
     const int lo = seg_lo;
+    // bits of the 8x8 block mask that precede this lane's 2x2 block (slab slot ranking)
+    const int my_blk = (lyi >> 1) * 8 + (lxi >> 1);
+    const uint32_t below_lo = my_blk >= 32 ? 0xffffffffu : (1u << my_blk) - 1u;
+    const uint32_t below_hi = my_blk >= 32 ? (1u << (my_blk - 32)) - 1u : 0u;
     uint32_t quad_last = last_contributor;  // max over the 2x2 block
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0xB1, 0xf, 0xf, false));
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0x4E, 0xf, 0xf, false));
@@ -562,178 +564,182 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         id1 = id2;
         id2 = whi - 2 * WIN - 1 - tid >= lo ? point_list[range.x + whi - 2 * WIN - 1 - tid] : 0u;
         cb1 = whi - WIN - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();  // the previous window's last round is done with rec / s_rect / s_id
+        __syncthreads();  // the previous window's last round is done with rec / s_id
         DBG_PHASE(whi == total ? 0 : 4);
-        s_rect[tid] = stage_entry<WIN>(geom, id0, cb0, tid < wcnt, X0, Y0, rec, s_id);
+        (void)stage_entry<WIN>(geom, id0, cb0, tid < wcnt, X0, Y0, rec, s_id);
 
-        // slab rounds over the window: each takes as many entries as fit the pool, at most 64
+        // Slab rounds over the window.  An entry's slab has four slots (the 2x2 pixels) per candidate
+        // block of its mask, in mask-bit order: slot = base + 4 * rank(block) + pixel-in-block with
+        // rank = popcount(mask below the block).  A round takes as many entries as fit the pool, at
+        // most 128.
         for (int s0 = 0; s0 < wcnt;) {
             dbg_rounds++;
-            __syncthreads();  // window staged / previous round's phase S2 done with pool, occ, s_desc
+            __syncthreads();  // window staged / previous round's phase S2 done with pool, s_base
             DBG_PHASE(s0 == 0 ? 1 : 4);
-            if (wave == 0) {
-                const int slot = s0 + lane;
-                const bool valid = slot < wcnt;
-                const uint32_t rp = valid ? s_rect[slot] : 0u;
-                uint32_t area = 0, x0 = 0, y0 = 0, w = 2, h = 2;
-                if (rp) {
-                    const uint32_t gx0 = rp & 15u, gx1 = (rp >> 4) & 15u, gy0 = (rp >> 8) & 15u, gy1 = (rp >> 12) & 15u;
-                    x0 = 2 * gx0; y0 = 2 * gy0; w = 2 * (gx1 - gx0 + 1); h = 2 * (gy1 - gy0 + 1);
-                    area = w * h;
+            if (wave == 0) {  // lane l sizes entries 2l and 2l+1, one 64-lane scan covers the 128
+                uint32_t c[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int slot = s0 + 2 * lane + q;
+                    c[q] = 0;
+                    if (slot < wcnt)
+                        c[q] = 4u * (uint32_t)(__builtin_popcount(__float_as_uint(rec[3 * WIN + slot].w)) +
+                                               __builtin_popcount(__float_as_uint(rec[5 * WIN + slot].z)));
                 }
-                uint32_t incl = area;
+                uint32_t incl = c[0] + c[1];
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
                     const uint32_t y = __shfl_up(incl, d, 64);
                     if (lane >= d) incl += y;
                 }
-                const bool fits = valid && incl <= (uint32_t)SLAB_POOL;
-                const unsigned long long fm = __ballot(fits);
-                // entries that fit form a prefix; at least one fits (an area is at most 256)
-                if (lane == 0) s_nfit = fm == ~0ull ? 64 : __builtin_ctzll(~fm);
-                s_desc[lane] = (incl - area) | (x0 << 12) | (y0 << 16) | ((w - 1) << 20) | ((h - 1) << 24) |
-                               ((rp && fits) ? (1u << 28) : 0u);
+                const uint32_t b0 = incl - c[0] - c[1], b1 = incl - c[1];
+                const unsigned long long f0 = __ballot(s0 + 2 * lane < wcnt && b1 <= (uint32_t)SLAB_POOL);
+                const unsigned long long f1 = __ballot(s0 + 2 * lane + 1 < wcnt && incl <= (uint32_t)SLAB_POOL);
+                // entries that fit form a prefix; at least one fits (a slab has at most 256 slots)
+                const int L = f1 == ~0ull ? 64 : __builtin_ctzll(~f1);
+                if (lane == 0) s_nfit = L == 64 ? 128 : 2 * L + (int)((f0 >> L) & 1ull);
+                s_base[2 * lane] = b0;
+                s_base[2 * lane + 1] = b1;
+            } else {  // the other three waves clear the weights: w == 0 marks a slot nobody wrote
+                float4 *pw = (float4 *)pool_w;
+                for (int i = tid - 64; i < SLAB_POOL / 4; i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            (&occ[0][0])[tid] = 0ull;  // 64 entries x 4 words = 256 words
             __syncthreads();
             DBG_PHASE(2);
             const int nfit = s_nfit;
 
-            // ---- phase P: every quad walks its own candidates, last list position first (window
-            //      slots ascend as list positions descend)
+            // ---- phase P: every quad walks its own candidates over the whole round, last list position
+            //      first (window slots ascend as list positions descend)
             {
-                const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * WIN + min(s0 + lane, WIN - 1);
-                const uint32_t bm = lane < nfit ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
-                if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) != 0ull) {
-                    unsigned long long m = quad_masks(bm, (wave & 1) * 4, grp);
-                    // entries at or beyond the last contributor of all four pixels are not this quad's
-                    const int jmin = whi - s0 - (int)quad_last;
-                    m = jmin >= 64 ? 0ull : (jmin > 0 ? m & (~0ull << jmin) : m);
-#pragma unroll 1
-                    for (int half = 0; half < 2; half++) {
-                        uint32_t mm = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-                        const int jb = 32 * half;
-                        while (__ballot(mm != 0u) != 0ull) {
-                            const bool has = mm != 0u;
-                            const int j = jb + (has ? __builtin_ctz(mm) : 0);  // entry of this round
-                            mm &= mm - 1u;
-                            const int ws = s0 + j;                               // window slot
-                            const uint32_t contributor = (uint32_t)(whi - 1 - ws);  // 0-based list position
-                            const EntryRec ent = load_entry<WIN>(rec, ws);
-                            Hit h;
-                            float Tw[3], opa;
-                            const bool active = eval_rec(ent, lx, ly, h, Tw, opa) && has && contributor < last_contributor;
-                            if (__ballot(active) == 0ull || (v.dbg & 16u)) continue;
-                            if (active) {
-                                const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
-                                const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
-                                const float alpha = h.alpha, c_d = h.depth;
-                                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                                T = T * inv_1ma;
-                                const float w = alpha * T;
-                                // The colour, depth, alpha and normal channels share one recurrence
-                                // ("what lies behind this entry") and enter dL/dalpha only through
-                                // their dot product with the pixel's incoming gradient, so the eight
-                                // channel recurrences of the published kernel collapse into one.
-                                const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2] +
-                                                   nrm[0] * dnrm[0] + nrm[1] * dnrm[1] + nrm[2] * dnrm[2] +
-                                                   c_d * dL_ddepth + dL_daccum;
-                                accum_g = last_alpha * last_g + (1.f - last_alpha) * accum_g;
-                                last_g = gval;
-                                float dL_dalpha = gval - accum_g;
-                                float dL_dz = 0.0f, dL_dweight = 0.0f;
-                                const float inv_cd = __builtin_amdgcn_rcpf(c_d);
-                                const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
-                                const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
-                                if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
-                                dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
-                                dL_dalpha += dL_dweight - last_dL_dT;
-                                last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                                const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                                dL_dz += dL_dmd * dmd_dd;
-                                dL_dalpha *= T;
-                                last_alpha = alpha;
-                                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-                                dL_dz += w * dL_ddepth;
-                                // park (w, dL/dalpha, dL/dz) in this pixel's slot of the entry's slab
-                                const uint32_t d = s_desc[j];
-                                const int sl = (lyi - (int)((d >> 16) & 15u)) * (int)(((d >> 20) & 15u) + 1u) +
-                                               (lxi - (int)((d >> 12) & 15u));
-                                const int slot = (int)(d & 0xfffu) + sl;
-                                pool_w[slot] = w; pool_a[slot] = dL_dalpha; pool_z[slot] = dL_dz;
-                                atomicOr(&occ[j][sl >> 6], 1ull << (sl & 63));  // ds_or_b64
-                            }
-                        }
+                unsigned long long m0 = 0ull, m1 = 0ull;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * WIN + min(s0 + 64 * k + lane, WIN - 1);
+                    const uint32_t bm = 64 * k + lane < nfit ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
+                    unsigned long long m = 0ull;
+                    if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) != 0ull) m = quad_masks(bm, (wave & 1) * 4, grp);
+                    if (k == 0) m0 = m; else m1 = m;
+                }
+                // entries at or beyond the last contributor of all four pixels are not this quad's
+                const int jmin = whi - s0 - (int)quad_last;
+                if (jmin > 0) {
+                    m0 = jmin >= 64 ? 0ull : m0 & (~0ull << jmin);
+                    m1 = jmin >= 128 ? 0ull : (jmin > 64 ? m1 & (~0ull << (jmin - 64)) : m1);
+                }
+                while (__ballot((m0 | m1) != 0ull) != 0ull) {
+                    const bool has = (m0 | m1) != 0ull;
+                    const bool lo_word = m0 != 0ull;
+                    const unsigned long long mw = lo_word ? m0 : m1;
+                    const int j = (lo_word ? 0 : 64) + (has ? __builtin_ctzll(mw) : 0);  // entry of this round
+                    m0 = lo_word ? m0 & (m0 - 1ull) : m0;
+                    m1 = lo_word ? m1 : m1 & (m1 - 1ull);
+                    const int ws = s0 + j;                               // window slot
+                    const uint32_t contributor = (uint32_t)(whi - 1 - ws);  // 0-based list position
+                    const EntryRec ent = load_entry<WIN>(rec, ws);
+                    Hit h;
+                    float Tw[3], opa;
+                    const bool active = eval_rec(ent, lx, ly, h, Tw, opa) && has && contributor < last_contributor;
+                    if (__ballot(active) == 0ull || (v.dbg & 16u)) continue;
+                    if (active) {
+                        const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
+                        const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
+                        const float alpha = h.alpha, c_d = h.depth;
+                        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                        T = T * inv_1ma;
+                        const float w = alpha * T;
+                        // The colour, depth, alpha and normal channels share one recurrence
+                        // ("what lies behind this entry") and enter dL/dalpha only through
+                        // their dot product with the pixel's incoming gradient, so the eight
+                        // channel recurrences of the published kernel collapse into one.
+                        const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2] +
+                                           nrm[0] * dnrm[0] + nrm[1] * dnrm[1] + nrm[2] * dnrm[2] +
+                                           c_d * dL_ddepth + dL_daccum;
+                        accum_g = last_alpha * last_g + (1.f - last_alpha) * accum_g;
+                        last_g = gval;
+                        float dL_dalpha = gval - accum_g;
+                        float dL_dz = 0.0f, dL_dweight = 0.0f;
+                        const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                        const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
+                        const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
+                        if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
+                        dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
+                        dL_dalpha += dL_dweight - last_dL_dT;
+                        last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                        dL_dz += dL_dmd * dmd_dd;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                        dL_dz += w * dL_ddepth;
+                        // park (w, dL/dalpha, dL/dz) in this pixel's slot of the entry's slab
+                        const uint32_t mlo = __float_as_uint(ent.r3.w), mhi = __float_as_uint(r5.z);
+                        const int rank = __builtin_popcount(mlo & below_lo) + __builtin_popcount(mhi & below_hi);
+                        const int slot = (int)s_base[j] + 4 * rank + (lane & 3);
+                        pool_w[slot] = w; pool_a[slot] = dL_dalpha; pool_z[slot] = dL_dz;
                     }
                 }
             }
             __syncthreads();
             DBG_PHASE(3);
 
-            // ---- phase S2: four lanes per entry visit the occupied slots of its slab and
-            //      accumulate the 21 coefficient-space sums in registers
-            {
-                const int e = tid >> 2, sub = tid & 3;
-                const uint32_t d = s_desc[e];
-                const bool has = e < nfit && ((d >> 28) & 1u) && !(v.dbg & 2u);
+            // ---- phase S2: four lanes per entry (lane = pixel of the 2x2 block) step through the
+            //      entry's candidate blocks and accumulate the 21 coefficient-space sums in registers;
+            //      a group takes entries g and g + 64 of the round
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                if (half * 64 >= nfit) break;
+                const int e = half * 64 + (tid >> 2), sub = tid & 3;
+                const int ws = min(s0 + e, WIN - 1);
+                const bool has = e < nfit && !(v.dbg & 2u);
+                const uint32_t mlo = has ? __float_as_uint(rec[3 * WIN + ws].w) : 0u;
+                const uint32_t mhi = has ? __float_as_uint(rec[5 * WIN + ws].z) : 0u;
+                unsigned long long bmask = ((unsigned long long)mhi << 32) | mlo;
+                // the entry's T rows are needed at the very end: fetch them now, behind the slot loop
+                float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0, gq2 = gq0;
+                if (bmask && sub == 0) {
+                    const float4 *gm = geom + (size_t)s_id[ws] * 5;
+                    gq0 = gm[0]; gq1 = gm[1]; gq2 = gm[2];
+                }
                 float g[21];
 #pragma unroll
                 for (int k = 0; k < 21; k++) g[k] = 0.f;
-                unsigned long long ow[4] = {0ull, 0ull, 0ull, 0ull};
-                if (has) {
-#pragma unroll
-                    for (int wd = 0; wd < 4; wd++) ow[wd] = occ[e][wd];
-                }
-                const bool touched = (ow[0] | ow[1] | ow[2] | ow[3]) != 0ull;
-                // the entry's T rows are needed at the very end: fetch them now, behind the slot loop
-                float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0, gq2 = gq0;
-                if (touched && sub == 0) {
-                    const float4 *gm = geom + (size_t)s_id[s0 + e] * 5;
-                    gq0 = gm[0]; gq1 = gm[1]; gq2 = gm[2];
-                }
-                if (touched) {
-                    const int base = (int)(d & 0xfffu), x0 = (int)((d >> 12) & 15u), y0 = (int)((d >> 16) & 15u);
-                    const int w = (int)((d >> 20) & 15u) + 1;
-                    const float inv_w = 1.0f / (float)w;
-                    const int ws = s0 + e;
+                bool any = false;
+                if (bmask) {
                     const EntryRec ent = load_entry<WIN>(rec, ws);
-                    // lane `sub` takes the slots = sub (mod 4): one bit in four of every word, so the
-                    // four words interleave into a single 64-bit work mask (bit 4i + wd <-> slot 64 wd + 4i + sub)
-                    unsigned long long om = 0ull;
-#pragma unroll
-                    for (int wd = 0; wd < 4; wd++) om |= ((ow[wd] >> sub) & 0x1111111111111111ull) << wd;
-                    {
-                        while (om) {
-                            const int bit = __builtin_ctzll(om);
-                            om &= om - 1ull;
-                            const int s2 = (bit & 3) * 64 + (bit & ~3) + sub;
-                            const float ww = pool_w[base + s2], da = pool_a[base + s2], dz = pool_z[base + s2];
-                            const int row = (int)(((float)s2 + 0.5f) * inv_w), col = s2 - row * w;
-                            const int plx = x0 + col, ply = y0 + row;
-                            const float flx = (float)plx, fly = (float)ply;
-                            Hit h;
-                            float Tw[3], opa;
-                            (void)eval_rec(ent, flx, fly, h, Tw, opa);  // same arithmetic as phase P
-                            const float *gp = gpix + (ply * 16 + plx) * 6;
-                            g[18] += ww * gp[0]; g[19] += ww * gp[1]; g[20] += ww * gp[2];
-                            g[14] += ww * gp[3]; g[15] += ww * gp[4]; g[16] += ww * gp[5];
-                            // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
-                            g[9] += dz * h.sx; g[10] += dz * h.sy; g[11] += dz;
-                            const float dL_dG = opa * da;
-                            if (h.use3d) {
-                                const float dL_dsx = dL_dG * -h.G * h.sx + dz * Tw[0];
-                                const float dL_dsy = dL_dG * -h.G * h.sy + dz * Tw[1];
-                                const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
-                                const float dpz = -(dpx * h.sx + dpy * h.sy);
-                                g[0] += dpx; g[1] += dpy; g[2] += dpz;
-                                g[3] += flx * dpx; g[4] += flx * dpy; g[5] += flx * dpz;
-                                g[6] += fly * dpx; g[7] += fly * dpy; g[8] += fly * dpz;
-                            } else {
-                                g[12] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddx);
-                                g[13] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddy);
-                            }
-                            g[17] += h.G * da;
+                    int slot = (int)s_base[e] + sub;
+                    while (bmask) {
+                        const int blk = __builtin_ctzll(bmask);
+                        bmask &= bmask - 1ull;
+                        const float ww = pool_w[slot];
+                        const int cur = slot;
+                        slot += 4;
+                        if (ww == 0.f) continue;
+                        any = true;
+                        const float da = pool_a[cur], dz = pool_z[cur];
+                        const int plx = 2 * (blk & 7) + (sub & 1), ply = 2 * (blk >> 3) + (sub >> 1);
+                        const float flx = (float)plx, fly = (float)ply;
+                        Hit h;
+                        float Tw[3], opa;
+                        (void)eval_rec(ent, flx, fly, h, Tw, opa);  // same arithmetic as phase P
+                        const float *gp = gpix + (ply * 16 + plx) * 6;
+                        g[18] += ww * gp[0]; g[19] += ww * gp[1]; g[20] += ww * gp[2];
+                        g[14] += ww * gp[3]; g[15] += ww * gp[4]; g[16] += ww * gp[5];
+                        // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
+                        g[9] += dz * h.sx; g[10] += dz * h.sy; g[11] += dz;
+                        const float dL_dG = opa * da;
+                        if (h.use3d) {
+                            const float dL_dsx = dL_dG * -h.G * h.sx + dz * Tw[0];
+                            const float dL_dsy = dL_dG * -h.G * h.sy + dz * Tw[1];
+                            const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
+                            const float dpz = -(dpx * h.sx + dpy * h.sy);
+                            g[0] += dpx; g[1] += dpy; g[2] += dpz;
+                            g[3] += flx * dpx; g[4] += flx * dpy; g[5] += flx * dpz;
+                            g[6] += fly * dpx; g[7] += fly * dpy; g[8] += fly * dpz;
+                        } else {
+                            g[12] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddx);
+                            g[13] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddy);
                         }
+                        g[17] += h.G * da;
                     }
                 }
                 // sum over the 4 lanes of the entry (every lane ends with the total)
@@ -742,8 +748,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     g[k] += dpp_full<0xB1>(g[k]);
                     g[k] += dpp_full<0x4E>(g[k]);
                 }
+                const unsigned long long anyb = __ballot(any);
+                const bool touched = ((anyb >> (lane & ~3)) & 0xfull) != 0ull;
                 if (sub == 0 && touched) {
-                    const int ws = s0 + e;
                     const uint32_t p = range.x + (uint32_t)(whi - 1 - ws);
                     const float4 g0 = gq0, g1 = gq1, g2 = gq2;
                     const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
@@ -773,7 +780,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     const uint32_t m16 = (uint32_t)__ballot(lane < 16 && ((bal >> (4 * (lane & 15))) & 1ull)) & 0xffffu;
                     if (m16) {
                         // entry k of the wave sits at list position p0 - k: bit-reverse so that bits ascend with p
-                        const long long p_lo = (long long)range.x + (whi - 1 - s0 - 16 * wave) - 15;
+                        const long long p_lo = (long long)range.x + (whi - 1 - s0 - half * 64 - 16 * wave) - 15;
                         unsigned long long bits = (unsigned long long)(__builtin_bitreverse32(m16) >> 16);
                         long long pb = p_lo;
                         if (pb < 0) { bits >>= (unsigned)(-pb); pb = 0; }
