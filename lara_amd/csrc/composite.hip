@@ -439,7 +439,8 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 // A round takes as many list entries (from the back) as fit the pool, at most SLAB_CHUNK.
 constexpr int SLAB_WIN = 256;     // list entries staged per window (one per thread)
 constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
-constexpr int SLAB_POOL = 3072;   // (pixel, entry) slots per round: 36 KB as three fp32 planes
+constexpr int SLAB_POOL = 512;    // (entry, 2x2 block) slots per round
+constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padded to 96 bytes (48 KB in all)
 
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
@@ -452,8 +453,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      float4 *__restrict__ pair_grad, uint32_t *__restrict__ pair_valid) {
     constexpr int WIN = SLAB_WIN;
     __shared__ float4 rec[REC4 * WIN];
-    __shared__ float pool_w[SLAB_POOL], pool_a[SLAB_POOL], pool_z[SLAB_POOL];
-    __shared__ float gpix[256 * 6];      // per pixel: dL/dcolor (3), dL/dnormal (3)
+    __shared__ __attribute__((aligned(16))) float pool[SLAB_POOL * SLAB_F];
     __shared__ uint32_t s_base[SLAB_CHUNK];  // first pool slot of each entry of the round
     __shared__ uint32_t s_id[WIN];
     __shared__ uint32_t s_maxc;
@@ -507,11 +507,6 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         dL_dreg = dL_dallmap[6 * HW + pix];
         final_D = final_T[pix + HW];
         final_D2 = final_T[pix + 2 * HW];
-    }
-    {
-        float *gp = gpix + (lyi * 16 + lxi) * 6;
-        gp[0] = dpix[0]; gp[1] = dpix[1]; gp[2] = dpix[2];
-        gp[3] = dnrm[0]; gp[4] = dnrm[1]; gp[5] = dnrm[2];
     }
     const float final_A = 1.0f - T_final;
     const float bg_dot_dpixel = v.bg[0] * dpix[0] + v.bg[1] * dpix[1] + v.bg[2] * dpix[2];
@@ -583,8 +578,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     const int slot = s0 + 2 * lane + q;
                     c[q] = 0;
                     if (slot < wcnt)
-                        c[q] = 4u * (uint32_t)(__builtin_popcount(__float_as_uint(rec[3 * WIN + slot].w)) +
-                                               __builtin_popcount(__float_as_uint(rec[5 * WIN + slot].z)));
+                        c[q] = (uint32_t)(__builtin_popcount(__float_as_uint(rec[3 * WIN + slot].w)) +
+                                          __builtin_popcount(__float_as_uint(rec[5 * WIN + slot].z)));
                 }
                 uint32_t incl = c[0] + c[1];
 #pragma unroll
@@ -595,14 +590,14 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 const uint32_t b0 = incl - c[0] - c[1], b1 = incl - c[1];
                 const unsigned long long f0 = __ballot(s0 + 2 * lane < wcnt && b1 <= (uint32_t)SLAB_POOL);
                 const unsigned long long f1 = __ballot(s0 + 2 * lane + 1 < wcnt && incl <= (uint32_t)SLAB_POOL);
-                // entries that fit form a prefix; at least one fits (a slab has at most 256 slots)
+                // entries that fit form a prefix; at least one fits (a slab has at most 64 slots)
                 const int L = f1 == ~0ull ? 64 : __builtin_ctzll(~f1);
                 if (lane == 0) s_nfit = L == 64 ? 128 : 2 * L + (int)((f0 >> L) & 1ull);
                 s_base[2 * lane] = b0;
                 s_base[2 * lane + 1] = b1;
-            } else {  // the other three waves clear the weights: w == 0 marks a slot nobody wrote
-                float4 *pw = (float4 *)pool_w;
-                for (int i = tid - 64; i < SLAB_POOL / 4; i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {  // the other three waves clear the pool: a block no quad visits must read as zeros
+                float4 *pw = (float4 *)pool;
+                for (int i = tid - 64; i < SLAB_POOL * SLAB_F / 4; i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
             DBG_PHASE(2);
@@ -640,117 +635,107 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     float Tw[3], opa;
                     const bool active = eval_rec(ent, lx, ly, h, Tw, opa) && has && contributor < last_contributor;
                     if (__ballot(active) == 0ull || (v.dbg & 16u)) continue;
-                    if (active) {
-                        const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
-                        const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
-                        const float alpha = h.alpha, c_d = h.depth;
-                        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T = T * inv_1ma;
-                        const float w = alpha * T;
-                        // The colour, depth, alpha and normal channels share one recurrence
-                        // ("what lies behind this entry") and enter dL/dalpha only through
-                        // their dot product with the pixel's incoming gradient, so the eight
-                        // channel recurrences of the published kernel collapse into one.
-                        const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2] +
-                                           nrm[0] * dnrm[0] + nrm[1] * dnrm[1] + nrm[2] * dnrm[2] +
-                                           c_d * dL_ddepth + dL_daccum;
-                        accum_g = last_alpha * last_g + (1.f - last_alpha) * accum_g;
-                        last_g = gval;
-                        float dL_dalpha = gval - accum_g;
-                        float dL_dz = 0.0f, dL_dweight = 0.0f;
-                        const float inv_cd = __builtin_amdgcn_rcpf(c_d);
-                        const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
-                        const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
-                        if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
-                        dL_dweight += (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
-                        dL_dalpha += dL_dweight - last_dL_dT;
-                        last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                        dL_dz += dL_dmd * dmd_dd;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-                        dL_dz += w * dL_ddepth;
-                        // park (w, dL/dalpha, dL/dz) in this pixel's slot of the entry's slab
-                        const uint32_t mlo = __float_as_uint(ent.r3.w), mhi = __float_as_uint(r5.z);
-                        const int rank = __builtin_popcount(mlo & below_lo) + __builtin_popcount(mhi & below_hi);
-                        const int slot = (int)s_base[j] + 4 * rank + (lane & 3);
-                        pool_w[slot] = w; pool_a[slot] = dL_dalpha; pool_z[slot] = dL_dz;
+                    // From here on all lanes run (the quad sums below need uniform control flow): inactive
+                    // lanes keep their state and contribute exact zeros.
+                    const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
+                    const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
+                    const float alpha = h.alpha, c_d = h.depth;
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float T_new = T * inv_1ma;
+                    const float w = alpha * T_new;
+                    // The colour, depth, alpha and normal channels share one recurrence
+                    // ("what lies behind this entry") and enter dL/dalpha only through
+                    // their dot product with the pixel's incoming gradient, so the eight
+                    // channel recurrences of the published kernel collapse into one.
+                    const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2] +
+                                       nrm[0] * dnrm[0] + nrm[1] * dnrm[1] + nrm[2] * dnrm[2] +
+                                       c_d * dL_ddepth + dL_daccum;
+                    const float accum_new = last_alpha * last_g + (1.f - last_alpha) * accum_g;
+                    float dL_dalpha = gval - accum_new;
+                    float dL_dz = 0.0f;
+                    const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_cd);
+                    const float dmd_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_cd * inv_cd;
+                    if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
+                    const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    const float dLdT_new = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                    const float dL_dmd = 2.0f * (T_new * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                    dL_dz += dL_dmd * dmd_dd;
+                    dL_dalpha *= T_new;
+                    dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                    dL_dz += w * dL_ddepth;
+                    T = active ? T_new : T;
+                    accum_g = active ? accum_new : accum_g;
+                    last_g = active ? gval : last_g;
+                    last_alpha = active ? alpha : last_alpha;
+                    last_dL_dT = active ? dLdT_new : last_dL_dT;
+                    // this pixel's 22 coefficient-space partials (zeros when inactive) ...
+                    const float ww = active ? w : 0.f, da = active ? dL_dalpha : 0.f, dz = active ? dL_dz : 0.f;
+                    const float sx = active ? h.sx : 0.f, sy = active ? h.sy : 0.f, rz = active ? h.rz : 0.f;
+                    float g[22];
+                    g[18] = ww * dpix[0]; g[19] = ww * dpix[1]; g[20] = ww * dpix[2];
+                    g[14] = ww * dnrm[0]; g[15] = ww * dnrm[1]; g[16] = ww * dnrm[2];
+                    // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
+                    g[9] = dz * sx; g[10] = dz * sy; g[11] = dz;
+                    const float qG = opa * da * h.G;  // dL/dG * G
+                    const float dL_dsx = dz * Tw[0] - qG * sx, dL_dsy = dz * Tw[1] - qG * sy;
+                    const float dpx = h.use3d ? dL_dsx * rz : 0.f, dpy = h.use3d ? dL_dsy * rz : 0.f;
+                    const float dpz = -(dpx * sx + dpy * sy);
+                    g[0] = dpx; g[1] = dpy; g[2] = dpz;
+                    g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
+                    g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
+                    g[12] = h.use3d ? 0.f : -qG * FILTER_INV_SQUARE * h.ddx;
+                    g[13] = h.use3d ? 0.f : -qG * FILTER_INV_SQUARE * h.ddy;
+                    g[17] = h.G * da;
+                    g[21] = ww;  // > 0 marks a block that contributed
+                    // ... summed over the quad's 2x2 pixels with a DPP reduce-scatter (each lane ends up
+                    // with 5-6 of the 22 sums) and parked in the (entry, block) slot: plain stores, one
+                    // writer per slot
+                    float r[6];
+                    quad_reduce_scatter(g, r, lane);
+                    const uint32_t mlo = __float_as_uint(ent.r3.w), mhi = __float_as_uint(r5.z);
+                    const int rank = __builtin_popcount(mlo & below_lo) + __builtin_popcount(mhi & below_hi);
+                    float *ps = pool + ((int)s_base[has ? j : 0] + rank) * SLAB_F + (lane & 3);
+                    if (has) {
+                        ps[0] = r[0]; ps[4] = r[1]; ps[8] = r[2]; ps[12] = r[3]; ps[16] = r[4];
+                        if (!(lane & 2)) ps[20] = r[5];
                     }
                 }
             }
             __syncthreads();
             DBG_PHASE(3);
 
-            // ---- phase S2: four lanes per entry (lane = pixel of the 2x2 block) step through the
-            //      entry's candidate blocks and accumulate the 21 coefficient-space sums in registers;
-            //      a group takes entries g and g + 64 of the round
-#pragma unroll 1
-            for (int half = 0; half < 2; half++) {
-                if (half * 64 >= nfit) break;
-                const int e = half * 64 + (tid >> 2), sub = tid & 3;
+            // ---- phase S2: two lanes per entry add up the entry's block slots (no geometry any more)
+            {
+                const int e = tid >> 1, part = tid & 1;
                 const int ws = min(s0 + e, WIN - 1);
                 const bool has = e < nfit && !(v.dbg & 2u);
-                const uint32_t mlo = has ? __float_as_uint(rec[3 * WIN + ws].w) : 0u;
-                const uint32_t mhi = has ? __float_as_uint(rec[5 * WIN + ws].z) : 0u;
-                unsigned long long bmask = ((unsigned long long)mhi << 32) | mlo;
+                const int cnt = has ? __builtin_popcount(__float_as_uint(rec[3 * WIN + ws].w)) +
+                                          __builtin_popcount(__float_as_uint(rec[5 * WIN + ws].z)) : 0;
                 // the entry's T rows are needed at the very end: fetch them now, behind the slot loop
                 float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0, gq2 = gq0;
-                if (bmask && sub == 0) {
+                if (cnt && part == 0) {
                     const float4 *gm = geom + (size_t)s_id[ws] * 5;
                     gq0 = gm[0]; gq1 = gm[1]; gq2 = gm[2];
                 }
-                float g[21];
+                float g[24];
 #pragma unroll
-                for (int k = 0; k < 21; k++) g[k] = 0.f;
-                bool any = false;
-                if (bmask) {
-                    const EntryRec ent = load_entry<WIN>(rec, ws);
-                    int slot = (int)s_base[e] + sub;
-                    while (bmask) {
-                        const int blk = __builtin_ctzll(bmask);
-                        bmask &= bmask - 1ull;
-                        const float ww = pool_w[slot];
-                        const int cur = slot;
-                        slot += 4;
-                        if (ww == 0.f) continue;
-                        any = true;
-                        const float da = pool_a[cur], dz = pool_z[cur];
-                        const int plx = 2 * (blk & 7) + (sub & 1), ply = 2 * (blk >> 3) + (sub >> 1);
-                        const float flx = (float)plx, fly = (float)ply;
-                        Hit h;
-                        float Tw[3], opa;
-                        (void)eval_rec(ent, flx, fly, h, Tw, opa);  // same arithmetic as phase P
-                        const float *gp = gpix + (ply * 16 + plx) * 6;
-                        g[18] += ww * gp[0]; g[19] += ww * gp[1]; g[20] += ww * gp[2];
-                        g[14] += ww * gp[3]; g[15] += ww * gp[4]; g[16] += ww * gp[5];
-                        // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
-                        g[9] += dz * h.sx; g[10] += dz * h.sy; g[11] += dz;
-                        const float dL_dG = opa * da;
-                        if (h.use3d) {
-                            const float dL_dsx = dL_dG * -h.G * h.sx + dz * Tw[0];
-                            const float dL_dsy = dL_dG * -h.G * h.sy + dz * Tw[1];
-                            const float dpx = dL_dsx * h.rz, dpy = dL_dsy * h.rz;
-                            const float dpz = -(dpx * h.sx + dpy * h.sy);
-                            g[0] += dpx; g[1] += dpy; g[2] += dpz;
-                            g[3] += flx * dpx; g[4] += flx * dpy; g[5] += flx * dpz;
-                            g[6] += fly * dpx; g[7] += fly * dpy; g[8] += fly * dpz;
-                        } else {
-                            g[12] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddx);
-                            g[13] += dL_dG * (-h.G * FILTER_INV_SQUARE * h.ddy);
-                        }
-                        g[17] += h.G * da;
+                for (int k = 0; k < 24; k++) g[k] = 0.f;
+                const float4 *ps = (const float4 *)(pool + (int)s_base[e] * SLAB_F);
+                for (int i = part; i < cnt; i += 2) {
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        const float4 t = ps[i * (SLAB_F / 4) + q];
+                        g[4 * q] += t.x; g[4 * q + 1] += t.y; g[4 * q + 2] += t.z; g[4 * q + 3] += t.w;
                     }
+                    const float2 t2 = *(const float2 *)(ps + i * (SLAB_F / 4) + 5);
+                    g[20] += t2.x; g[21] += t2.y;
                 }
-                // sum over the 4 lanes of the entry (every lane ends with the total)
 #pragma unroll
-                for (int k = 0; k < 21; k++) {
-                    g[k] += dpp_full<0xB1>(g[k]);
-                    g[k] += dpp_full<0x4E>(g[k]);
-                }
-                const unsigned long long anyb = __ballot(any);
-                const bool touched = ((anyb >> (lane & ~3)) & 0xfull) != 0ull;
-                if (sub == 0 && touched) {
+                for (int k = 0; k < 22; k++) g[k] += dpp_full<0xB1>(g[k]);  // the entry's two lanes
+                const bool touched = g[21] > 0.f;
+                if (part == 0 && touched) {
                     const uint32_t p = range.x + (uint32_t)(whi - 1 - ws);
                     const float4 g0 = gq0, g1 = gq1, g2 = gq2;
                     const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
@@ -774,14 +759,14 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     row[3] = make_float4(g[15], g[16], g[17], g[18]);
                     row[4] = make_float4(g[19], g[20], 0.f, 0.f);
                 }
-                // publish the wave's 16 validity bits (consecutive list positions) with <= 2 atomic ORs
+                // publish the wave's 32 validity bits (consecutive list positions) with <= 2 atomic ORs
                 {
                     const unsigned long long bal = __ballot(touched);
-                    const uint32_t m16 = (uint32_t)__ballot(lane < 16 && ((bal >> (4 * (lane & 15))) & 1ull)) & 0xffffu;
-                    if (m16) {
+                    const uint32_t m32 = (uint32_t)__ballot(lane < 32 && ((bal >> (2 * (lane & 31))) & 1ull));
+                    if (m32) {
                         // entry k of the wave sits at list position p0 - k: bit-reverse so that bits ascend with p
-                        const long long p_lo = (long long)range.x + (whi - 1 - s0 - half * 64 - 16 * wave) - 15;
-                        unsigned long long bits = (unsigned long long)(__builtin_bitreverse32(m16) >> 16);
+                        const long long p_lo = (long long)range.x + (whi - 1 - s0 - 32 * wave) - 31;
+                        unsigned long long bits = (unsigned long long)__builtin_bitreverse32(m32);
                         long long pb = p_lo;
                         if (pb < 0) { bits >>= (unsigned)(-pb); pb = 0; }
                         bits <<= (unsigned)(pb & 31);
