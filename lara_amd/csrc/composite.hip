@@ -423,20 +423,24 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-// Quad-SIMT reverse traversal + deferred, atomic-free reduction.
+// Quad-SIMT reverse traversal + two-level, atomic-free reduction.
 //
-// Phase P (lane = pixel, each DPP quad walks its own candidate list back to front) only runs the
-// per-pixel recurrences of the reference's backward (T, the accum_rec family, the distortion
-// terms) and leaves, per contributing (pixel, entry), three scalars: w = alpha*T, dL/dalpha and
-// dL/dz.  They are parked in an LDS *slab pool*: phase S gives every staged entry a slab the size
-// of its candidate block rectangle (typically 6x6 pixels), so each (pixel, entry) owns one slot --
-// plain ds_write, no atomics, no collisions.  Phase S2 (4 lanes per entry) walks the entry's slab,
-// re-evaluates the splat geometry for the pixels that contributed, forms the 21 coefficient-space
-// partial derivatives and accumulates them in registers; a 2-step DPP reduce and the entry has
-// its sums.  Versus reducing per entry across the wave inside the traversal (one candidate stream
-// per wave, a 55-instruction butterfly and a 64-lane gradient evaluation for 11 useful lanes) this
-// needs ~3x fewer wave instructions, and it keeps the backward free of floating-point atomics.
-// A round takes as many list entries (from the back) as fit the pool, at most SLAB_CHUNK.
+// One workgroup per (tile, 1024-entry segment of its list); pixels whose walk began above the segment
+// resume from the forward's checkpoint (see the prologue).  A window of 256 entries is staged at a
+// time; inside it, rounds of up to 128 entries:
+//   phase P  (lane = pixel, each DPP quad walks its own candidate list back to front) runs the
+//            per-pixel recurrences of the reference's backward (T, the collapsed accum_rec
+//            recurrence, the distortion terms), forms the pixel's 22 coefficient-space partial
+//            derivatives, adds the quad's 2x2 pixels with a DPP reduce-scatter and parks the sums in
+//            the LDS slot of its (entry, block): plain ds_write, one writer per slot.  An entry's
+//            slab has one slot per candidate block of its mask (slot = base + popcount(mask below
+//            the block)); a 64-lane scan over the round hands out the bases, and a round takes as
+//            many entries as fit the 512-slot pool.
+//   phase S2 (two lanes per entry) adds the entry's block slots, maps the sums back through
+//            A = k0 x l0, B = Tw x l0, C = k0 x Tw and writes the 80-byte gradient row.
+// Versus reducing per entry across the wave inside the traversal (one candidate stream per wave, a
+// 55-instruction butterfly and a 64-lane gradient evaluation for 11 useful lanes) this needs half
+// the wave instructions, and it keeps the backward free of floating-point atomics.
 constexpr int SLAB_WIN = 256;     // list entries staged per window (one per thread)
 constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
 constexpr int SLAB_POOL = 512;    // (entry, 2x2 block) slots per round
