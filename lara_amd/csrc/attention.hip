@@ -77,7 +77,7 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
                            const float *ln_weight, const float *ln_bias, float eps,
                            const uint16_t *wq, const uint16_t *wkv, const uint16_t *wo, float *y,
                            void *workspace, void *stream) {
-    if (G < 0 || cond_dim <= 0 || (cond_dim % 16) != 0) return LARA2DGS_E_INVALID;
+    if (G < 0 || cond_dim <= 0 || (cond_dim % 32) != 0) return LARA2DGS_E_INVALID;
     if (G == 0) return LARA2DGS_OK;
     if (!x || !cond_bf16 || !ln_weight || !ln_bias || !wq || !wkv || !wo || !y || !workspace)
         return LARA2DGS_E_INVALID;

@@ -37,19 +37,20 @@ int64_t lara_groupblock_workspace_bytes(int32_t scenes, int32_t R) {
     if (scenes < 0 || R <= 0 || (R & 1)) return LARA2DGS_E_INVALID;
     const int64_t M = (int64_t)scenes * R * R * R;
     // xn | q | o | kv (bf16 [M,256] each; q|o doubles as the MLP hidden [M,512]) + (mean, rstd) per row
-    return M * 256 * 2 * 4 + M * 8 + 1024;
+    // + one zeroed row (the convolution's padding voxels)
+    return M * 256 * 2 * 4 + M * 8 + 512 + 1024;
 }
 
 int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *x,
                             const uint16_t *cond_bf16, const lara_groupblock_weights *w,
                             void *workspace, void *stream) {
-    if (scenes < 0 || R <= 0 || (R & 1) || cond_dim <= 0 || (cond_dim % 16) != 0 || !w) return LARA2DGS_E_INVALID;
+    if (scenes < 0 || R <= 0 || (R & 1) || cond_dim <= 0 || (cond_dim % 32) != 0 || !w) return LARA2DGS_E_INVALID;
     if (scenes == 0) return LARA2DGS_OK;
     if (!x || !cond_bf16 || !workspace || !w->ln1_w || !w->ln1_b || !w->wq || !w->wkv || !w->wo || !w->ln2_w ||
         !w->ln2_b || !w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->ln3_w || !w->ln3_b || !w->wconv)
         return LARA2DGS_E_INVALID;
     const int64_t M64 = (int64_t)scenes * R * R * R;
-    if (M64 > (1 << 30)) return LARA2DGS_E_INVALID;
+    if (M64 * 2056 + 512 >= (1ll << 32)) return LARA2DGS_E_INVALID;  // kernels address the workspace with 32-bit offsets
     const int M = (int)M64, G = M / 8;
     hipStream_t s = (hipStream_t)stream;
     // 1. attention step, in place (its workspace is the first 4 * M * 512 bytes of ours)
@@ -59,6 +60,7 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
     unsigned short *xn = (unsigned short *)workspace;
     unsigned short *hid = xn + (size_t)M * 256;  // [M, 512]
     float2 *stats = (float2 *)((char *)workspace + (size_t)M * 256 * 2 * 4);
+    char *zero_row = (char *)workspace + (size_t)M * 256 * 2 * 4 + (size_t)M * 8;
     // 2. MLP
     {
         L2D_PROF("gb_ln2", s);
@@ -87,11 +89,13 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
                            stats, M);
     }
     L2D_CHECK_LAUNCH();
+    if (hipMemsetAsync(zero_row, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     {
         L2D_PROF("gb_conv3d", s);
         GemmP p{};
         p.A = xn; p.W = w->wconv; p.C = x; p.resid = x; p.M = M; p.N = 256; p.K = 27 * 256;
         p.R = R; p.Cin = 256; p.stats = stats; p.gamma = w->ln3_w; p.beta = w->ln3_b;
+        p.zero_off = (uint32_t)(zero_row - (char *)xn);
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 4, 256>), dim3((M + 255) / 256, 2), dim3(256), 0, s, p);
     }
     L2D_CHECK_LAUNCH();

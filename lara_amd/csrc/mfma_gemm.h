@@ -72,6 +72,7 @@ struct GemmP {
     const float2 *stats; // EPI 4: per-row (mean, rstd) of resid
     const float *gamma, *beta;
     int Cout;            // EPI 5
+    uint32_t zero_off;   // AMODE 1: byte offset from A of a zeroed row of Cin bf16 (the padding voxels)
 };
 
 // 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_exp / v_rcp
@@ -120,25 +121,29 @@ gemm_bf16_nt_kernel(const GemmP p) {
     // those start 0, 64, 128, 192 bytes into the 256-byte bank row (rows 0..3 would wrap onto each other)
     const int sq = tid >> 2, schunk = tid & 3;
     const int srow = (sq & ~15) | ((sq & 3) << 2) | ((sq >> 2) & 3);
-    const unsigned short *gsrc[NS];
+    // global addresses are a uniform base + a 32-bit byte offset per thread (operands are < 4 GB): one
+    // v_add per load in the main loop instead of 64-bit pointer arithmetic
+    const char *Ab = (const char *)A, *Wb = (const char *)W;
+    uint32_t goff[NS];
     int loff[NS];
     int vb[NA], vd[NA], vh[NA], vw[NA];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
-        const int row = srow + 64 * i;  // 0..255: A rows then W rows
-        const unsigned short *base = row < GM ? A + (size_t)min(bm0 + row, M - 1) * (AMODE ? p.Cin : K)
-                                              : W + (size_t)min(bn0 + row - GM, N - 1) * K;
-        gsrc[i] = base + schunk * 8;
+        const int row = srow + 64 * i;  // A rows then W rows
+        goff[i] = row < GM ? (uint32_t)min(bm0 + row, M - 1) * (uint32_t)((AMODE ? p.Cin : K) * 2) + schunk * 16
+                           : (uint32_t)min(bn0 + row - GM, N - 1) * (uint32_t)(K * 2) + schunk * 16;
         loff[i] = row * LROW + schunk * 16;
         if (AMODE == 1 && i < NA) token_to_voxel(min(bm0 + row, M - 1), p.R, vb[i < NA ? i : 0], vd[i < NA ? i : 0], vh[i < NA ? i : 0], vw[i < NA ? i : 0]);
     }
-    const int ktiles = (K + GK - 1) / GK;
+    const int ktiles = K / GK;               // K is a multiple of 32 (checked by the callers)
     const int kpt = AMODE ? p.Cin / GK : 1;  // K tiles per filter tap
-    uint4 stage[NS];
-    const unsigned short *nrow[NA];
+    // (staging registers are named scalars, not an array: an indexed private array ends up in scratch)
+    uint4 st0, st1, st2, st3, st4 = make_uint4(0, 0, 0, 0), st5 = make_uint4(0, 0, 0, 0);
+    uint32_t noff[NA];
 #pragma unroll
-    for (int i = 0; i < NA; i++) nrow[i] = nullptr;
+    for (int i = 0; i < NA; i++) noff[i] = 0;
     auto gload = [&](int kt) {
+        const uint32_t kb = (uint32_t)kt * (GK * 2);
         if (AMODE == 1) {
             const int tap = kt / kpt, kc = kt - tap * kpt;
             if (kc == 0) {  // a new filter tap: resolve this thread's neighbour rows once for its kpt K tiles
@@ -147,25 +152,37 @@ gemm_bf16_nt_kernel(const GemmP p) {
                 for (int i = 0; i < NA; i++) {
                     const int nd = vd[i] + dz, nh = vh[i] + dy, nw = vw[i] + dx;
                     const bool in = (unsigned)nd < (unsigned)p.R && (unsigned)nh < (unsigned)p.R && (unsigned)nw < (unsigned)p.R;
-                    nrow[i] = in ? A + (size_t)voxel_to_token(vb[i], nd, nh, nw, p.R) * p.Cin + schunk * 8 : nullptr;
+                    // outside the volume: a row of zeros the caller keeps next to the activations (no branch)
+                    noff[i] = (in ? (uint32_t)voxel_to_token(vb[i], nd, nh, nw, p.R) * (uint32_t)(p.Cin * 2) : p.zero_off) + schunk * 16;
                 }
             }
-#pragma unroll
-            for (int i = 0; i < NA; i++)
-                stage[i] = nrow[i] ? *(const uint4 *)(nrow[i] + kc * GK) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int i = NA; i < NS; i++) stage[i] = *(const uint4 *)(gsrc[i] + (size_t)kt * GK);
+            const uint32_t kcb = (uint32_t)kc * (GK * 2);
+            static_assert(AMODE == 0 || NA == 4, "the implicit convolution is instantiated for 256-row tiles");
+            st0 = *(const uint4 *)(Ab + (noff[0] + kcb));
+            st1 = *(const uint4 *)(Ab + (noff[1] + kcb));
+            st2 = *(const uint4 *)(Ab + (noff[NA > 2 ? 2 : 0] + kcb));
+            st3 = *(const uint4 *)(Ab + (noff[NA > 3 ? 3 : 0] + kcb));
+            st4 = *(const uint4 *)(Wb + (goff[NS > 4 ? 4 : 0] + kb));
+            st5 = *(const uint4 *)(Wb + (goff[NS > 5 ? 5 : 0] + kb));
         } else {
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                const int k = kt * GK + schunk * 8;
-                stage[i] = k < K ? *(const uint4 *)(gsrc[i] + (size_t)kt * GK) : make_uint4(0, 0, 0, 0);
+            st0 = *(const uint4 *)(Ab + (goff[0] + kb));
+            st1 = *(const uint4 *)(Ab + (goff[1] + kb));
+            st2 = *(const uint4 *)((NA > 2 ? Ab : Wb) + (goff[2] + kb));
+            st3 = *(const uint4 *)((NA > 3 ? Ab : Wb) + (goff[3] + kb));
+            if (NS > 4) {
+                st4 = *(const uint4 *)(Wb + (goff[NS > 4 ? 4 : 0] + kb));
+                st5 = *(const uint4 *)(Wb + (goff[NS > 5 ? 5 : 0] + kb));
             }
         }
     };
     auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NS; i++) *(uint4 *)(&lds[buf][loff[i]]) = stage[i];
+        unsigned char *l = &lds[buf][0];
+        *(uint4 *)(l + loff[0]) = st0; *(uint4 *)(l + loff[1]) = st1;
+        *(uint4 *)(l + loff[2]) = st2; *(uint4 *)(l + loff[3]) = st3;
+        if (NS > 4) {
+            *(uint4 *)(l + loff[NS > 4 ? 4 : 0]) = st4;
+            *(uint4 *)(l + loff[NS > 5 ? 5 : 0]) = st5;
+        }
     };
 
     f32x16 acc[MI][2];
