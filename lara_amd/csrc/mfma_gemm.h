@@ -201,18 +201,25 @@ gemm_bf16_nt_kernel(const GemmP p) {
         if (kt + 1 < ktiles) gload(kt + 1);  // in flight while this tile is multiplied
         const unsigned char *la = &lds[buf][(wm + r) * LROW + kh * 16];
         const unsigned char *lb = &lds[buf][(GM + wn + r) * LROW + kh * 16];
+        // fragments of K step s+1 are fetched while the MFMAs of step s run
+        bf16x8 a[2][MI], b[2][2];
+#pragma unroll
+        for (int i = 0; i < MI; i++) a[0][i] = *(const bf16x8 *)(la + i * 32 * LROW);
+#pragma unroll
+        for (int j = 0; j < 2; j++) b[0][j] = *(const bf16x8 *)(lb + j * 32 * LROW);
 #pragma unroll
         for (int s = 0; s < GK / 16; s++) {
-            bf16x8 a[MI], b[2];
+            if (s + 1 < GK / 16) {
 #pragma unroll
-            for (int i = 0; i < MI; i++) a[i] = *(const bf16x8 *)(la + i * 32 * LROW + s * 32);
+                for (int i = 0; i < MI; i++) a[(s + 1) & 1][i] = *(const bf16x8 *)(la + i * 32 * LROW + (s + 1) * 32);
 #pragma unroll
-            for (int j = 0; j < 2; j++) b[j] = *(const bf16x8 *)(lb + j * 32 * LROW + s * 32);
+                for (int j = 0; j < 2; j++) b[(s + 1) & 1][j] = *(const bf16x8 *)(lb + j * 32 * LROW + (s + 1) * 32);
+            }
 #pragma unroll
             for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < ktiles) lstore(buf ^ 1);  // the other buffer was last read one iteration ago
         __syncthreads();
