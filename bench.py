@@ -125,6 +125,38 @@ def step(scenes, settings, gc, ga, n_streams=1):
             v.grad = None
 
 
+def forward_only_leg(scenes, settings, args):
+    """BASELINE.json configs[1] (inference): forward renders only, same scenes / views / streams."""
+    from lara_amd import GaussianRasterizer
+    cur = torch.cuda.current_stream()
+
+    def fwd():
+        with torch.no_grad():
+            for i, sc in enumerate(scenes):
+                side = _streams[i % args.streams] if args.streams > 1 and _streams else None
+                if side is not None:
+                    side.wait_stream(cur)
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    opac, scales = torch.sigmoid(sc["opacity"]), torch.exp(sc["scales"])
+                    rots = torch.nn.functional.normalize(sc["rotations"])
+                    for rs in settings:
+                        GaussianRasterizer(rs)(means3D=sc["centers"], means2D=None, shs=sc["shs"], opacities=opac,
+                                               scales=scales, rotations=rots, cov3D_precomp=None)
+            for side in _streams[:args.streams if args.streams > 1 else 0]:
+                cur.wait_stream(side)
+
+    fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = len(scenes) * len(settings) * args.steps
+    return {"value": round(frames / dt, 1), "unit": "frames/s",
+            "workload": "forward renders only (configs[1]: inference), same scenes and views"}
+
+
 def measure_roofline(scenes, settings, gc, ga, args):
     """Per-kernel HIP-event times over one step; returns (roofline dict, per-kernel table, D)."""
     from lara_amd import rasterizer
@@ -172,10 +204,29 @@ def measure_roofline(scenes, settings, gc, ga, args):
             traffic = tj["bytes_per_launch"][dom]["total"]
     except Exception:
         traffic = None
+    # what a plain device-to-device copy reaches on this box (read + write bytes / time): the achievable
+    # HBM rate to hold beside the vendor peak (SURVEY.md section 8d asks for both)
+    buf = torch.empty(2, 1 << 28, dtype=torch.uint8, device=scenes[0]["centers"].device)
+    buf[1].copy_(buf[0])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        buf[1].copy_(buf[0])
+    e1.record()
+    torch.cuda.synchronize()
+    copy_GBs = 5 * 2 * (1 << 28) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del buf
+    # the whole frame against the byte model of SURVEY.md section 8d (175 P + 120 D + 60 HW forward,
+    # 248 P + 220 D + 100 HW backward)
+    frame_bytes = (175 + 248) * P + (120 + 220) * D + 160 * HW
+    frame_us = sum(v["avg_us"] for v in table.values())
     roof = {"kernel": dom, "bound": "hbm", "achieved": round(t["alg_GBs"], 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(t["alg_GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
             "avg_launch_us": round(t["avg_us"], 2), "alg_bytes_per_launch": t["alg_bytes"],
-            "pairs_per_frame_D": D}
+            "pairs_per_frame_D": D, "measured_copy_GBs": round(copy_GBs, 1),
+            "whole_frame": {"alg_bytes": frame_bytes, "kernel_us": round(frame_us, 1),
+                            "achieved": round(frame_bytes / frame_us / 1e3, 1),
+                            "frac": round(frame_bytes / frame_us / 1e3 / HBM_PEAK_GBS, 5)}}
     return roof, table, D
 
 
@@ -370,6 +421,8 @@ def main():
         dt1 = time.perf_counter() - t1
         out["single_stream"] = {"value": round(frames_per_step * args.steps / dt1, 3), "unit": "frames/s",
                                 "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
+    if rank == 0 and world == 1 and not args.no_roofline:
+        out["forward_only"] = forward_only_leg(scenes, settings, args)
     if rank == 0 and not args.no_roofline:
         roof, table, D = measure_roofline(scenes, settings, gc, ga, args)
         out["roofline"] = roof
