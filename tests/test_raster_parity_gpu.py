@@ -150,6 +150,14 @@ def test_backward_big_splats_low_pass_and_sh3(hip_lib):
     _grad_check(act, cams[2], (1.0, 1.0, 1.0))
 
 
+def test_backward_ragged_image(hip_lib):
+    # image not a multiple of the tile size: edge tiles have pixels outside the image
+    from lara_amd import cameras
+    act, _ = small_scene(grid=12, size=150, seed=5, scale_boost=2.0)
+    cam = cameras.make_cameras(cameras.turntable_c2w(4)[1:2], 150, 90, 0.75, 0.6, 0.5, 2.5)[0]
+    _grad_check(act, cam, (0.2, 0.4, 0.6))
+
+
 def test_backward_deep_lists_cross_segment_boundaries(hip_lib):
     """The backward cuts a tile's list into 1024-entry segments that run as independent workgroups
     and resume from the forward's checkpoints: make lists several segments deep, with pixels that
