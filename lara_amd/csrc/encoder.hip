@@ -96,7 +96,7 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
         p.A = xn; p.W = w->wconv; p.C = x; p.resid = x; p.M = M; p.N = 256; p.K = 27 * 256;
         p.R = R; p.Cin = 256; p.stats = stats; p.gamma = w->ln3_w; p.beta = w->ln3_b;
         p.zero_off = (uint32_t)(zero_row - (char *)xn);
-        hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 4, 256>), dim3((M + 255) / 256, 2), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 4, 256, 128>), dim3((M + 255) / 256, 2), dim3(256), 0, s, p);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -59,7 +59,7 @@ ln_cast_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
 // group-major (2x2x2 voxel blocks, the order the attention works in), K = 27 * Cin, and K tile kt
 // reads channels [32 kc, 32 kc + 32) of the row of the voxel's (dz, dy, dx) neighbour (zeros outside
 // the volume); W is the weight re-laid as [Cout][tap][Cin], i.e. still K-contiguous.
-constexpr int GN = 128, GK = 32;
+constexpr int GK = 32;
 constexpr int LROW = GK * 2 + 16;  // padded LDS row, bytes
 
 struct GemmP {
@@ -101,10 +101,11 @@ __device__ __forceinline__ int voxel_to_token(const int b, const int d, const in
 // EPI 0: bf16 store            1: fp32 store of acc + resid        2: bf16 store of gelu(acc + bias)
 //     3: fp32 acc + bias + resid   4: fp32 LN(resid row) + acc (LN redone from stats, gamma, beta)
 //     5: fp32 acc + bias scattered as a stride-2, kernel-2 transposed convolution (N = 8 * Cout)
-template <int AMODE, int EPI, int GM = 128>
+template <int AMODE, int EPI, int GM = 128, int GN = 128>
 __global__ void __launch_bounds__(256)
 gemm_bf16_nt_kernel(const GemmP p) {
     constexpr int MI = GM / 64;         // 32-row MFMA tiles per wave along M
+    constexpr int NJ = GN / 64;         // 32-column MFMA tiles per wave along N
     constexpr int NA = GM / 64;         // staging passes that carry A rows
     constexpr int NS = (GM + GN) / 64;  // staging passes per K tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][(GM + GN) * LROW];
@@ -112,7 +113,7 @@ gemm_bf16_nt_kernel(const GemmP p) {
     const int M = p.M, N = p.N, K = p.K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bm0 = blockIdx.x * GM, bn0 = blockIdx.y * GN;
-    const int wm = (wave >> 1) * (GM / 2), wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (GM / 2), wn = (wave & 1) * (GN / 2);
     const int r = lane & 31, kh = lane >> 5;
 
     // staging map: GM + 128 rows (A rows, then W rows) x 4 sixteen-byte chunks per K tile; thread t
@@ -138,12 +139,16 @@ gemm_bf16_nt_kernel(const GemmP p) {
     const int ktiles = K / GK;               // K is a multiple of 32 (checked by the callers)
     const int kpt = AMODE ? p.Cin / GK : 1;  // K tiles per filter tap
     // (staging registers are named scalars, not an array: an indexed private array ends up in scratch)
-    uint4 st0, st1, st2, st3, st4 = make_uint4(0, 0, 0, 0), st5 = make_uint4(0, 0, 0, 0);
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    uint4 st0 = z4, st1 = z4, st2 = z4, st3 = z4, st4 = z4, st5 = z4, st6 = z4, st7 = z4;
     uint32_t noff[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) noff[i] = 0;
+    // pass i of the staging map: from A (dense row or the current tap's neighbour row) or from W
+#define L2D_GSRC(i) ((i) < NA ? (AMODE == 1 ? Ab + (noff[(i) < NA ? (i) : 0] + kcb) : Ab + (goff[i] + kb)) : Wb + (goff[i] + kb))
     auto gload = [&](int kt) {
         const uint32_t kb = (uint32_t)kt * (GK * 2);
+        uint32_t kcb = 0;
         if (AMODE == 1) {
             const int tap = kt / kpt, kc = kt - tap * kpt;
             if (kc == 0) {  // a new filter tap: resolve this thread's neighbour rows once for its kpt K tiles
@@ -156,40 +161,27 @@ gemm_bf16_nt_kernel(const GemmP p) {
                     noff[i] = (in ? (uint32_t)voxel_to_token(vb[i], nd, nh, nw, p.R) * (uint32_t)(p.Cin * 2) : p.zero_off) + schunk * 16;
                 }
             }
-            const uint32_t kcb = (uint32_t)kc * (GK * 2);
-            static_assert(AMODE == 0 || NA == 4, "the implicit convolution is instantiated for 256-row tiles");
-            st0 = *(const uint4 *)(Ab + (noff[0] + kcb));
-            st1 = *(const uint4 *)(Ab + (noff[1] + kcb));
-            st2 = *(const uint4 *)(Ab + (noff[NA > 2 ? 2 : 0] + kcb));
-            st3 = *(const uint4 *)(Ab + (noff[NA > 3 ? 3 : 0] + kcb));
-            st4 = *(const uint4 *)(Wb + (goff[NS > 4 ? 4 : 0] + kb));
-            st5 = *(const uint4 *)(Wb + (goff[NS > 5 ? 5 : 0] + kb));
-        } else {
-            st0 = *(const uint4 *)(Ab + (goff[0] + kb));
-            st1 = *(const uint4 *)(Ab + (goff[1] + kb));
-            st2 = *(const uint4 *)((NA > 2 ? Ab : Wb) + (goff[2] + kb));
-            st3 = *(const uint4 *)((NA > 3 ? Ab : Wb) + (goff[3] + kb));
-            if (NS > 4) {
-                st4 = *(const uint4 *)(Wb + (goff[NS > 4 ? 4 : 0] + kb));
-                st5 = *(const uint4 *)(Wb + (goff[NS > 5 ? 5 : 0] + kb));
-            }
+            kcb = (uint32_t)kc * (GK * 2);
         }
+        st0 = *(const uint4 *)L2D_GSRC(0); st1 = *(const uint4 *)L2D_GSRC(1);
+        st2 = *(const uint4 *)L2D_GSRC(2); st3 = *(const uint4 *)L2D_GSRC(3);
+        if (NS > 4) { st4 = *(const uint4 *)L2D_GSRC(NS > 4 ? 4 : 0); st5 = *(const uint4 *)L2D_GSRC(NS > 5 ? 5 : 0); }
+        if (NS > 6) { st6 = *(const uint4 *)L2D_GSRC(NS > 6 ? 6 : 0); st7 = *(const uint4 *)L2D_GSRC(NS > 7 ? 7 : 0); }
     };
+#undef L2D_GSRC
     auto lstore = [&](int buf) {
         unsigned char *l = &lds[buf][0];
         *(uint4 *)(l + loff[0]) = st0; *(uint4 *)(l + loff[1]) = st1;
         *(uint4 *)(l + loff[2]) = st2; *(uint4 *)(l + loff[3]) = st3;
-        if (NS > 4) {
-            *(uint4 *)(l + loff[NS > 4 ? 4 : 0]) = st4;
-            *(uint4 *)(l + loff[NS > 5 ? 5 : 0]) = st5;
-        }
+        if (NS > 4) { *(uint4 *)(l + loff[NS > 4 ? 4 : 0]) = st4; *(uint4 *)(l + loff[NS > 5 ? 5 : 0]) = st5; }
+        if (NS > 6) { *(uint4 *)(l + loff[NS > 6 ? 6 : 0]) = st6; *(uint4 *)(l + loff[NS > 7 ? 7 : 0]) = st7; }
     };
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
@@ -202,23 +194,23 @@ gemm_bf16_nt_kernel(const GemmP p) {
         const unsigned char *la = &lds[buf][(wm + r) * LROW + kh * 16];
         const unsigned char *lb = &lds[buf][(GM + wn + r) * LROW + kh * 16];
         // fragments of K step s+1 are fetched while the MFMAs of step s run
-        bf16x8 a[2][MI], b[2][2];
+        bf16x8 a[2][MI], b[2][NJ];
 #pragma unroll
         for (int i = 0; i < MI; i++) a[0][i] = *(const bf16x8 *)(la + i * 32 * LROW);
 #pragma unroll
-        for (int j = 0; j < 2; j++) b[0][j] = *(const bf16x8 *)(lb + j * 32 * LROW);
+        for (int j = 0; j < NJ; j++) b[0][j] = *(const bf16x8 *)(lb + j * 32 * LROW);
 #pragma unroll
         for (int s = 0; s < GK / 16; s++) {
             if (s + 1 < GK / 16) {
 #pragma unroll
                 for (int i = 0; i < MI; i++) a[(s + 1) & 1][i] = *(const bf16x8 *)(la + i * 32 * LROW + (s + 1) * 32);
 #pragma unroll
-                for (int j = 0; j < 2; j++) b[(s + 1) & 1][j] = *(const bf16x8 *)(lb + j * 32 * LROW + (s + 1) * 32);
+                for (int j = 0; j < NJ; j++) b[(s + 1) & 1][j] = *(const bf16x8 *)(lb + j * 32 * LROW + (s + 1) * 32);
             }
 #pragma unroll
             for (int i = 0; i < MI; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < NJ; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < ktiles) lstore(buf ^ 1);  // the other buffer was last read one iteration ago
@@ -230,13 +222,14 @@ gemm_bf16_nt_kernel(const GemmP p) {
     float *ep = (float *)&lds[0][0] + wave * (32 * 68);  // 32 rows x (64 + 4 pad) floats per wave
     unsigned long long *rowbase = (unsigned long long *)((float *)&lds[0][0] + 4 * (32 * 68)) + wave * 32;  // EPI 5
 #pragma unroll
-    for (int i = 0; i < MI; i++) {
+    for (int ij = 0; ij < MI * (NJ / 2); ij++) {
+        const int i = ij / (NJ / 2), jh = ij % (NJ / 2);  // 32 rows x 64 columns of the wave tile per trip
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++)
-                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][j][e];
+                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][2 * jh + j][e];
         if (EPI == 5 && lane < 32) {  // output offset of the voxel (2d, 2h, 2w) of each of the wave's 32 rows
             int b, d, h, w;
             token_to_voxel(min(bm0 + wm + i * 32 + lane, M - 1), p.R, b, d, h, w);
@@ -247,7 +240,7 @@ gemm_bf16_nt_kernel(const GemmP p) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
-            const int row = bm0 + wm + i * 32 + lr, col = bn0 + wn + c4;
+            const int row = bm0 + wm + i * 32 + lr, col = bn0 + wn + jh * 64 + c4;
             if (row < M && col < N) {
                 float4 v = *(const float4 *)(ep + lr * 68 + c4);
                 const size_t o = (size_t)row * N + col;
