@@ -441,9 +441,9 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 // Versus reducing per entry across the wave inside the traversal (one candidate stream per wave, a
 // 55-instruction butterfly and a 64-lane gradient evaluation for 11 useful lanes) this needs half
 // the wave instructions, and it keeps the backward free of floating-point atomics.
-constexpr int SLAB_WIN = 256;     // list entries staged per window (one per thread)
+constexpr int SLAB_WIN = 128;     // list entries staged per window (one per thread)
 constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
-constexpr int SLAB_POOL = 512;    // (entry, 2x2 block) slots per round
+constexpr int SLAB_POOL = 384;    // (entry, 2x2 block) slots per round
 constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padded to 96 bytes (48 KB in all)
 
 __global__ void __launch_bounds__(256)
@@ -462,6 +462,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __shared__ uint32_t s_id[WIN];
     __shared__ uint32_t s_maxc;
     __shared__ int s_nfit;
+    __shared__ uint32_t s_total;
     if (header[1]) return;
     const unsigned long long dbg_t0 = (v.dbg & 32u) ? wall_clock64() : 0ull;
     int dbg_rounds = 0;
@@ -556,6 +557,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     uint32_t id1 = total - 1 - tid >= lo ? point_list[range.x + total - 1 - tid] : 0u;
     uint32_t id2 = total - WIN - 1 - tid >= lo ? point_list[range.x + total - WIN - 1 - tid] : 0u;
     float4 cb1 = total - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int dirty = SLAB_POOL;  // pool slots that may hold data (all of them before the first round)
     for (int whi = total; whi > lo; whi -= WIN) {
         const int wcnt = min(WIN, whi - lo);
         const uint32_t id0 = id1;
@@ -565,7 +567,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         cb1 = whi - WIN - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();  // the previous window's last round is done with rec / s_id
         DBG_PHASE(whi == total ? 0 : 4);
-        (void)stage_entry<WIN>(geom, id0, cb0, tid < wcnt, X0, Y0, rec, s_id);
+        if (tid < WIN) (void)stage_entry<WIN>(geom, id0, cb0, tid < wcnt, X0, Y0, rec, s_id);
 
         // Slab rounds over the window.  An entry's slab has four slots (the 2x2 pixels) per candidate
         // block of its mask, in mask-bit order: slot = base + 4 * rank(block) + pixel-in-block with
@@ -599,13 +601,16 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 if (lane == 0) s_nfit = L == 64 ? 128 : 2 * L + (int)((f0 >> L) & 1ull);
                 s_base[2 * lane] = b0;
                 s_base[2 * lane + 1] = b1;
-            } else {  // the other three waves clear the pool: a block no quad visits must read as zeros
+                if (lane == 63) s_total = incl;
+            } else {  // the other three waves clear what the previous round used of the pool: a block no
+                      // quad visits must read as zeros
                 float4 *pw = (float4 *)pool;
-                for (int i = tid - 64; i < SLAB_POOL * SLAB_F / 4; i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = tid - 64; i < dirty * (SLAB_F / 4); i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
             DBG_PHASE(2);
             const int nfit = s_nfit;
+            dirty = nfit < SLAB_CHUNK ? (int)s_base[nfit] : min((int)s_total, SLAB_POOL);
 
             // ---- phase P: every quad walks its own candidates over the whole round, last list position
             //      first (window slots ascend as list positions descend)
