@@ -297,6 +297,31 @@ def encoder_leg(device, scenes):
             "conv3d_us": round(conv_us, 1), "conv3d_TFLOPs": round(2 * M * 27 * 256 * 256 / conv_us / 1e6, 1)}
 
 
+def rays_leg(device, scenes, views, res):
+    """Device-side generation of the step's tar_rays + tar_rays_down (dataLoader/utils.py:21-34):
+    a pure store stream, priced against the HBM peak."""
+    from lara_amd import cameras
+    from lara_amd.batch import build_rays, fov_to_ixt
+    c2w = cameras.turntable_c2w(views).float().to(device)
+    ixt = fov_to_ixt(torch.full((views, 2), 0.75), (res, res)).to(device)
+    from lara_amd import rasterizer
+    for _ in range(2):
+        build_rays(c2w, ixt, res, res)
+    torch.cuda.synchronize()
+    rasterizer.profile_enable(True)
+    for _ in range(scenes * 5):
+        build_rays(c2w, ixt, res, res)
+        build_rays(c2w, ixt, res, res, 1.0 / 16)
+    torch.cuda.synchronize()
+    rec = rasterizer.profile_collect()
+    rasterizer.profile_enable(False)
+    us = 1e3 * sum(t for k, t in rec if k == "build_rays") / 5  # kernel time (HIP events on the launch stream)
+    nbytes = scenes * views * 24 * (res * res + (res // 16) ** 2)
+    return {"workload": f"tar_rays + tar_rays_down of {scenes} scenes x {views} views @{res}x{res}, written on the device",
+            "us_per_step": round(us, 1), "achieved": round(nbytes / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "bound": "hbm"}
+
+
 def cpu_baseline(args):
     """The CPU oracle (fp32 restatement, OpenMP over tiles) on a bounded sample of the same
     workload: the 8 views of scene 0, forward + backward each (about 10-30 s of CPU work)."""
@@ -431,6 +456,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         out["attention"] = attention_leg(device, args.scenes)
         out["encoder"] = encoder_leg(device, args.scenes)
+        out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
