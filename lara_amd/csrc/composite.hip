@@ -426,7 +426,7 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 // Quad-SIMT reverse traversal + two-level, atomic-free reduction.
 //
 // One workgroup per (tile, 1024-entry segment of its list); pixels whose walk began above the segment
-// resume from the forward's checkpoint (see the prologue).  A window of 256 entries is staged at a
+// resume from the forward's checkpoint (see the prologue).  A window of 128 entries is staged at a
 // time; inside it, rounds of up to 128 entries:
 //   phase P  (lane = pixel, each DPP quad walks its own candidate list back to front) runs the
 //            per-pixel recurrences of the reference's backward (T, the collapsed accum_rec
@@ -435,7 +435,7 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float x) {
 //            the LDS slot of its (entry, block): plain ds_write, one writer per slot.  An entry's
 //            slab has one slot per candidate block of its mask (slot = base + popcount(mask below
 //            the block)); a 64-lane scan over the round hands out the bases, and a round takes as
-//            many entries as fit the 512-slot pool.
+//            many entries as fit the 384-slot pool.
 //   phase S2 (two lanes per entry) adds the entry's block slots, maps the sums back through
 //            A = k0 x l0, B = Tw x l0, C = k0 x Tw and writes the 80-byte gradient row.
 // Versus reducing per entry across the wave inside the traversal (one candidate stream per wave, a
