@@ -77,9 +77,11 @@ conv3d_ring_kernel(const GemmP p) {
         noff[q] = chunk * 16;
     }
     const int ktiles = K / 32, kpt = Cin / 32;
+    int cur_tap = -1;
     auto issue = [&](const int kt) {  // this wave's four pieces of K tile kt
         const int tap = kt / kpt, kc = kt - tap * kpt;
-        if (kc == 0) {
+        if (tap != cur_tap) {
+            cur_tap = tap;
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -138,19 +140,19 @@ conv3d_ring_kernel(const GemmP p) {
         const unsigned char *buf = ring + (kt % RING) * RTILE;
         bf16x8 a[2][4], b[2][2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
+        for (int s2 = 0; s2 < 2; s2++) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[s][i] = *(const bf16x8 *)(buf + aoff[i][s]);
+            for (int i = 0; i < 4; i++) a[s2][i] = *(const bf16x8 *)(buf + aoff[i][s2]);
 #pragma unroll
-            for (int j = 0; j < 2; j++) b[s][j] = *(const bf16x8 *)(buf + boff[j][s]);
+            for (int j = 0; j < 2; j++) b[s2][j] = *(const bf16x8 *)(buf + boff[j][s2]);
         }
 #pragma unroll
-        for (int s = 0; s < 2; s++)
+        for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2][i], b[s2][j], acc[i][j], 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads done before the next barrier
     }
     __syncthreads();
