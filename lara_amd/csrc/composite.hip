@@ -6,27 +6,31 @@
 // (colour = C + T*bg; allmap = [sum w*depth, 1-T, sum w*normal (view space), median depth,
 // distortion]).
 //
-// Structure (both directions).  One 256-thread workgroup per 16x16 tile (the binning contract),
-// four wave64s = four 8x8 quadrants.  Inside a wave every group of 4 lanes (a DPP quad) owns a
-// 2x2 pixel block and walks ITS OWN candidate list ("quad-SIMT"): at LaRa's statistics a surfel
-// reaches alpha >= 1/255 on ~14 pixels of a tile, so with one candidate stream per wave only 11 of
-// 64 lanes did useful work; per-quad streams need 2.5x fewer wave iterations.
-// A tile's list is consumed 256 entries at a time in two phases:
+// Structure (both directions).  256-thread workgroups over 16x16 tiles (the binning contract): one per
+// tile in the forward, one per (tile, 1024-entry segment of its list) in the backward.  Four wave64s
+// = four 8x8 quadrants.  Inside a wave every group of 4 lanes (a DPP quad) owns a 2x2 pixel block
+// and walks ITS OWN candidate list ("quad-SIMT"): at LaRa's statistics a surfel reaches
+// alpha >= 1/255 on ~14 pixels of a tile, so with one candidate stream per wave only 11 of 64 lanes
+// did useful work.
+// A list is consumed in rounds (512 entries forward, windows of 128 backward) in two phases:
 //   phase S  (thread = list entry)  gather the surfel record through the sorted id list, turn it
 //            into TILE-RELATIVE coefficients -- the ray/surfel intersection p = k x l is affine in
 //            the pixel offset: p(lx,ly) = A + lx*B + ly*C with A = k0 x l0, B = Tw x l0,
-//            C = k0 x Tw, k0/l0 = the reference's k/l at the tile origin -- and rasterise the
-//            surfel's conservative alpha>=1/255 box onto the tile's 8x8 grid of 2x2 blocks (64-bit
-//            mask).  Costs 1/64 of a wave-instruction per entry.
+//            C = k0 x Tw, k0/l0 = the reference's k/l at the tile origin -- and scan-convert
+//            {alpha >= 1/255} (a conic per pixel row, plus the low-pass disc) onto the tile's 8x8
+//            grid of 2x2 blocks (64-bit mask).
 //   phase P  (lane = pixel)  per 64 entries each wave transposes the (entry x block) bit matrix
-//            with 16 ballots, every quad keeps the mask of its block and walks only its set bits;
-//            records are read from LDS with per-quad addresses.  Skipping is exact: an entry is
-//            skipped for a block only if the reference would have skipped it for all 4 pixels
-//            (alpha < 1/255), and list positions (`contributor` numbering) are kept.
-// Backward adds: the 22 per-pixel partial derivatives of an entry (coefficient space) are reduced
-// over the quad with a 2-step DPP reduce-scatter, accumulated per tile in LDS (ds_add_f32),
-// transformed to dL/dT etc. by the entry's own thread (phase S2) and only then added to HBM: one
-// atomic per (tile, surfel, component) instead of one per (pixel, surfel, component).
+//            with 16 ballots, every quad keeps the words of its block and walks only its set bits
+//            over the whole round; records are read from LDS with per-quad addresses.  Skipping is
+//            conservative-exact: an entry is skipped for a block only if the reference would have
+//            skipped it for all 4 pixels (alpha < 1/255), and list positions (`contributor`
+//            numbering) are kept.
+// Backward adds: the 22 per-pixel partial derivatives of an entry (coefficient space) are summed
+// over the quad with a 2-step DPP reduce-scatter and parked in the LDS slot of the (entry, block)
+// pair -- one writer per slot, no atomics --, a second phase (two lanes per entry) adds an entry's
+// slots, maps the sums to dL/dT etc. and writes ONE gradient row per (tile, surfel) pair;
+// preprocess_bwd gathers a surfel's rows.  The reference issues one atomic per (pixel, surfel,
+// component).
 #include "common.h"
 
 namespace {
