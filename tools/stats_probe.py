@@ -1,5 +1,7 @@
+"""Walk statistics of composite_fwd (LARA2DGS_DEBUG_FLAGS=4): quad candidates, valid (pixel, entry) pairs,
+wave iterations, tile list lengths.  Run on the GPU box:  LARA2DGS_DEBUG_FLAGS=4 python tools/stats_probe.py"""
 import sys, math, os
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lara_amd import cameras, synthetic, rasterizer, GaussianRasterizationSettings
 dev=torch.device('cuda:0')

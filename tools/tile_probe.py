@@ -1,3 +1,5 @@
+"""Per-wave cycle counts of composite_fwd (LARA2DGS_DEBUG_FLAGS=32): heaviest wave vs aggregate work.
+Run on the GPU box:  LARA2DGS_DEBUG_FLAGS=32 python tools/tile_probe.py"""
 import sys, math, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
