@@ -14,10 +14,13 @@
 //                    to a tile: S^T = K Q^T puts a query's four scores into the four accumulator
 //                    registers of one lane (softmax needs no cross-lane traffic), and those registers
 //                    ARE the A-operand fragment of the following P.V product.
+#include <cstdlib>
+
 #include "mfma_gemm.h"
 #include "../../include/lara_groupattn.h"
 
 namespace {
+
 
 // ---- per-group softmax attention on 16x16x16 bf16 MFMA ---------------------------------------------
 // One wave per unit of 4 groups (32 query tokens, 16 key/value tokens); Q [G*8,256], KV [G*4,512]
@@ -148,7 +151,9 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
         L2D_PROF("ga_gemm_kv", s);
         GemmP p{};
         p.A = cond_bf16; p.W = wkv; p.C = kv; p.M = Mkv; p.N = 512; p.K = cond_dim;
-        hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 0>), dim3((Mkv + 127) / 128, 4), dim3(256), 0, s, p);
+        // K = cond_dim = 800: deep enough for the LDS-DMA ring (102 -> 77 us); the K = 256 / 512 GEMMs of
+        // the block are bound by their fp32 residual streams and ran no faster on it
+        if (launch_gemm_ring<0, 0>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     }
     L2D_CHECK_LAUNCH();
     {

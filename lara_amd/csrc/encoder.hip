@@ -31,162 +31,6 @@ tokens_volume_kernel(const int R, const int C, const float *__restrict__ src, fl
     else dst[v] = src[i];
 }
 
-// ---- 3x3x3 convolution, 256 x 256 tile, LDS-DMA ring -------------------------------------------------
-// C[M,256] = LN3(x) + sum over 27 taps of A_tap[M,256] . W_tap[256,256]^T, as in mfma_gemm.h (AMODE 1,
-// EPI 4), restructured around what limited that kernel: register staging put as
-// many LDS cycles into ds_write_b128 (13 cycles per wave instruction) as into fragment reads, and kept
-// the operand re-reads through L2 at two passes over A.  Here
-//   * the whole N = 256 sits in one workgroup (8 waves as 2 x 4, wave tile 128 x 64), so the gathered
-//     operand is fetched once per tap;
-//   * K tiles (32 channels of one tap: A 256 rows x 64 B, W 256 rows x 64 B = 32 KB) travel global ->
-//     LDS with global_load_lds_dwordx4: no staging registers, no ds_write; every wave issues 4 of the 32
-//     one-KB pieces of a tile;
-//   * a ring of four tile buffers keeps three tiles in flight: iteration kt waits for its own four
-//     pieces of tile kt with a COUNTED vmcnt (8 younger pieces stay in flight), one barrier makes
-//     everybody's pieces visible and retires the reads of tile kt-1, whose buffer is then refilled
-//     with tile kt+3;
-//   * LDS rows are 64 B, unpadded (the DMA writes lane-linear); the 16-byte chunk index is XORed with
-//     (row >> 2) & 3 on the SOURCE address and on the fragment reads, which spreads the rows a
-//     ds_read_b128 lane group touches over all four chunk slots.
-constexpr int RT = 256;             // tile rows (M) and columns (N)
-constexpr int RING = 4;             // tile buffers
-constexpr int RTILE = 2 * RT * 64;  // bytes per K tile: A panel + W panel
-
-__global__ void __launch_bounds__(512)
-conv3d_ring_kernel(const GemmP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // RING * RTILE bytes
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int M = p.M, K = p.K, Cin = p.Cin;
-    const int bm0 = blockIdx.x * RT;
-    const int wr = wave >> 2, wc = wave & 3;  // wave tile: rows wr*128.., columns wc*64..
-    const int r = lane & 31, kh = lane >> 5;
-    const char *Ab = (const char *)p.A, *Wb = (const char *)p.W;
-
-    // staging: wave w moves pieces {2w, 2w+1} of the A panel and of the W panel; piece i = rows 16 i ..
-    // 16 i + 15, lane L lands in row 16 i + L/4, physical chunk L & 3, and must therefore FETCH the
-    // logical chunk (L & 3) ^ ((row >> 2) & 3)
-    int srow[2];
-    uint32_t woff[2], noff[2];
-    int vb[2], vd[2], vh[2], vw[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        srow[q] = 32 * wave + 16 * q + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((srow[q] >> 2) & 3);
-        woff[q] = (uint32_t)srow[q] * (uint32_t)(K * 2) + chunk * 16;  // N = 256 rows of W exactly
-        token_to_voxel(min(bm0 + srow[q], M - 1), p.R, vb[q], vd[q], vh[q], vw[q]);
-        noff[q] = chunk * 16;
-    }
-    const int ktiles = K / 32, kpt = Cin / 32;
-    int cur_tap = -1;
-    auto issue = [&](const int kt) {  // this wave's four pieces of K tile kt
-        const int tap = kt / kpt, kc = kt - tap * kpt;
-        if (tap != cur_tap) {
-            cur_tap = tap;
-            const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int nd = vd[q] + dz, nh = vh[q] + dy, nw = vw[q] + dx;
-                const bool in = (unsigned)nd < (unsigned)p.R && (unsigned)nh < (unsigned)p.R && (unsigned)nw < (unsigned)p.R;
-                const int chunk = (lane & 3) ^ ((srow[q] >> 2) & 3);
-                noff[q] = (in ? (uint32_t)voxel_to_token(vb[q], nd, nh, nw, p.R) * (uint32_t)(Cin * 2) : p.zero_off) + chunk * 16;
-            }
-        }
-        unsigned char *buf = ring + (kt % RING) * RTILE;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ab + (noff[q] + (uint32_t)kc * 64)),
-                                             (__attribute__((address_space(3))) void *)(buf + (2 * wave + q) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Wb + (woff[q] + (uint32_t)kt * 64)),
-                                             (__attribute__((address_space(3))) void *)(buf + RT * 64 + (2 * wave + q) * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-    // fragment addresses inside a tile buffer (row * 64 + swizzled chunk * 16), for K steps 0 and 1
-    int aoff[4][2], boff[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = wr * 128 + 32 * i + r;
-            aoff[i][s] = row * 64 + (((2 * s + kh) ^ ((row >> 2) & 3)) << 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int row = wc * 64 + 32 * j + r;
-            boff[j][s] = RT * 64 + row * 64 + (((2 * s + kh) ^ ((row >> 2) & 3)) << 4);
-        }
-    }
-
-    issue(0);
-    if (1 < ktiles) issue(1);
-    if (2 < ktiles) issue(2);
-    for (int kt = 0; kt < ktiles; kt++) {
-        // my four pieces of tile kt have landed once at most the pieces of the tiles issued after it
-        // (two tiles = 8 pieces, fewer at the tail) are still in flight
-        const int younger = min(ktiles - 1 - kt, 2);
-        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // all pieces of tile kt visible; all reads of tile kt-1 retired
-        if (kt + 3 < ktiles) issue(kt + 3);
-        const unsigned char *buf = ring + (kt % RING) * RTILE;
-        bf16x8 a[2][4], b[2][2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[s2][i] = *(const bf16x8 *)(buf + aoff[i][s2]);
-#pragma unroll
-            for (int j = 0; j < 2; j++) b[s2][j] = *(const bf16x8 *)(buf + boff[j][s2]);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2][i], b[s2][j], acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads done before the next barrier
-    }
-    __syncthreads();
-
-    // epilogue: out = LN3(x)[row] (redone in fp32 from the row statistics) + acc, through LDS so that
-    // the loads of x and the stores are 16 bytes per lane
-    float *ep = (float *)ring + wave * (32 * 68);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][j][e];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
-            const int row = bm0 + wr * 128 + i * 32 + lr, col = wc * 64 + c4;
-            if (row < M) {
-                const float4 v = *(const float4 *)(ep + lr * 68 + c4);
-                const size_t o = (size_t)row * 256 + col;
-                const float4 rs = *(const float4 *)(p.resid + o);
-                const float2 st = p.stats[row];
-                const float4 ga = *(const float4 *)(p.gamma + col), be = *(const float4 *)(p.beta + col);
-                *(float4 *)((float *)p.C + o) =
-                    make_float4(v.x + (rs.x - st.x) * st.y * ga.x + be.x, v.y + (rs.y - st.x) * st.y * ga.y + be.y,
-                                v.z + (rs.z - st.x) * st.y * ga.z + be.z, v.w + (rs.w - st.x) * st.y * ga.w + be.w);
-            }
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" {
@@ -254,15 +98,7 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
         p.A = xn; p.W = w->wconv; p.C = x; p.resid = x; p.M = M; p.N = 256; p.K = 27 * 256;
         p.R = R; p.Cin = 256; p.stats = stats; p.gamma = w->ln3_w; p.beta = w->ln3_b;
         p.zero_off = (uint32_t)(zero_row - (char *)xn);
-        static const int ring_conv = getenv("LARA_CONV_RING") ? atoi(getenv("LARA_CONV_RING")) : 1;
-        if (ring_conv) {
-            static const hipError_t attr = hipFuncSetAttribute((const void *)conv3d_ring_kernel,
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, RING * RTILE);
-            if (attr != hipSuccess) return LARA2DGS_E_LAUNCH;
-            hipLaunchKernelGGL(conv3d_ring_kernel, dim3((M + 255) / 256), dim3(512), RING * RTILE, s, p);
-        } else {
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 4, 256, 128>), dim3((M + 255) / 256, 2), dim3(256), 0, s, p);
-        }
+        if (launch_gemm_ring<1, 4>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
