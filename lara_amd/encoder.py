@@ -205,7 +205,24 @@ class VolTransformer(nn.Module):
             m.deconv_b.copy_(vt.deconv.bias)
         return m
 
-    def forward(self, image_feats: torch.Tensor) -> torch.Tensor:
+    def _run(self, cond: torch.Tensor, x: torch.Tensor, out: torch.Tensor, B: int) -> None:
+        """The 12 blocks + tail on the current stream: x <- pos tokens; x <- block(x, cond) ...; out <- tail(x)."""
+        R, dev = self.vol_low_res, cond.device
+        x.view(B, -1, self.embed_dim).copy_(self._pos_tokens)  # network.py:152: the same positional volume per scene
+        for layer in self.layers:
+            layer.forward_tokens(x, cond, B, R)
+        with torch.cuda.device(dev):
+            rc = _lib().lara_voltrans_head_forward(B, R, x.data_ptr(), self.norm_w.data_ptr(), self.norm_b.data_ptr(),
+                                                   float(self.eps), self.wdeconv.data_ptr(), self.deconv_b.data_ptr(),
+                                                   self.out_dim, out.data_ptr(), self._ws.data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream)
+        _check(rc, "lara_voltrans_head_forward")
+
+    def forward(self, image_feats: torch.Tensor, use_graph: bool = False) -> torch.Tensor:
+        """``use_graph``: replay the ~125 launches of a forward as ONE HIP graph (captured on first use per
+        batch size; weights and buffers must stay where they are; the result is a fresh tensor).  Off by
+        default: the launches are long enough (30-450 us) that the host stays ahead of the GPU anyway --
+        measured 12.6 ms (launches) vs 12.7 ms (graph) at 4 scenes, 4.35 vs 4.50 ms at one."""
         _require_device(image_feats)
         B, R = image_feats.shape[0], self.vol_low_res
         dev = image_feats.device
@@ -213,18 +230,35 @@ class VolTransformer(nn.Module):
         if self._pos_tokens is None or self._pos_tokens.device != dev:
             with torch.no_grad():
                 self._pos_tokens = volume_to_tokens(self.pos_embed.detach().to(dev))
-        x = self._pos_tokens.repeat(B, 1)  # network.py:152: the same positional volume for every scene
-        for layer in self.layers:
-            layer.forward_tokens(x, cond, B, R)
-        lib = _lib()
         need = B * R ** 3 * 512
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        out = torch.empty(B, 2 * R, 2 * R, 2 * R, self.out_dim, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            rc = lib.lara_voltrans_head_forward(B, R, x.data_ptr(), self.norm_w.data_ptr(), self.norm_b.data_ptr(),
-                                                float(self.eps), self.wdeconv.data_ptr(), self.deconv_b.data_ptr(),
-                                                self.out_dim, out.data_ptr(), self._ws.data_ptr(),
-                                                torch.cuda.current_stream(dev).cuda_stream)
-        _check(rc, "lara_voltrans_head_forward")
-        return out
+            self._graphs = {}
+        if not use_graph:
+            x = torch.empty(B * R ** 3, self.embed_dim, dtype=torch.float32, device=dev)
+            out = torch.empty(B, 2 * R, 2 * R, 2 * R, self.out_dim, dtype=torch.float32, device=dev)
+            self._run(cond, x, out, B)
+            return out
+        key = (B, dev.index)
+        entry = getattr(self, "_graphs", {}).get(key)
+        if entry is None:
+            s_cond = torch.empty_like(cond)
+            s_x = torch.empty(B * R ** 3, self.embed_dim, dtype=torch.float32, device=dev)
+            s_out = torch.empty(B, 2 * R, 2 * R, 2 * R, self.out_dim, dtype=torch.float32, device=dev)
+            s_cond.copy_(cond)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up outside capture: workspaces, function attributes, lazy init
+                self._run(s_cond, s_x, s_out, B)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._run(s_cond, s_x, s_out, B)
+            entry = (graph, s_cond, s_x, s_out)
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            self._graphs[key] = entry
+        graph, s_cond, s_x, s_out = entry
+        s_cond.copy_(cond)
+        graph.replay()
+        return s_out.clone()

@@ -21,13 +21,19 @@ with torch.no_grad():  # random-init weights of the reference's shapes (no check
 B, M = a.scenes, a.scenes * 32 ** 3
 feats = torch.randn(B, 4, 800, 16, 16, 16, device=dev)
 with torch.no_grad():
-    vt(feats); torch.cuda.synchronize()
-    rasterizer.profile_enable(True)
-    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(a.reps): vt(feats)
-    t1.record(); torch.cuda.synchronize()
-rec = rasterizer.profile_collect(); rasterizer.profile_enable(False)
+    vt(feats, use_graph=False); torch.cuda.synchronize()
+    rasterizer.profile_enable(True)   # per-kernel HIP events need plain launches
+    for _ in range(a.reps): vt(feats, use_graph=False)
+    torch.cuda.synchronize()
+    rec = rasterizer.profile_collect(); rasterizer.profile_enable(False)
+    walls = {}
+    for mode in (False, True):        # wall time per forward: plain launches vs one HIP graph replay
+        vt(feats, use_graph=mode); torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(a.reps): vt(feats, use_graph=mode)
+        t1.record(); torch.cuda.synchronize()
+        walls[mode] = t0.elapsed_time(t1) / a.reps
 agg = {}
 for k, ms in rec:
     t = agg.setdefault(k, [0, 0.0]); t[0] += 1; t[1] += ms
@@ -40,6 +46,6 @@ for k, (n, t) in agg.items():
     us = 1e3 * t / n; per_fwd = n / a.reps
     tot_t += us * per_fwd; tot_f += fl.get(k, 0) * per_fwd
     print(f"{k:12s} {us:9.1f} us x{per_fwd:4.0f}/fwd  {fl.get(k, 0) / us / 1e6:8.1f} TFLOP/s")
-wall = t0.elapsed_time(t1) / a.reps
-print(f"VolTransformer forward, {B} scenes, {a.layers} layers: kernels {tot_t / 1e3:.2f} ms, wall {wall:.2f} ms, "
+print(f"VolTransformer forward, {B} scenes, {a.layers} layers: kernels {tot_t / 1e3:.2f} ms, wall {walls[False]:.2f} ms "
+      f"(launches) / {walls[True]:.2f} ms (HIP graph), "
       f"{tot_f / tot_t / 1e6:.1f} TFLOP/s over kernel time ({tot_f / tot_t / 1e6 / 2500 * 100:.1f} % of the 2.5 PF dense bf16 MFMA peak)")
