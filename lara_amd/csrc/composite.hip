@@ -420,10 +420,6 @@ __device__ __forceinline__ void quad_reduce_scatter(const float g[22], float r[6
     r[5] = v1[10] + dpp_full<0x4E>(v1[10]);
 }
 
-__device__ __forceinline__ void atomic_add_f32(float *p, float x) {
-    __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------

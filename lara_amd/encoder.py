@@ -189,6 +189,7 @@ class VolTransformer(nn.Module):
         self.deconv_b = nn.Parameter(torch.zeros(out_dim))
         self._pos_tokens = None
         self._ws = None
+        self._graphs = {}
 
     @classmethod
     def from_reference(cls, vt) -> "VolTransformer":
@@ -240,7 +241,7 @@ class VolTransformer(nn.Module):
             self._run(cond, x, out, B)
             return out
         key = (B, dev.index)
-        entry = getattr(self, "_graphs", {}).get(key)
+        entry = self._graphs.get(key)
         if entry is None:
             s_cond = torch.empty_like(cond)
             s_x = torch.empty(B * R ** 3, self.embed_dim, dtype=torch.float32, device=dev)
@@ -255,8 +256,6 @@ class VolTransformer(nn.Module):
             with torch.cuda.graph(graph):
                 self._run(s_cond, s_x, s_out, B)
             entry = (graph, s_cond, s_x, s_out)
-            if not hasattr(self, "_graphs"):
-                self._graphs = {}
             self._graphs[key] = entry
         graph, s_cond, s_x, s_out = entry
         s_cond.copy_(cond)
