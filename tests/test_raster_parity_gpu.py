@@ -152,6 +152,28 @@ def test_backward_big_splats_low_pass_and_sh3(hip_lib):
     _grad_check(act, cams[2], (1.0, 1.0, 1.0))
 
 
+def test_backward_is_bit_reproducible(hip_lib):
+    """No floating-point atomics anywhere in the backward: two runs give identical bits (the slot
+    reservation of the binning uses integer atomics, but the per-tile sort fixes the list order, and every
+    gradient row has exactly one writer and is summed in a fixed order)."""
+    from lara_amd import GaussianRasterizer
+    act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)  # multi-segment lists
+    rs = raster_settings(cams[1], (1.0, 1.0, 1.0), device=DEV)
+    g = torch.Generator().manual_seed(5)
+    dc, da = torch.randn(3, 64, 64, generator=g).to(DEV), (torch.randn(7, 64, 64, generator=g) * 0.1).to(DEV)
+    runs = []
+    for _ in range(3):
+        inp = {k: v.to(DEV).requires_grad_(True) for k, v in act.items()}
+        color, _, allmap = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]),
+                                                  shs=inp["shs"], opacities=inp["opacities"], scales=inp["scales"],
+                                                  rotations=inp["rotations"])
+        ((color * dc).sum() + (allmap * da).sum()).backward()
+        runs.append([color.detach().clone(), allmap.detach().clone()] + [inp[k].grad.clone() for k in sorted(inp)])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_forward_backward_1024_eval_resolution(hip_lib):
     """BASELINE.json configs[4]: 1024 x 1024 novel views (4096 tiles; splats four times the training footprint)."""
     act, cams = small_scene(grid=20, size=1024, seed=13)
