@@ -199,7 +199,7 @@ def measure_roofline(scenes, settings, gc, ga, args):
     # their own, so they are collected by tools/gpu_traffic.sh and committed under profiles/
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01f.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01g.json")))
         if args.regime == "init" and args.grid == 64 and args.res == 512:
             traffic = tj["bytes_per_launch"][dom]["total"]
     except Exception:
