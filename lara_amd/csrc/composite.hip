@@ -459,6 +459,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __shared__ float4 rec[REC4 * WIN];
     __shared__ __attribute__((aligned(16))) float pool[SLAB_POOL * SLAB_F];
     __shared__ uint32_t s_base[SLAB_CHUNK];  // first pool slot of each entry of the round
+    __shared__ unsigned long long s_live[SLAB_CHUNK];  // an entry's candidate blocks whose quad still walks it
+    __shared__ uint32_t s_ql[64];            // per 2x2 block: last contributor over its four pixels
     __shared__ uint32_t s_id[WIN];
     __shared__ uint32_t s_maxc;
     __shared__ int s_nfit;
@@ -533,6 +535,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     uint32_t quad_last = last_contributor;  // max over the 2x2 block
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0xB1, 0xf, 0xf, false));
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0x4E, 0xf, 0xf, false));
+    if ((lane & 3) == 0) s_ql[my_blk] = quad_last;  // read by wave 0 after the first window's barrier
     if (total <= lo) return;
 
     // A pixel whose walk began above this segment resumes from the forward's checkpoint at seg_hi:
@@ -578,14 +581,42 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             __syncthreads();  // window staged / previous round's phase S2 done with pool, s_base
             DBG_PHASE(s0 == 0 ? 1 : 4);
             if (wave == 0) {  // lane l sizes entries 2l and 2l+1, one 64-lane scan covers the 128
+                // A block needs a slot in an entry's slab only while its quad still walks that entry
+                // (list position below the quad's last contributor): block b is live from round entry
+                // jmin_b = whi - s0 - quad_last_b on.  Lane b drops its bit at jmin_b, an OR-scan over
+                // the entries turns that into each entry's live mask.  Where pixels saturate early
+                // (opaque surfaces) the deep entries shrink to a few slots and rounds stay full.
+                const int jm = max(whi - s0 - (int)s_ql[lane], 0);
+                unsigned long long la = ~0ull, lb = ~0ull;
+                if (__ballot(jm > 0) != 0ull) {  // (usually every block is live for the whole round: skip)
+                    // (volatile: the words are modified by OTHER lanes' atomics between this lane's store and load)
+                    volatile unsigned long long *vlive = s_live;
+                    vlive[2 * lane] = 0ull;
+                    vlive[2 * lane + 1] = 0ull;
+                    if (jm < SLAB_CHUNK) atomicOr(&s_live[jm], 1ull << lane);
+                    __builtin_amdgcn_wave_barrier();
+                    la = vlive[2 * lane];
+                    lb = la | vlive[2 * lane + 1];
+                    unsigned long long ex = lb;  // inclusive OR-scan of the pair masks over the lanes
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t ylo = __shfl_up((uint32_t)ex, d, 64), yhi = __shfl_up((uint32_t)(ex >> 32), d, 64);
+                        if (lane >= d) ex |= ((unsigned long long)yhi << 32) | ylo;
+                    }
+                    const uint32_t plo = __shfl_up((uint32_t)ex, 1, 64), phi = __shfl_up((uint32_t)(ex >> 32), 1, 64);
+                    const unsigned long long before = lane ? (((unsigned long long)phi << 32) | plo) : 0ull;
+                    la |= before; lb |= before;
+                }
                 uint32_t c[2];
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int slot = s0 + 2 * lane + q;
-                    c[q] = 0;
+                    unsigned long long mk = 0ull;
                     if (slot < wcnt)
-                        c[q] = (uint32_t)(__builtin_popcount(__float_as_uint(rec[3 * WIN + slot].w)) +
-                                          __builtin_popcount(__float_as_uint(rec[5 * WIN + slot].z)));
+                        mk = (((unsigned long long)__float_as_uint(rec[5 * WIN + slot].z) << 32) | __float_as_uint(rec[3 * WIN + slot].w)) &
+                             (q ? lb : la);
+                    s_live[2 * lane + q] = mk;
+                    c[q] = (uint32_t)__builtin_popcountll(mk);
                 }
                 uint32_t incl = c[0] + c[1];
 #pragma unroll
@@ -703,8 +734,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     // writer per slot
                     float r[6];
                     quad_reduce_scatter(g, r, lane);
-                    const uint32_t mlo = __float_as_uint(ent.r3.w), mhi = __float_as_uint(r5.z);
-                    const int rank = __builtin_popcount(mlo & below_lo) + __builtin_popcount(mhi & below_hi);
+                    const unsigned long long lv = s_live[has ? j : 0];
+                    const int rank = __builtin_popcount((uint32_t)lv & below_lo) + __builtin_popcount((uint32_t)(lv >> 32) & below_hi);
                     float *ps = pool + ((int)s_base[has ? j : 0] + rank) * SLAB_F + (lane & 3);
                     if (has) {
                         ps[0] = r[0]; ps[4] = r[1]; ps[8] = r[2]; ps[12] = r[3]; ps[16] = r[4];
@@ -720,8 +751,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 const int e = tid >> 1, part = tid & 1;
                 const int ws = min(s0 + e, WIN - 1);
                 const bool has = e < nfit && !(v.dbg & 2u);
-                const int cnt = has ? __builtin_popcount(__float_as_uint(rec[3 * WIN + ws].w)) +
-                                          __builtin_popcount(__float_as_uint(rec[5 * WIN + ws].z)) : 0;
+                const int cnt = has ? __builtin_popcountll(s_live[e]) : 0;
                 // the entry's T rows are needed at the very end: fetch them now, behind the slot loop
                 float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0, gq2 = gq0;
                 if (cnt && part == 0) {
