@@ -7,9 +7,13 @@ import torch
 from lara_amd import cameras, synthetic, rasterizer, GaussianRasterizer, GaussianRasterizationSettings
 dev = torch.device('cuda:0')
 cams = cameras.make_cameras(cameras.turntable_c2w(8), 512, 512, 0.75, 0.75, 1.106, 2.706, device=dev)
-for regime in ('init', 'trained'):
-    sc = synthetic.make_scene(grid=64, K=2, regime=regime, seed=0, device=dev)
-    act = {k: v.requires_grad_(True) for k, v in synthetic.activate(sc).items()}
+for regime in ('init', 'trained', 'fine'):  # 'fine': the opacity > 0.005 subset of the trained scene (network.py:465)
+    sc = synthetic.make_scene(grid=64, K=2, regime='trained' if regime == 'fine' else regime, seed=0, device=dev)
+    act = synthetic.activate(sc)
+    if regime == 'fine':
+        keep = act["opacities"][:, 0] > 0.005
+        act = {k: v[keep].contiguous() for k, v in act.items()}
+    act = {k: v.requires_grad_(True) for k, v in act.items()}
     gc = torch.randn(3, 512, 512, device=dev) / 512 ** 2
     ga = torch.randn(7, 512, 512, device=dev) / 512 ** 2 * 0.1
     for ci in (0, 3):
