@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LARA2DGS_ABI_VERSION 2
+#define LARA2DGS_ABI_VERSION 3
 
 #define LARA2DGS_OK 0
 #define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
@@ -81,10 +81,12 @@ typedef struct lara2dgs_state_layout {
                           * backward gather per-surfel gradients deterministically, without atomics */
     int64_t final_T;     /* float[10][H][W]: end-of-walk T, M1, M2, colour(3), depth, normal(3) sums */
     int64_t n_contrib;   /* uint32[2][H][W]: last contributor, median contributor */
-    int64_t seg_base;    /* uint32[tiles+1]: exclusive scan of floor((len-1)/1024) = interior boundaries when a
-                          * tile's list is cut into 1024-entry segments (the backward's unit of work) */
+    int64_t seg_base;    /* uint32[tiles+1]: exclusive scan of floor((len-1)/512) = interior boundaries when a
+                          * tile's list is cut into 512-entry segments (the backward's unit of work) */
+    int64_t seg_cnt;     /* uint32[tiles]: boundaries in use: the same number, or 0 for a tile whose checkpoint
+                          * rows did not fit (its backward then runs as one segment) */
     int64_t bwd_order;   /* uint32[tiles]: tile ids by length of the last (partial) segment, longest first */
-    int64_t bwd_items;   /* uint32[capacity/1024+1][2]: (tile, segment) of every full segment */
+    int64_t bwd_items;   /* uint32[capacity/512+1][2]: (tile, segment) of every full segment (tile = ~0: unused) */
     int64_t ckpt;        /* float[capacity/1024+1][10][256]: the ten per-pixel running sums as the forward walk
                           * crosses a segment boundary; lets segments of one tile run on different CUs */
     int64_t total;

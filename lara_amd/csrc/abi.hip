@@ -86,6 +86,7 @@ StateView carve_state(const ViewDev &v, void *state) {
     s.final_T = (float *)(b + L.final_T);
     s.n_contrib = (uint32_t *)(b + L.n_contrib);
     s.seg_base = (uint32_t *)(b + L.seg_base);
+    s.seg_cnt = (uint32_t *)(b + L.seg_cnt);
     s.bwd_order = (uint32_t *)(b + L.bwd_order);
     s.bwd_items = (uint2 *)(b + L.bwd_items);
     s.ckpt = (float *)(b + L.ckpt);

@@ -50,8 +50,8 @@ __global__ void __launch_bounds__(1024)
 tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ sub_start,
                  uint2 *__restrict__ ranges, uint32_t *__restrict__ header,
                  uint32_t *__restrict__ tile_order, uint32_t *__restrict__ block_tot,
-                 uint32_t *__restrict__ seg_base, uint32_t *__restrict__ bwd_order,
-                 uint2 *__restrict__ bwd_items) {
+                 uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt,
+                 uint32_t *__restrict__ bwd_order, uint2 *__restrict__ bwd_items) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s, s_max;
     __shared__ uint32_t bcnt[64];
@@ -177,10 +177,14 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         const uint32_t incl = carry_s + wave_off + x;
         if (i < v.tiles) {
             seg_base[i] = incl - nb;
+            // checkpoint rows are a fixed slab: a tile whose rows do not fit runs unsegmented
+            const bool fits = (int64_t)incl <= l2d_ckpt_slots((int64_t)v.cap);
+            const uint32_t used = fits ? nb : 0u;
+            seg_cnt[i] = used;
             if (!overflow)
-                for (uint32_t q = 0; q < nb; q++) bwd_items[incl - nb + q] = make_uint2((uint32_t)i, q);
-            const uint32_t pl = len - nb * L2D_SEG;  // 0 .. L2D_SEG
-            atomicAdd(&bcnt[63u - (pl * 64u) / (L2D_SEG + 1u)], 1u);
+                for (uint32_t q = 0; q < nb; q++) bwd_items[incl - nb + q] = make_uint2(fits ? (uint32_t)i : ~0u, q);
+            const uint32_t pl = len - used * L2D_SEG;  // length of the last segment
+            atomicAdd(&bcnt[63u - (uint32_t)(((uint64_t)min(pl, (uint32_t)L2D_SEG) * 64u) / (L2D_SEG + 1u))], 1u);
         }
         __syncthreads();
         if (tid == 1023) carry_s = incl;
@@ -201,8 +205,8 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
     for (int i = tid; i < v.tiles; i += 1024) {
         const uint2 rg = ranges[i];
         const uint32_t len = rg.y - rg.x;
-        const uint32_t pl = len - (len ? (len - 1u) / L2D_SEG : 0u) * L2D_SEG;
-        bwd_order[atomicAdd(&bcnt[63u - (pl * 64u) / (L2D_SEG + 1u)], 1u)] = (uint32_t)i;
+        const uint32_t pl = len - seg_cnt[i] * L2D_SEG;
+        bwd_order[atomicAdd(&bcnt[63u - (uint32_t)(((uint64_t)min(pl, (uint32_t)L2D_SEG) * 64u) / (L2D_SEG + 1u))], 1u)] = (uint32_t)i;
     }
     // exclusive scan (in place) of the per-surfel-block pair totals -> surfel-major pair numbering
     __syncthreads();
@@ -423,7 +427,7 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
     {
         L2D_PROF("tile_scan", s);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
-                           st.ranges, st.header, st.tile_order, sc.block_tot, st.seg_base, st.bwd_order,
+                           st.ranges, st.header, st.tile_order, sc.block_tot, st.seg_base, st.seg_cnt, st.bwd_order,
                            st.bwd_items);
     }
     L2D_CHECK_LAUNCH();

@@ -15,7 +15,7 @@
 #define L2D_SLICES 16            // per-tile counters are split 16 ways to shorten same-address atomic chains
 #define L2D_LDS_HIST_TILES 8192  // per-workgroup LDS tile histogram up to this many tiles (32 KB)
 #define GRAD_F 20          // floats per surfel in the backward accumulator (18 used)
-#define L2D_SEG 1024       // backward work unit: a tile's list is cut into segments of this many entries
+#define L2D_SEG 512       // backward work unit: a tile's list is cut into segments of this many entries
 #define L2D_CKPT_F 10      // floats per pixel in a segment-boundary checkpoint / in the per-pixel finals
 
 // Everything a kernel needs to know about the view, passed by value (lands in SGPRs / kernarg).
@@ -39,6 +39,7 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     float *final_T;       // [L2D_CKPT_F][HW] end-of-walk T, M1, M2, C(3), D, N(3)
     uint32_t *n_contrib;  // [2][HW]
     uint32_t *seg_base;   // [tiles+1] exclusive scan of interior segment boundaries per tile
+    uint32_t *seg_cnt;    // [tiles] interior boundaries actually used (0 when the checkpoint slab is full)
     uint32_t *bwd_order;  // [tiles] tile ids by length of their last (partial) segment, longest first
     uint2 *bwd_items;     // [cap/L2D_SEG+1] (tile, segment) of every full segment
     float *ckpt;          // [cap/L2D_SEG+1][L2D_CKPT_F][256] per-pixel prefix sums at segment boundaries
@@ -57,6 +58,10 @@ struct ScratchView {
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Checkpoint rows: half of the worst case cap / L2D_SEG.  Tiles whose boundaries do not fit (more pairs
+// than half the capacity: 8 per surfel by default) simply run their backward unsegmented.
+__host__ __device__ static inline int64_t l2d_ckpt_slots(int64_t cap) { return cap / (2 * L2D_SEG) + 1; }
+
 static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state_layout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const int64_t HW = (int64_t)H * W;
@@ -73,9 +78,10 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->n_contrib = o;   o = align_up(o + 2 * HW * 4, 256);
     const int64_t nseg = cap / L2D_SEG + 1;
     L->seg_base = o;    o = align_up(o + (tiles + 1) * 4, 256);
+    L->seg_cnt = o;     o = align_up(o + tiles * 4, 256);
     L->bwd_order = o;   o = align_up(o + tiles * 4, 256);
     L->bwd_items = o;   o = align_up(o + nseg * 8, 256);
-    L->ckpt = o;        o = align_up(o + nseg * L2D_CKPT_F * 256 * 4, 256);
+    L->ckpt = o;        o = align_up(o + l2d_ckpt_slots(cap) * L2D_CKPT_F * 256 * 4, 256);
     L->total = o;
 }
 

@@ -7,7 +7,7 @@
 // distortion]).
 //
 // Structure (both directions).  256-thread workgroups over 16x16 tiles (the binning contract): one per
-// tile in the forward, one per (tile, 1024-entry segment of its list) in the backward.  Four wave64s
+// tile in the forward, one per (tile, 512-entry segment of its list) in the backward.  Four wave64s
 // = four 8x8 quadrants.  Inside a wave every group of 4 lanes (a DPP quad) owns a 2x2 pixel block
 // and walks ITS OWN candidate list ("quad-SIMT"): at LaRa's statistics a surfel reaches
 // alpha >= 1/255 on ~14 pixels of a tile, so with one candidate stream per wave only 11 of 64 lanes
@@ -237,7 +237,8 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                     const uint32_t *__restrict__ seg_base, float *__restrict__ ckpt,
+                     const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
+                     float *__restrict__ ckpt,
                      float *__restrict__ out_color, float *__restrict__ out_allmap) {
     constexpr int CHUNK = FWD_CHUNK;
     static_assert(L2D_SEG % FWD_CHUNK == 0, "segment boundaries must fall on round boundaries");
@@ -291,7 +292,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     for (int base = 0; base < total; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
         dbg_rounds++;
-        if (base && base % L2D_SEG == 0 && !px.done) {
+        if (base && base % L2D_SEG == 0 && !px.done && (uint32_t)(base / L2D_SEG) <= seg_cnt[tile]) {
             // crossing a segment boundary: park the running sums over entries [0, base) so that the
             // backward can start a walk here (pixels that are done never read theirs)
             float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)(base / L2D_SEG - 1)) * (L2D_CKPT_F * 256) + tid;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void quad_reduce_scatter(const float g[22], float r[6
 // ------------------------------------------------------------------------------------------------
 // Quad-SIMT reverse traversal + two-level, atomic-free reduction.
 //
-// One workgroup per (tile, 1024-entry segment of its list); pixels whose walk began above the segment
+// One workgroup per (tile, 512-entry segment of its list); pixels whose walk began above the segment
 // resume from the forward's checkpoint (see the prologue).  A window of 128 entries is staged at a
 // time; inside it, rounds of up to 128 entries:
 //   phase P  (lane = pixel, each DPP quad walks its own candidate list back to front) runs the
@@ -451,7 +452,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-                     const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ bwd_order,
+                     const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
+                     const uint32_t *__restrict__ bwd_order,
                      const uint2 *__restrict__ bwd_items, const float *__restrict__ ckpt,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                      float4 *__restrict__ pair_grad, uint32_t *__restrict__ pair_valid) {
@@ -477,10 +479,11 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     int tile, seg;
     if (blockIdx.x < n_full) {
         const uint2 it = bwd_items[blockIdx.x];
+        if (it.x == ~0u) return;  // a segment of a tile that runs unsegmented (checkpoint slab full)
         tile = (int)it.x; seg = (int)it.y;
     } else if (blockIdx.x - n_full < (uint32_t)v.tiles) {
         tile = (int)bwd_order[blockIdx.x - n_full];
-        seg = (int)(seg_base[tile + 1] - seg_base[tile]);
+        seg = (int)seg_cnt[tile];
     } else {
         return;
     }
@@ -496,7 +499,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const float lx = (float)lxi, ly = (float)lyi;
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
     const uint2 range = ranges[tile];
-    const int seg_lo = seg * L2D_SEG, seg_hi = min(seg_lo + L2D_SEG, (int)(range.y - range.x));
+    // the last segment runs to the end of the list (all of it for a tile that is not segmented)
+    const int seg_lo = seg * L2D_SEG;
+    const int seg_hi = seg == (int)seg_cnt[tile] ? (int)(range.y - range.x) : seg_lo + L2D_SEG;
 
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
@@ -855,7 +860,7 @@ int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float
         L2D_PROF("composite_fwd", s);
         hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
-                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.ckpt,
+                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt,
                            out_color, out_allmap);
     }
     L2D_CHECK_LAUNCH();
@@ -871,7 +876,7 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
         const unsigned grid = (unsigned)v.tiles + v.cap / L2D_SEG;
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
-                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.bwd_order,
+                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.bwd_order,
                            st.bwd_items, st.ckpt, dL_dcolor, dL_dallmap, sc.pair_grad, sc.pair_valid);
     }
     L2D_CHECK_LAUNCH();

@@ -29,7 +29,7 @@ from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class _View(ctypes.Structure):
@@ -47,7 +47,7 @@ class _View(ctypes.Structure):
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "pair_base", "pair_pos", "final_T", "n_contrib",
-                 "seg_base", "bwd_order", "bwd_items", "ckpt", "total")]
+                 "seg_base", "seg_cnt", "bwd_order", "bwd_items", "ckpt", "total")]
 
 
 _lib = None
@@ -407,8 +407,9 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
         final_T=sec(L.final_T, 10 * H * W * 4, torch.float32, (10, H, W)),
         n_contrib=sec(L.n_contrib, 2 * H * W * 4, torch.int32, (2, H, W)),
         seg_base=sec(L.seg_base, (tiles + 1) * 4, torch.int32, (tiles + 1,)),
+        seg_cnt=sec(L.seg_cnt, tiles * 4, torch.int32, (tiles,)),
         bwd_order=sec(L.bwd_order, tiles * 4, torch.int32, (tiles,)),
-        bwd_items=sec(L.bwd_items, (cap // 1024 + 1) * 8, torch.int32, (cap // 1024 + 1, 2)),
+        bwd_items=sec(L.bwd_items, (cap // 512 + 1) * 8, torch.int32, (cap // 512 + 1, 2)),
     )
 
 

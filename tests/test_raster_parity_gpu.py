@@ -211,7 +211,7 @@ def test_backward_ragged_image(hip_lib):
 
 
 def test_backward_deep_lists_cross_segment_boundaries(hip_lib):
-    """The backward cuts a tile's list into 1024-entry segments that run as independent workgroups
+    """The backward cuts a tile's list into 512-entry segments that run as independent workgroups
     and resume from the forward's checkpoints: make lists several segments deep, with pixels that
     walk through all of them."""
     act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)
@@ -219,6 +219,32 @@ def test_backward_deep_lists_cross_segment_boundaries(hip_lib):
     ref = run_oracle(oracle_view(cam, bg), to_numpy(act))
     assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 3 * 1024
     assert ref.n_contrib[0].max() > 2 * 1024 + 100
+    _grad_check(act, cam, bg)
+
+
+def test_backward_when_checkpoint_rows_run_out(hip_lib, monkeypatch):
+    """Checkpoint rows are a fixed slab (capacity / 1024 + 1): with the pair capacity barely above the real
+    count, about half of the deep tiles do not get rows and must run their backward unsegmented -- same
+    gradients, and the work items of their segments are marked unused."""
+    from lara_amd import rasterizer
+    act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)
+    cam, bg = cams[1], (1.0, 1.0, 1.0)
+    ref = run_oracle(oracle_view(cam, bg), to_numpy(act))
+    cap = int(ref.num_rendered) + 64
+    monkeypatch.setattr(rasterizer, "binning_capacity", lambda P: cap)
+    r = _gpu_forward(raster_settings(cam, bg, sh_degree=1, device=DEV), act)
+    v = r["views"]
+    assert int(v["header"][1]) == 0
+    want = (np.maximum(ref.ranges[:, 1].astype(np.int64) - ref.ranges[:, 0] - 1, 0) // 512)
+    used = v["seg_cnt"].cpu().numpy()
+    base = v["seg_base"].cpu().numpy()
+    assert np.array_equal(base[:-1], np.cumsum(want) - want) and base[-1] == want.sum()
+    fits = base[:-1] + want <= cap // 1024 + 1
+    assert np.array_equal(used, np.where(fits, want, 0))
+    assert (used < want).any() and (used > 0).any(), "the case must mix segmented and unsegmented tiles"
+    items = v["bwd_items"].cpu().numpy().view(np.uint32)[: int(want.sum())]
+    assert int(v["header"][3]) == want.sum()
+    assert (items[:, 0] == 0xFFFFFFFF).sum() == want[~fits].sum()
     _grad_check(act, cam, bg)
 
 

@@ -37,8 +37,8 @@ for regime in ('init', 'trained', 'fine'):  # 'fine': the opacity > 0.005 subset
         if blk < nfull:
             tile, seg = [int(x) for x in v["bwd_items"][blk].cpu()]
         else:
-            tile = int(v["bwd_order"][blk - nfull]); seg = int(v["seg_base"][tile + 1] - v["seg_base"][tile])
-        rg = v["ranges"][tile].cpu().numpy(); ids = v["point_list"][int(rg[0]) + seg * 1024: min(int(rg[0]) + seg * 1024 + 1024, int(rg[1]))].long()
+            tile = int(v["bwd_order"][blk - nfull]); seg = int(v["seg_cnt"][tile])
+        rg = v["ranges"][tile].cpu().numpy(); ids = v["point_list"][int(rg[0]) + seg * 512: min(int(rg[0]) + seg * 512 + 512, int(rg[1]))].long()
         cb = v["cullbox"][ids].cpu().numpy(); nonempty = int(((cb[:, 1] >= cb[:, 0]) & (cb[:, 3] >= cb[:, 2])).sum())
         ty, tx = divmod(tile, 32)
         ncb = v["n_contrib"][0][ty*16:ty*16+16, tx*16:tx*16+16]
