@@ -87,6 +87,63 @@ int lara_tokens_from_volume(int32_t scenes, int32_t R, int32_t C, const float *v
 int lara_volume_from_tokens(int32_t scenes, int32_t R, int32_t C, const float *tokens, float *volume,
                             void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backward (training).  In the reference this is torch autograd through the modules above under
+ * bf16-mixed autocast.  A block saves only its input rows: lara_groupblock_backward re-runs the
+ * block's forward into its workspace, then produces
+ *   g      in: dL/d(block output) fp32 [M, 256]   out: dL/d(block input), in place
+ *   dcond  += dL/d(cond) fp32 [M/2, cond_dim]      (the same cond feeds every layer: accumulate)
+ *   dw     += the parameter gradients, fp32, in the layouts of lara_groupblock_weights
+ * The caller zero-fills dcond and dw once per step.  Matrix products: bf16 operands, fp32 accumulate;
+ * all reductions have a fixed order (bit-reproducible).  Requires R >= 4.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* the bf16 matrices of lara_groupblock_weights, transposed (row-major [in, out]); wconv_t is
+ * [in][mirrored tap][out], i.e. wconv_t[ci][t][co] = wconv[co][26 - t][ci] */
+typedef struct lara_groupblock_weights_t {
+    const uint16_t *wq_t;    /* [256, 256]        */
+    const uint16_t *wkv_t;   /* [cond_dim, 512]   */
+    const uint16_t *wo_t;    /* [256, 256]        */
+    const uint16_t *w1_t;    /* [256, 512]        */
+    const uint16_t *w2_t;    /* [512, 256]        */
+    const uint16_t *wconv_t; /* [256, 27, 256]    */
+} lara_groupblock_weights_t;
+
+/* fp32 gradient accumulators, same shapes as the fields of lara_groupblock_weights */
+typedef struct lara_groupblock_grads {
+    float *ln1_w, *ln1_b, *wq, *wkv, *wo, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2, *ln3_w, *ln3_b, *wconv;
+} lara_groupblock_grads;
+
+int64_t lara_groupblock_backward_workspace_bytes(int32_t scenes, int32_t R);
+
+int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
+                             const uint16_t *cond_bf16, const lara_groupblock_weights *w,
+                             const lara_groupblock_weights_t *wt, float *g, float *dcond,
+                             const lara_groupblock_grads *dw, void *workspace, void *stream);
+
+/* Backward of lara_voltrans_head_forward.  x: the rows that entered the head; dout: fp32
+ * [scenes, 2R, 2R, 2R, Cout]; wdeconv_t: wdeconv transposed, [256, 8 * Cout] bf16.  Writes g = dL/dx
+ * (fp32 [M, 256]) and ACCUMULATES d_ln_w, d_ln_b [256], d_wdeconv [8 * Cout, 256] and d_bias8
+ * [8 * Cout] (the bias gradient per kernel tap: sum the 8 taps).  Cout % 16 == 0. */
+int64_t lara_voltrans_head_backward_workspace_bytes(int32_t scenes, int32_t R, int32_t Cout);
+int lara_voltrans_head_backward(int32_t scenes, int32_t R, const float *x, const float *ln_w, const float *ln_b,
+                                float eps, const uint16_t *wdeconv_t, int32_t Cout, const float *dout, float *g,
+                                float *d_ln_w, float *d_ln_b, float *d_wdeconv, float *d_bias8, void *workspace,
+                                void *stream);
+
+/* Building blocks of the above, exported for the parity tests:
+ *   dst[N, Kc] += A[M, N]^T . B[M, Kc]   (bf16 operands, M % 16 == 0, N and Kc even)
+ *   LayerNorm(256) backward: dx = dLN(dy; x, gamma) (+ skip); dgamma, dbeta accumulated
+ *   backward of the per-group attention core: (q, k|v, dO) -> dq [G*8, 256], dk|dv [G*4, 512], bf16 */
+int64_t lara_gemm_tn_workspace_bytes(void);
+int lara_gemm_tn_bf16(int32_t M, int32_t N, int32_t Kc, const uint16_t *A, const uint16_t *B, float *dst,
+                      void *workspace, void *stream);
+int lara_layernorm256_backward(int32_t rows, const float *dy, const float *x, const float *gamma, float eps,
+                               const float *skip, float *dx, float *dgamma, float *dbeta, void *workspace,
+                               void *stream);
+int lara_groupattn_core_backward(int32_t G, const uint16_t *q, const uint16_t *kv, const uint16_t *d_o, uint16_t *dq,
+                                 uint16_t *dkv, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

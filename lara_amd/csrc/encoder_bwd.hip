@@ -1,0 +1,594 @@
+// encoder_bwd.hip -- backward of LaRa's GroupAttBlock / VolTransformer tail (lightning/network.py:81-102,
+// :156-163; in the reference this is torch autograd through nn.MultiheadAttention, nn.LayerNorm,
+// nn.Linear, nn.Conv3d and nn.ConvTranspose3d under bf16-mixed autocast) on gfx950 matrix cores.
+//
+// A block keeps NOTHING from its forward except its input rows: the backward re-runs the block's
+// forward into scratch (the same kernels as encoder.hip, keeping the intermediates this time) and then
+// walks it in reverse.  Gradients w.r.t. activations are NT GEMMs against host-transposed weights (the
+// forward's kernels, new epilogues); gradients w.r.t. weights are TN GEMMs (reduction over the token
+// rows) in gemm_bf16_tn_kernel below; LayerNorm, the per-group softmax attention and the bias sums have
+// their own small kernels.  All matrix products take bf16 operands and accumulate in fp32, like the
+// forward; every reduction has a fixed order (partials + a second pass, no float atomics), so results
+// are bit-reproducible.
+#include <cstdlib>
+
+#include "mfma_gemm.h"
+#include "group_attn.h"
+#include "../../include/lara_groupattn.h"
+
+namespace {
+
+// ---- C[N, T*Kc] (+)= A[M, N]^T . B[M or gathered, Kc]: weight gradients -------------------------------
+// Both operands are row-major with the REDUCTION index (token row m) as the slow one, the opposite of
+// what an MFMA fragment wants (8 consecutive k per lane).  A lane therefore loads one dword (columns
+// 2r, 2r+1) from each of the 8 rows of its k-slice and re-packs the halves: the low halves are the
+// fragment of column 2r, the high halves of column 2r+1 -- two MFMA tiles (even / odd columns) per 64
+// operand columns, no LDS, no barriers.  The 8 rows m0 + 8 kh + e of a k-slice are one 2x2x2 voxel group
+// in the group-major token order, which also makes the gathered variant cheap: for the convolution's
+// weight gradient, B rows are the (dz, dy, dx) neighbours of the A rows, looked up in a table
+// nbr[tap][m] (row index, or the index of a zeroed row) that is built once per volume shape.
+// Workgroup: 4 waves as 2 x 2, tile 128 (A columns) x 128 (B columns), wave tile 64 x 64; grid.y splits
+// the token rows, every split writes its own partial tile (summed by accum_partials_kernel).
+struct TnP {
+    const unsigned short *A, *B;
+    float *part;     // [splits][N][T * Kc]
+    const int *nbr;  // GATHER: [T][M] rows of B
+    int M, lda, ldb, N, Kc, T, chunk;
+};
+
+__device__ __forceinline__ bf16x8 pack_lo(const uint32_t *w) {
+    union { uint32_t u[4]; bf16x8 v; } r;
+#pragma unroll
+    for (int d = 0; d < 4; d++) r.u[d] = (w[2 * d] & 0xffffu) | (w[2 * d + 1] << 16);
+    return r.v;
+}
+__device__ __forceinline__ bf16x8 pack_hi(const uint32_t *w) {
+    union { uint32_t u[4]; bf16x8 v; } r;
+#pragma unroll
+    for (int d = 0; d < 4; d++) r.u[d] = (w[2 * d] >> 16) | (w[2 * d + 1] & 0xffff0000u);
+    return r.v;
+}
+
+template <bool GATHER>
+__global__ void __launch_bounds__(256)
+gemm_bf16_tn_kernel(const TnP p) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, kh = lane >> 5;
+    const int ctiles = (p.Kc + 127) / 128 * p.T;  // column tiles (a tile never straddles two taps)
+    const int ct = blockIdx.x % ctiles, nt = blockIdx.x / ctiles;
+    const int tpt = (p.Kc + 127) / 128;  // tiles per tap
+    const int tap = ct / tpt, kc0 = (ct - tap * tpt) * 128;
+    const int nbase = nt * 128 + (wave >> 1) * 64, kbase = kc0 + (wave & 1) * 64;
+    const int an = min(nbase + 2 * r, p.N - 2), bk = min(kbase + 2 * r, p.Kc - 2);
+    const int m_start = blockIdx.y * p.chunk, m_end = min(p.M, m_start + p.chunk);
+    const unsigned short *Ap = p.A + an, *Bp = p.B + bk;
+    const int *nb = GATHER ? p.nbr + (size_t)tap * p.M : nullptr;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    uint32_t wa[8], wb[8], na[8], nbv[8];
+    auto load = [&](const int m0, uint32_t *a, uint32_t *b) {
+        const int row0 = m0 + 8 * kh;
+        int rows[8];
+        if (GATHER) {
+            const int4 i0 = *(const int4 *)(nb + row0), i1 = *(const int4 *)(nb + row0 + 4);
+            rows[0] = i0.x; rows[1] = i0.y; rows[2] = i0.z; rows[3] = i0.w;
+            rows[4] = i1.x; rows[5] = i1.y; rows[6] = i1.z; rows[7] = i1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            a[e] = *(const uint32_t *)(Ap + (size_t)(row0 + e) * p.lda);
+            b[e] = *(const uint32_t *)(Bp + (size_t)(GATHER ? rows[e] : row0 + e) * p.ldb);
+        }
+    };
+    if (m_start < m_end) load(m_start, wa, wb);
+    for (int m0 = m_start; m0 < m_end; m0 += 16) {
+        const bool more = m0 + 16 < m_end;
+        if (more) load(m0 + 16, na, nbv);  // in flight while this slice is multiplied
+        const bf16x8 a0 = pack_lo(wa), a1 = pack_hi(wa), b0 = pack_lo(wb), b1 = pack_hi(wb);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { wa[e] = na[e]; wb[e] = nbv[e]; }
+        }
+    }
+    // accumulator (ta, tb)[reg]: A column nbase + 2 i + ta with i = (reg&3) + 8 (reg>>2) + 4 kh, B column
+    // kbase + 2 (lane&31) + tb: the two tb's of a lane are neighbours -> float2 stores
+    const int ldc = p.T * p.Kc;
+    float *out = p.part + (size_t)blockIdx.y * p.N * ldc + (size_t)tap * p.Kc;
+    const int col = kbase + 2 * r;
+    if (col < p.Kc) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int n = nbase + 2 * ((e & 3) + 8 * (e >> 2) + 4 * kh) + ta;
+                if (n < p.N) *(float2 *)(out + (size_t)n * ldc + col) = make_float2(acc[ta][0][e], acc[ta][1][e]);
+            }
+    }
+}
+
+// dst[i] += sum over parts of part[s * stride + i]; 64 elements per workgroup, 4 slices of the parts
+__global__ void __launch_bounds__(256)
+accum_partials_kernel(float *__restrict__ dst, const float *__restrict__ part, const int n, const int parts,
+                      const size_t stride) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < n)
+        for (int q = sl; q < parts; q += 4) s += part[(size_t)q * stride + c];
+    red[sl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sl == 0 && c < n) dst[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// nbr[tap][m] = token row of voxel(m) + (dz, dy, dx), or `zero_row` outside the volume
+__global__ void __launch_bounds__(256)
+neighbour_table_kernel(int *__restrict__ nbr, const int M, const int R, const int zero_row) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    int b, d, h, w;
+    token_to_voxel(m, R, b, d, h, w);
+    for (int tap = 0; tap < 27; tap++) {
+        const int nd = d + tap / 9 - 1, nh = h + (tap / 3) % 3 - 1, nw = w + tap % 3 - 1;
+        const bool in = (unsigned)nd < (unsigned)R && (unsigned)nh < (unsigned)R && (unsigned)nw < (unsigned)R;
+        nbr[(size_t)tap * M + m] = in ? voxel_to_token(b, nd, nh, nw, R) : zero_row;
+    }
+}
+
+// ---- LayerNorm(256) backward: one wave per row, 16 rows per wave, 64 rows per workgroup ---------------
+// dx = rstd (a - mean(a) - xhat mean(a xhat)), a = dy gamma;  out = dx (+ skip) as fp32 and, optionally,
+// bf16; per-workgroup partial column sums of dy xhat (dgamma), dy (dbeta) and out (the bias gradient of
+// the linear layer that produced the LayerNorm's input) go to part[block][3][256].
+// dx_out may alias dy or skip (a lane reads its own four elements before it writes them).
+__global__ void __launch_bounds__(256)
+ln_bwd_kernel(const float *dy, const float *__restrict__ x, const float *__restrict__ gamma, const float eps,
+              const float *skip, float *dx_out, unsigned short *__restrict__ dx_bf16, float *__restrict__ part,
+              const int tokens) {
+    __shared__ float red[4][12][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4 g = ((const float4 *)gamma)[lane];
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, po[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; i++) {
+        const int tok = blockIdx.x * 64 + wave * 16 + i;
+        if (tok >= tokens) break;
+        const float4 v = ((const float4 *)(x + (size_t)tok * 256))[lane];
+        const float4 d = ((const float4 *)(dy + (size_t)tok * 256))[lane];
+        float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / 256.0f);
+        const float c0 = v.x - mean, c1 = v.y - mean, c2 = v.z - mean, c3 = v.w - mean;
+        float q = c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + eps);
+        const float h0 = c0 * rstd, h1 = c1 * rstd, h2 = c2 * rstd, h3 = c3 * rstd;
+        const float a0 = d.x * g.x, a1 = d.y * g.y, a2 = d.z * g.z, a3 = d.w * g.w;
+        float sa = a0 + a1 + a2 + a3, sh = a0 * h0 + a1 * h1 + a2 * h2 + a3 * h3;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sh += __shfl_xor(sh, o, 64); }
+        sa *= (1.0f / 256.0f); sh *= (1.0f / 256.0f);
+        float4 r = make_float4(rstd * (a0 - sa - h0 * sh), rstd * (a1 - sa - h1 * sh), rstd * (a2 - sa - h2 * sh),
+                               rstd * (a3 - sa - h3 * sh));
+        if (skip) {
+            const float4 k = ((const float4 *)(skip + (size_t)tok * 256))[lane];
+            r.x += k.x; r.y += k.y; r.z += k.z; r.w += k.w;
+        }
+        ((float4 *)(dx_out + (size_t)tok * 256))[lane] = r;
+        if (dx_bf16) {
+            ushort4 hb;
+            hb.x = f2bf(r.x); hb.y = f2bf(r.y); hb.z = f2bf(r.z); hb.w = f2bf(r.w);
+            ((ushort4 *)(dx_bf16 + (size_t)tok * 256))[lane] = hb;
+        }
+        pg[0] += d.x * h0; pg[1] += d.y * h1; pg[2] += d.z * h2; pg[3] += d.w * h3;
+        pb[0] += d.x; pb[1] += d.y; pb[2] += d.z; pb[3] += d.w;
+        po[0] += r.x; po[1] += r.y; po[2] += r.z; po[3] += r.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) { red[wave][c][lane] = pg[c]; red[wave][4 + c][lane] = pb[c]; red[wave][8 + c][lane] = po[c]; }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const float t = (red[0][k][lane] + red[1][k][lane]) + (red[2][k][lane] + red[3][k][lane]);
+            // quantity k / 4, channel 4 * lane + k % 4
+            part[(size_t)blockIdx.x * 768 + (k >> 2) * 256 + 4 * lane + (k & 3)] = t;
+        }
+    }
+}
+
+// ---- column sums of a bf16 matrix [rows, C] (bias gradients): 64 rows per workgroup -> part[block][C] ----
+__global__ void __launch_bounds__(256)
+colsum_bf16_kernel(const unsigned short *__restrict__ src, float *__restrict__ part, const int rows, const int C) {
+    const int r0 = blockIdx.x * 64, r1 = min(rows, r0 + 64);
+    for (int c2 = threadIdx.x; c2 < C / 2; c2 += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int rr = r0; rr < r1; rr++) {
+            const uint32_t w = *(const uint32_t *)(src + (size_t)rr * C + 2 * c2);
+            s0 += __uint_as_float(w << 16);
+            s1 += __uint_as_float(w & 0xffff0000u);
+        }
+        part[(size_t)blockIdx.x * C + 2 * c2] = s0;
+        part[(size_t)blockIdx.x * C + 2 * c2 + 1] = s1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cast_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, const size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = ((const float4 *)src)[i];
+    ushort4 h;
+    h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
+    ((ushort4 *)dst)[i] = h;
+}
+
+// gradient of the transposed convolution's output [scenes, 2R, 2R, 2R, Cout] fp32, gathered into the rows
+// of its GEMM form: dog[m][tap * Cout + co] (bf16), tap = (i*2 + j)*2 + k
+__global__ void __launch_bounds__(256)
+deconv_grad_gather_kernel(const float *__restrict__ dout, unsigned short *__restrict__ dog, const int M, const int R,
+                          const int Cout) {
+    const int c4n = 2 * Cout;  // float4 groups per row (8 * Cout / 4)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * c4n) return;
+    const int m = (int)(i / c4n), c = (int)(i - (size_t)m * c4n) * 4;
+    const int tap = c / Cout, co = c - tap * Cout;
+    int b, d, h, w;
+    token_to_voxel(m, R, b, d, h, w);
+    const size_t R2 = 2 * (size_t)R;
+    const size_t o = ((((size_t)b * R2 + 2 * d + (tap >> 2)) * R2 + 2 * h + ((tap >> 1) & 1)) * R2 + 2 * w + (tap & 1)) * Cout + co;
+    const float4 v = *(const float4 *)(dout + o);
+    ushort4 hb;
+    hb.x = f2bf(v.x); hb.y = f2bf(v.y); hb.z = f2bf(v.z); hb.w = f2bf(v.w);
+    *(ushort4 *)(dog + (size_t)m * 8 * Cout + c) = hb;
+}
+
+// ---- backward of the per-group softmax attention (16 heads x head_dim 16, 8 queries x 4 keys) -----------
+// Two groups per workgroup, 128 threads each.  Phase 1, thread = (head, query): scores, softmax, dP, dS
+// and its dQ row; phase 2, thread = (head, key, half of the head's 16 channels): dK and dV as sums over
+// the 8 queries.  The group's Q, dO and K|V rows (4 KB each) sit in LDS; dQ and dK|dV leave through LDS
+// so that global traffic is whole 512- / 1024-byte rows.
+__global__ void __launch_bounds__(256)
+group_attn_bwd_kernel(const unsigned short *__restrict__ Q, const unsigned short *__restrict__ KV,
+                      const unsigned short *__restrict__ dO, unsigned short *__restrict__ dQ,
+                      unsigned short *__restrict__ dKV, const int G) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_q[2][8 * 256], s_do[2][8 * 256], s_kv[2][4 * 512], s_dq[2][8 * 256];
+    __shared__ float s_p[2][16 * 8 * 4], s_ds[2][16 * 8 * 4];
+    const int gl = threadIdx.x >> 7, t = threadIdx.x & 127;
+    const int g = blockIdx.x * 2 + gl;
+    const bool active = g < G;
+    if (active) {
+        const uint4 *gq = (const uint4 *)(Q + (size_t)g * 8 * 256), *gd = (const uint4 *)(dO + (size_t)g * 8 * 256);
+        const uint4 *gk = (const uint4 *)(KV + (size_t)g * 4 * 512);
+        ((uint4 *)s_q[gl])[t] = gq[t]; ((uint4 *)s_q[gl])[t + 128] = gq[t + 128];
+        ((uint4 *)s_do[gl])[t] = gd[t]; ((uint4 *)s_do[gl])[t + 128] = gd[t + 128];
+        ((uint4 *)s_kv[gl])[t] = gk[t]; ((uint4 *)s_kv[gl])[t + 128] = gk[t + 128];
+    }
+    __syncthreads();
+    if (active) {
+        const int h = t >> 3, i = t & 7;
+        float qv[16], dv[16];
+#pragma unroll
+        for (int d = 0; d < 16; d++) { qv[d] = bf2f(s_q[gl][i * 256 + h * 16 + d]); dv[d] = bf2f(s_do[gl][i * 256 + h * 16 + d]); }
+        float sc[4], dp[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                a += qv[d] * bf2f(s_kv[gl][j * 512 + h * 16 + d]);
+                b += dv[d] * bf2f(s_kv[gl][j * 512 + 256 + h * 16 + d]);
+            }
+            sc[j] = a * 0.25f; dp[j] = b;
+        }
+        const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        float pr[4], sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pr[j] = __expf(sc[j] - mx); sum += pr[j]; }
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pr[j] *= inv; dot += pr[j] * dp[j]; }
+        float ds[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            ds[j] = pr[j] * (dp[j] - dot) * 0.25f;  // includes the 1/sqrt(head_dim) of the scores
+            s_p[gl][(h * 8 + i) * 4 + j] = pr[j];
+            s_ds[gl][(h * 8 + i) * 4 + j] = ds[j];
+        }
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) a += ds[j] * bf2f(s_kv[gl][j * 512 + h * 16 + d]);
+            s_dq[gl][i * 256 + h * 16 + d] = f2bf(a);
+        }
+    }
+    __syncthreads();
+    float dk[8], dvv[8];
+    const int h2 = t >> 3, j2 = (t >> 1) & 3, d0 = (t & 1) * 8;
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) { dk[d] = 0.f; dvv[d] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float dsv = s_ds[gl][(h2 * 8 + i) * 4 + j2], pv = s_p[gl][(h2 * 8 + i) * 4 + j2];
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                dk[d] += dsv * bf2f(s_q[gl][i * 256 + h2 * 16 + d0 + d]);
+                dvv[d] += pv * bf2f(s_do[gl][i * 256 + h2 * 16 + d0 + d]);
+            }
+        }
+    }
+    __syncthreads();  // phase 1's reads of K|V are done: reuse its LDS for dK|dV
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            s_kv[gl][j2 * 512 + h2 * 16 + d0 + d] = f2bf(dk[d]);
+            s_kv[gl][j2 * 512 + 256 + h2 * 16 + d0 + d] = f2bf(dvv[d]);
+        }
+    }
+    __syncthreads();
+    if (active) {
+        uint4 *oq = (uint4 *)(dQ + (size_t)g * 8 * 256), *ok = (uint4 *)(dKV + (size_t)g * 4 * 512);
+        oq[t] = ((const uint4 *)s_dq[gl])[t]; oq[t + 128] = ((const uint4 *)s_dq[gl])[t + 128];
+        ok[t] = ((const uint4 *)s_kv[gl])[t]; ok[t + 128] = ((const uint4 *)s_kv[gl])[t + 128];
+    }
+}
+
+// ---- host helpers -------------------------------------------------------------------------------------
+constexpr size_t TN_PART_BYTES = 128ull << 20;  // partial-tile buffer of the weight-gradient GEMMs
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// dst[N, T*Kc] += A^T . B; `part` holds TN_PART_BYTES
+int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, int ldb, int Kc, int T, const int *nbr,
+            int M, float *dst, float *part, hipStream_t s) {
+    if ((M & 15) || (N & 1) || (Kc & 1) || (T > 1 && (Kc & 127))) return LARA2DGS_E_INVALID;
+    const int tiles = ((N + 127) / 128) * ((Kc + 127) / 128) * T;
+    const size_t out_bytes = (size_t)N * T * Kc * 4;
+    // about 1024 workgroups per launch, at least 512 token rows each (a split costs a partial tile)
+    int splits = max(1, min(min(max(1, 1024 / tiles), (int)(TN_PART_BYTES / out_bytes)), M / 512));
+    const int chunk = (((M + splits - 1) / splits) + 15) & ~15;
+    splits = (M + chunk - 1) / chunk;
+    TnP p{};
+    p.A = A; p.B = B; p.part = part; p.nbr = nbr; p.M = M; p.lda = lda; p.ldb = ldb; p.N = N; p.Kc = Kc; p.T = T;
+    p.chunk = chunk;
+    if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), dim3(tiles, splits), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles, splits), dim3(256), 0, s, p);
+    const int n = N * T * Kc;
+    hipLaunchKernelGGL(accum_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
+    return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
+}
+
+// LayerNorm backward + the reductions of its partial sums into dgamma, dbeta, dbias (any may be null)
+int ln_bwd(const float *dy, const float *x, const float *gamma, float eps, const float *skip, float *dx,
+           unsigned short *dx_bf16, float *dgamma, float *dbeta, float *dbias, float *part, int M, hipStream_t s) {
+    const int blocks = (M + 63) / 64;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, x, gamma, eps, skip, dx, dx_bf16, part, M);
+    float *dst[3] = {dgamma, dbeta, dbias};
+    for (int k = 0; k < 3; k++)
+        if (dst[k])
+            hipLaunchKernelGGL(accum_partials_kernel, dim3(4), dim3(256), 0, s, dst[k], part + k * 256, 256, blocks, (size_t)768);
+    return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
+}
+
+int colsum_bf16(const unsigned short *src, int rows, int C, float *dst, float *part, hipStream_t s) {
+    const int blocks = (rows + 63) / 64;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks), dim3(256), 0, s, src, part, rows, C);
+    hipLaunchKernelGGL(accum_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dst, part, C, blocks, (size_t)C);
+    return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
+}
+
+template <int EPI>
+void gemm_nt(const unsigned short *A, const unsigned short *W, void *C, int M, int N, int K, const float *resid,
+             unsigned short *C2, hipStream_t s) {
+    GemmP p{};
+    p.A = A; p.W = W; p.C = C; p.resid = resid; p.C2 = C2; p.M = M; p.N = N; p.K = K;
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, EPI>), dim3((M + 127) / 128, (N + 127) / 128), dim3(256), 0, s, p);
+}
+
+// scratch layout of lara_groupblock_backward, in bytes from the workspace start
+struct BwdWs {
+    size_t xn1, q, kv, o, x1, xn2, z, h, x2, xn3, gb, tmpf, dzb, dq, dkv, dob, nbr, lnpart, tnpart, total;
+};
+BwdWs bwd_layout(int64_t M) {
+    BwdWs w{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
+    const size_t b256 = (size_t)M * 512, f256 = (size_t)M * 1024, b512 = (size_t)M * 1024;
+    w.xn1 = take(b256); w.q = take(b256); w.kv = take(b256); w.o = take(b256);
+    w.x1 = take(f256); w.xn2 = take(b256); w.z = take(b512); w.h = take(b512); w.x2 = take(f256);
+    w.xn3 = take(b256 + 512);  // + the zeroed row (index M) the gathers read outside the volume
+    w.gb = take(b256 + 512);   // same
+    w.tmpf = take(f256); w.dzb = take(b512); w.dq = take(b256); w.dkv = take(b256); w.dob = take(b256);
+    w.nbr = take((size_t)27 * M * 4);
+    w.lnpart = take(((size_t)(M + 63) / 64) * 768 * 4);
+    w.tnpart = take(TN_PART_BYTES);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t lara_groupblock_backward_workspace_bytes(int32_t scenes, int32_t R) {
+    if (scenes < 0 || R < 4 || (R & 1)) return LARA2DGS_E_INVALID;
+    return (int64_t)bwd_layout((int64_t)scenes * R * R * R).total;
+}
+
+int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
+                             const uint16_t *cond_bf16, const lara_groupblock_weights *w,
+                             const lara_groupblock_weights_t *wt, float *g, float *dcond,
+                             const lara_groupblock_grads *dw, void *workspace, void *stream) {
+    if (scenes < 0 || R < 4 || (R & 1) || cond_dim <= 0 || (cond_dim % 32) != 0 || !w || !wt || !dw) return LARA2DGS_E_INVALID;
+    if (scenes == 0) return LARA2DGS_OK;
+    if (!x_in || !cond_bf16 || !g || !dcond || !workspace) return LARA2DGS_E_INVALID;
+    if (!w->ln1_w || !w->ln1_b || !w->wq || !w->wkv || !w->wo || !w->ln2_w || !w->ln2_b || !w->w1 || !w->b1 || !w->w2 ||
+        !w->b2 || !w->ln3_w || !w->ln3_b || !w->wconv || !wt->wq_t || !wt->wkv_t || !wt->wo_t || !wt->w1_t || !wt->w2_t ||
+        !wt->wconv_t || !dw->ln1_w || !dw->ln1_b || !dw->wq || !dw->wkv || !dw->wo || !dw->ln2_w || !dw->ln2_b ||
+        !dw->w1 || !dw->b1 || !dw->w2 || !dw->b2 || !dw->ln3_w || !dw->ln3_b || !dw->wconv)
+        return LARA2DGS_E_INVALID;
+    const int64_t M64 = (int64_t)scenes * R * R * R;
+    if (M64 * 2056 + 512 >= (1ll << 32)) return LARA2DGS_E_INVALID;
+    const int M = (int)M64, G = M / 8, Mkv = G * 4;
+    hipStream_t s = (hipStream_t)stream;
+    const BwdWs L = bwd_layout(M);
+    char *ws = (char *)workspace;
+    unsigned short *xn1 = (unsigned short *)(ws + L.xn1), *q = (unsigned short *)(ws + L.q), *kv = (unsigned short *)(ws + L.kv);
+    unsigned short *o = (unsigned short *)(ws + L.o), *xn2 = (unsigned short *)(ws + L.xn2), *z = (unsigned short *)(ws + L.z);
+    unsigned short *h = (unsigned short *)(ws + L.h), *xn3 = (unsigned short *)(ws + L.xn3), *gb = (unsigned short *)(ws + L.gb);
+    unsigned short *dzb = (unsigned short *)(ws + L.dzb), *dq = (unsigned short *)(ws + L.dq), *dkv = (unsigned short *)(ws + L.dkv);
+    unsigned short *dob = (unsigned short *)(ws + L.dob);
+    float *x1 = (float *)(ws + L.x1), *x2 = (float *)(ws + L.x2), *tmpf = (float *)(ws + L.tmpf);
+    float *lnpart = (float *)(ws + L.lnpart), *tnpart = (float *)(ws + L.tnpart);
+    int *nbr = (int *)(ws + L.nbr);
+    const int lnb = (M + 3) / 4;
+    int rc;
+
+    // ---- the block's forward again, keeping what the backward needs (network.py:88-95) ----
+    {
+        L2D_PROF("gbb_recompute", s);
+        hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x_in, w->ln1_w, w->ln1_b, w->eps, xn1, (float2 *)nullptr, M);
+        gemm_nt<0>(xn1, w->wq, q, M, 256, 256, nullptr, nullptr, s);
+        {
+            GemmP p{};
+            p.A = cond_bf16; p.W = w->wkv; p.C = kv; p.M = Mkv; p.N = 512; p.K = cond_dim;
+            if (launch_gemm_ring<0, 0>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        }
+        hipLaunchKernelGGL(group_attn_kernel, dim3((G + 15) / 16), dim3(256), 0, s, q, kv, o, G);
+        gemm_nt<1>(o, w->wo, x1, M, 256, 256, x_in, nullptr, s);
+        hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x1, w->ln2_w, w->ln2_b, w->eps, xn2, (float2 *)nullptr, M);
+        {
+            GemmP p{};
+            p.A = xn2; p.W = w->w1; p.C = h; p.C2 = z; p.bias = w->b1; p.M = M; p.N = 512; p.K = 256;
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 6>), dim3((M + 127) / 128, 4), dim3(256), 0, s, p);
+        }
+        {
+            GemmP p{};
+            p.A = h; p.W = w->w2; p.C = x2; p.resid = x1; p.bias = w->b2; p.M = M; p.N = 256; p.K = 512;
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 3>), dim3((M + 127) / 128, 2), dim3(256), 0, s, p);
+        }
+        hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x2, w->ln3_w, w->ln3_b, w->eps, xn3, (float2 *)nullptr, M);
+        if (hipMemsetAsync(xn3 + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        if (hipMemsetAsync(gb + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        hipLaunchKernelGGL(neighbour_table_kernel, dim3((M + 255) / 256), dim3(256), 0, s, nbr, M, R, M);
+    }
+    L2D_CHECK_LAUNCH();
+    // ---- x_out = pn + cnn(pn), pn = norm3(x2)  (network.py:94-100) ----
+    {
+        L2D_PROF("gbb_conv", s);
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, g, gb, (size_t)M * 64);
+        if ((rc = gemm_tn(gb, 256, 256, xn3, 256, 256, 27, nbr, M, dw->wconv, tnpart, s))) return rc;
+        GemmP p{};  // d pn = g + cnn^T(g): the same implicit GEMM with the taps mirrored and in/out swapped
+        p.A = gb; p.W = wt->wconv_t; p.C = g; p.resid = g; p.M = M; p.N = 256; p.K = 27 * 256;
+        p.R = R; p.Cin = 256; p.zero_off = (uint32_t)((size_t)M * 512);
+        if (launch_gemm_ring<1, 1>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        if ((rc = ln_bwd(g, x2, w->ln3_w, w->eps, nullptr, g, gb, dw->ln3_w, dw->ln3_b, dw->b2, lnpart, M, s))) return rc;
+    }
+    L2D_CHECK_LAUNCH();
+    // ---- x2 = x1 + mlp(norm2(x1)) ----
+    {
+        L2D_PROF("gbb_mlp", s);
+        gemm_nt<7>(gb, wt->w2_t, dzb, M, 512, 256, nullptr, z, s);  // dz = (g2 W2) * gelu'(z)
+        if ((rc = gemm_tn(gb, 256, 256, h, 512, 512, 1, nullptr, M, dw->w2, tnpart, s))) return rc;
+        if ((rc = colsum_bf16(dzb, M, 512, dw->b1, lnpart, s))) return rc;
+        if ((rc = gemm_tn(dzb, 512, 512, xn2, 256, 256, 1, nullptr, M, dw->w1, tnpart, s))) return rc;
+        gemm_nt<8>(dzb, wt->w1_t, tmpf, M, 256, 512, nullptr, nullptr, s);
+        if ((rc = ln_bwd(tmpf, x1, w->ln2_w, w->eps, g, g, gb, dw->ln2_w, dw->ln2_b, nullptr, lnpart, M, s))) return rc;
+    }
+    L2D_CHECK_LAUNCH();
+    // ---- x1 = x0 + cross_attn(norm1(x0), cond, cond) ----
+    {
+        L2D_PROF("gbb_attn", s);
+        gemm_nt<0>(gb, wt->wo_t, dob, M, 256, 256, nullptr, nullptr, s);
+        if ((rc = gemm_tn(gb, 256, 256, o, 256, 256, 1, nullptr, M, dw->wo, tnpart, s))) return rc;
+        hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, s, q, kv, dob, dq, dkv, G);
+        if ((rc = gemm_tn(dq, 256, 256, xn1, 256, 256, 1, nullptr, M, dw->wq, tnpart, s))) return rc;
+        if ((rc = gemm_tn(dkv, 512, 512, cond_bf16, cond_dim, cond_dim, 1, nullptr, Mkv, dw->wkv, tnpart, s))) return rc;
+        gemm_nt<1>(dkv, wt->wkv_t, dcond, Mkv, cond_dim, 512, dcond, nullptr, s);
+        gemm_nt<8>(dq, wt->wq_t, tmpf, M, 256, 256, nullptr, nullptr, s);
+        if ((rc = ln_bwd(tmpf, x_in, w->ln1_w, w->eps, g, g, nullptr, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int64_t lara_voltrans_head_backward_workspace_bytes(int32_t scenes, int32_t R, int32_t Cout) {
+    if (scenes < 0 || R < 4 || (R & 1) || Cout <= 0 || (Cout & 15)) return LARA2DGS_E_INVALID;
+    const size_t M = (size_t)scenes * R * R * R;
+    return (int64_t)(up256(M * 512) + up256(M * 16 * Cout) + up256(M * 1024) + up256(((M + 63) / 64) * 4 * (size_t)max(768, 8 * Cout)) +
+                     TN_PART_BYTES);
+}
+
+int lara_voltrans_head_backward(int32_t scenes, int32_t R, const float *x, const float *ln_w, const float *ln_b,
+                                float eps, const uint16_t *wdeconv_t, int32_t Cout, const float *dout, float *g,
+                                float *d_ln_w, float *d_ln_b, float *d_wdeconv, float *d_bias8, void *workspace,
+                                void *stream) {
+    if (scenes < 0 || R < 4 || (R & 1) || Cout <= 0 || (Cout & 15)) return LARA2DGS_E_INVALID;  // K = 8 Cout in steps of 32... 128
+    if (scenes == 0) return LARA2DGS_OK;
+    if (!x || !ln_w || !ln_b || !wdeconv_t || !dout || !g || !d_ln_w || !d_ln_b || !d_wdeconv || !d_bias8 || !workspace)
+        return LARA2DGS_E_INVALID;
+    const int M = scenes * R * R * R, N8 = 8 * Cout;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    size_t off = 0;
+    unsigned short *xn = (unsigned short *)(ws + off); off += up256((size_t)M * 512);
+    unsigned short *dog = (unsigned short *)(ws + off); off += up256((size_t)M * 16 * Cout);
+    float *tmpf = (float *)(ws + off); off += up256((size_t)M * 1024);
+    float *lnpart = (float *)(ws + off); off += up256(((size_t)(M + 63) / 64) * 4 * (size_t)max(768, N8));
+    float *tnpart = (float *)(ws + off);
+    int rc;
+    L2D_PROF("vtb_head", s);
+    hipLaunchKernelGGL(ln_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ln_w, ln_b, eps, xn, (float2 *)nullptr, M);
+    {
+        const size_t n = (size_t)M * 2 * Cout;
+        hipLaunchKernelGGL(deconv_grad_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dout, dog, M, R, Cout);
+    }
+    if ((rc = colsum_bf16(dog, M, N8, d_bias8, lnpart, s))) return rc;
+    if ((rc = gemm_tn(dog, N8, N8, xn, 256, 256, 1, nullptr, M, d_wdeconv, tnpart, s))) return rc;
+    gemm_nt<8>(dog, wdeconv_t, tmpf, M, 256, N8, nullptr, nullptr, s);
+    if ((rc = ln_bwd(tmpf, x, ln_w, eps, nullptr, g, nullptr, d_ln_w, d_ln_b, nullptr, lnpart, M, s))) return rc;
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+/* ---- unit entry points (parity tests of the individual kernels) ---- */
+
+int lara_gemm_tn_bf16(int32_t M, int32_t N, int32_t Kc, const uint16_t *A, const uint16_t *B, float *dst,
+                      void *workspace, void *stream) {
+    if (M <= 0 || N <= 0 || Kc <= 0 || !A || !B || !dst || !workspace) return LARA2DGS_E_INVALID;
+    return gemm_tn(A, N, N, B, Kc, Kc, 1, nullptr, M, dst, (float *)workspace, (hipStream_t)stream);
+}
+
+int64_t lara_gemm_tn_workspace_bytes(void) { return (int64_t)TN_PART_BYTES; }
+
+int lara_layernorm256_backward(int32_t rows, const float *dy, const float *x, const float *gamma, float eps,
+                               const float *skip, float *dx, float *dgamma, float *dbeta, void *workspace,
+                               void *stream) {
+    if (rows <= 0 || !dy || !x || !gamma || !dx || !dgamma || !dbeta || !workspace) return LARA2DGS_E_INVALID;
+    return ln_bwd(dy, x, gamma, eps, skip, dx, nullptr, dgamma, dbeta, nullptr, (float *)workspace, rows, (hipStream_t)stream);
+}
+
+int lara_groupattn_core_backward(int32_t G, const uint16_t *q, const uint16_t *kv, const uint16_t *d_o, uint16_t *dq,
+                                 uint16_t *dkv, void *stream) {
+    if (G < 0) return LARA2DGS_E_INVALID;
+    if (G == 0) return LARA2DGS_OK;
+    if (!q || !kv || !d_o || !dq || !dkv) return LARA2DGS_E_INVALID;
+    hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, (hipStream_t)stream, q, kv, d_o, dq, dkv, G);
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+}  // extern "C"

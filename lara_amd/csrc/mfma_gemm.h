@@ -73,9 +73,18 @@ struct GemmP {
     const float *gamma, *beta;
     int Cout;            // EPI 5
     uint32_t zero_off;   // AMODE 1: byte offset from A of a zeroed row of Cin bf16 (the padding voxels)
+    unsigned short *C2;  // EPI 6: bf16 [M, N] pre-activation out; EPI 7: the same, read
 };
 
 // 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_exp / v_rcp
+__device__ __forceinline__ float gelu_erf_grad(const float x) {  // Phi(x) + x phi(x)
+    const float z = fabsf(x) * 0.70710678f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float ex = __expf(-z * z);
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * ex, x));
+    return cdf + x * ex * 0.3989422804f;
+}
 __device__ __forceinline__ float gelu_erf(const float x) {
     const float z = fabsf(x) * 0.70710678f;
     const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
@@ -101,6 +110,9 @@ __device__ __forceinline__ int voxel_to_token(const int b, const int d, const in
 // EPI 0: bf16 store            1: fp32 store of acc + resid        2: bf16 store of gelu(acc + bias)
 //     3: fp32 acc + bias + resid   4: fp32 LN(resid row) + acc (LN redone from stats, gamma, beta)
 //     5: fp32 acc + bias scattered as a stride-2, kernel-2 transposed convolution (N = 8 * Cout)
+// (training, gemm_bf16_nt_kernel only)
+//     6: z = acc + bias -> bf16 C2, gelu(z) -> bf16 C       7: bf16 store of acc * gelu'(C2)
+//     8: fp32 store
 template <int AMODE, int EPI, int GM = 128, int GN = 128>
 __global__ void __launch_bounds__(256)
 gemm_bf16_nt_kernel(const GemmP p) {
@@ -244,17 +256,29 @@ gemm_bf16_nt_kernel(const GemmP p) {
             if (row < M && col < N) {
                 float4 v = *(const float4 *)(ep + lr * 68 + c4);
                 const size_t o = (size_t)row * N + col;
-                if (EPI == 2 || EPI == 3) {
+                if (EPI == 2 || EPI == 3 || EPI == 6) {
                     const float4 bs = *(const float4 *)(p.bias + col);
                     v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
                 }
-                if (EPI == 0 || EPI == 2) {
-                    if (EPI == 2) {  // erf GELU (nn.GELU's default); the result is rounded to bf16 anyway
+                if (EPI == 0 || EPI == 2 || EPI == 6 || EPI == 7) {
+                    if (EPI == 6) {
+                        ushort4 z;
+                        z.x = f2bf(v.x); z.y = f2bf(v.y); z.z = f2bf(v.z); z.w = f2bf(v.w);
+                        *(ushort4 *)(p.C2 + o) = z;
+                    }
+                    if (EPI == 7) {
+                        const ushort4 z = *(const ushort4 *)(p.C2 + o);
+                        v.x *= gelu_erf_grad(bf2f(z.x)); v.y *= gelu_erf_grad(bf2f(z.y));
+                        v.z *= gelu_erf_grad(bf2f(z.z)); v.w *= gelu_erf_grad(bf2f(z.w));
+                    }
+                    if (EPI == 2 || EPI == 6) {  // erf GELU (nn.GELU's default); the result is rounded to bf16 anyway
                         v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                     }
                     ushort4 h;
                     h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
                     *(ushort4 *)((unsigned short *)p.C + o) = h;
+                } else if (EPI == 8) {
+                    *(float4 *)((float *)p.C + o) = v;
                 } else if (EPI == 1 || EPI == 3) {
                     const float4 rs = *(const float4 *)(p.resid + o);
                     *(float4 *)((float *)p.C + o) = make_float4(v.x + rs.x, v.y + rs.y, v.z + rs.z, v.w + rs.w);

@@ -1,0 +1,258 @@
+"""Training path of LaRa's volume transformer on MI355X: forward AND backward on the HIP kernels of
+``liblara2dgs.so`` (csrc/encoder.hip, csrc/encoder_bwd.hip).
+
+``VolTransformer`` here is a drop-in for the reference module of the same name
+(lightning/network.py:105-164): the same constructor arguments, the same ``forward(image_feats)``,
+and -- because it is built from the same torch sub-modules, used purely as parameter containers -- the
+same ``state_dict`` keys and fp32 master parameters, so the reference's optimiser, DDP wrapper and
+checkpoints work on it unchanged.  What changes is what runs: ``forward`` casts the weights to bf16
+(the precision the reference's matmuls run in under ``precision="bf16-mixed"``,
+train_lightning.py:74) and launches the HIP forward, saving only each layer's input rows; ``backward``
+re-runs each layer's forward inside ``lara_groupblock_backward`` and returns fp32 gradients for
+every parameter and for ``image_feats``.
+
+There is no CPU path and no torch fallback: tensors must live on the GPU and the library must load.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch import nn
+
+from .encoder import _BlockWeights, _lib as _fwd_lib, cond_tokens, tokens_to_volume, volume_to_tokens
+from .rasterizer import _check
+
+_configured = False
+
+
+class _BlockWeightsT(ctypes.Structure):  # struct lara_groupblock_weights_t
+    _fields_ = [(n, ctypes.c_void_p) for n in ("wq_t", "wkv_t", "wo_t", "w1_t", "w2_t", "wconv_t")]
+
+
+_GRAD_FIELDS = ("ln1_w", "ln1_b", "wq", "wkv", "wo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2", "ln3_w", "ln3_b", "wconv")
+
+
+class _BlockGrads(ctypes.Structure):  # struct lara_groupblock_grads
+    _fields_ = [(n, ctypes.c_void_p) for n in _GRAD_FIELDS]
+
+
+def _lib():
+    global _configured
+    lib = _fwd_lib()
+    if not _configured:
+        vp, i32, f32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_int64
+        lib.lara_groupblock_backward_workspace_bytes.restype = i64
+        lib.lara_groupblock_backward_workspace_bytes.argtypes = [i32, i32]
+        lib.lara_groupblock_backward.restype = ctypes.c_int
+        lib.lara_groupblock_backward.argtypes = [i32, i32, i32, vp, vp, ctypes.POINTER(_BlockWeights),
+                                                 ctypes.POINTER(_BlockWeightsT), vp, vp, ctypes.POINTER(_BlockGrads), vp, vp]
+        lib.lara_voltrans_head_backward_workspace_bytes.restype = i64
+        lib.lara_voltrans_head_backward_workspace_bytes.argtypes = [i32, i32, i32]
+        lib.lara_voltrans_head_backward.restype = ctypes.c_int
+        lib.lara_voltrans_head_backward.argtypes = [i32, i32, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.lara_gemm_tn_workspace_bytes.restype = i64
+        lib.lara_gemm_tn_workspace_bytes.argtypes = []
+        lib.lara_gemm_tn_bf16.restype = ctypes.c_int
+        lib.lara_gemm_tn_bf16.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp]
+        lib.lara_layernorm256_backward.restype = ctypes.c_int
+        lib.lara_layernorm256_backward.argtypes = [i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
+        lib.lara_groupattn_core_backward.restype = ctypes.c_int
+        lib.lara_groupattn_core_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+        _configured = True
+    return lib
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+_scratch = {}   # (device index, tag) -> uint8 tensor, grown on demand
+
+
+def _workspace(dev, tag: str, nbytes: int) -> torch.Tensor:
+    if nbytes < 0:
+        _check(int(nbytes), f"workspace size query ({tag})")
+    key = (dev.index, tag)
+    t = _scratch.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _scratch[key] = t
+    return t
+
+
+# per-layer parameters handed to the autograd function, in this order (reference layouts, fp32)
+_LAYER_PARAMS = ("norm1.weight", "norm1.bias", "cross_attn.q_proj_weight", "cross_attn.k_proj_weight",
+                 "cross_attn.v_proj_weight", "cross_attn.out_proj.weight", "norm2.weight", "norm2.bias",
+                 "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias", "norm3.weight", "norm3.bias", "cnn.weight")
+_NLP = len(_LAYER_PARAMS)
+
+
+def _layer_bf16(p):
+    """fp32 reference-layout parameters of one block -> (forward weights dict, transposed weights dict)."""
+    (ln1w, ln1b, wq, wk, wv, wo, ln2w, ln2b, w1, b1, w2, b2, ln3w, ln3b, wc) = p
+    bf = torch.bfloat16
+    f = {"ln1_w": ln1w.float().contiguous(), "ln1_b": ln1b.float().contiguous(),
+         "ln2_w": ln2w.float().contiguous(), "ln2_b": ln2b.float().contiguous(),
+         "ln3_w": ln3w.float().contiguous(), "ln3_b": ln3b.float().contiguous(),
+         "b1": b1.float().contiguous(), "b2": b2.float().contiguous(),
+         "wq": wq.to(bf).contiguous(), "wkv": torch.cat([wk, wv], 0).to(bf).contiguous(), "wo": wo.to(bf).contiguous(),
+         "w1": w1.to(bf).contiguous(), "w2": w2.to(bf).contiguous(),
+         # cnn.weight [out, in, kd, kh, kw] -> [out][tap][in]
+         "wconv": wc.permute(0, 2, 3, 4, 1).reshape(256, 27 * 256).to(bf).contiguous()}
+    return f
+
+
+def _layer_bf16_t(f, wc):
+    bf = torch.bfloat16
+    return {"wq_t": f["wq"].t().contiguous(), "wkv_t": f["wkv"].t().contiguous(), "wo_t": f["wo"].t().contiguous(),
+            "w1_t": f["w1"].t().contiguous(), "w2_t": f["w2"].t().contiguous(),
+            # [in][mirrored tap][out]: wconv_t[ci][t][co] = cnn.weight[co, ci, 26 - t]
+            "wconv_t": wc.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(256, 27 * 256).to(bf).contiguous()}
+
+
+def _fill(struct, tensors, names):
+    for n in names:
+        setattr(struct, n, tensors[n].data_ptr())
+    return struct
+
+
+class _VolTransFn(torch.autograd.Function):
+    """(cond fp32 [B*G^3, 4, C], eps_block, eps_final, R, out_dim, pos_embed, norm.w, norm.b, deconv.w, deconv.b,
+    15 tensors per layer ...) -> [B, 2R, 2R, 2R, out_dim]"""
+
+    @staticmethod
+    def forward(ctx, cond, eps_block, eps_final, R, out_dim, pos_embed, norm_w, norm_b, deconv_w, deconv_b, *layer_params):
+        if not cond.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        lib = _lib()
+        dev = cond.device
+        n_layers = len(layer_params) // _NLP
+        G3 = (R // 2) ** 3
+        B = cond.shape[0] // G3
+        M = B * R ** 3
+        cond_dim = cond.shape[2]
+        cond_bf = cond.detach().to(torch.bfloat16).contiguous()
+        x = volume_to_tokens(pos_embed.detach().float()).repeat(B, 1)       # network.py:152
+        saved_x = []
+        ws = _workspace(dev, "fwd", lib.lara_groupblock_workspace_bytes(B, R))
+        with torch.cuda.device(dev):
+            for l in range(n_layers):
+                saved_x.append(x.clone())
+                f = _layer_bf16([t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]])
+                w = _fill(_BlockWeights(), f, ("ln1_w", "ln1_b", "wq", "wkv", "wo", "ln2_w", "ln2_b", "w1", "b1", "w2",
+                                               "b2", "ln3_w", "ln3_b", "wconv"))
+                w.eps = eps_block
+                _check(lib.lara_groupblock_forward(B, R, cond_dim, x.data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
+                                                   ws.data_ptr(), _stream(dev)), "lara_groupblock_forward")
+            wd = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).contiguous()
+            nw, nb, db = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous(), deconv_b.detach().float().contiguous()
+            out = torch.empty(B, 2 * R, 2 * R, 2 * R, out_dim, dtype=torch.float32, device=dev)
+            hws = _workspace(dev, "head", M * 512)
+            _check(lib.lara_voltrans_head_forward(B, R, x.data_ptr(), nw.data_ptr(), nb.data_ptr(), float(eps_final),
+                                                  wd.data_ptr(), db.data_ptr(), out_dim, out.data_ptr(), hws.data_ptr(),
+                                                  _stream(dev)), "lara_voltrans_head_forward")
+        ctx.save_for_backward(cond_bf, x, pos_embed, norm_w, norm_b, deconv_w, *saved_x, *layer_params)
+        ctx.meta = (float(eps_block), float(eps_final), R, out_dim, B, n_layers, cond_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib()
+        eps_block, eps_final, R, out_dim, B, n_layers, cond_dim = ctx.meta
+        sv = ctx.saved_tensors
+        cond_bf, x_last, pos_embed, norm_w, norm_b, deconv_w = sv[:6]
+        saved_x = sv[6:6 + n_layers]
+        layer_params = sv[6 + n_layers:]
+        dev = cond_bf.device
+        M = B * R ** 3
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = dout.float().contiguous()
+        g = torch.empty(M, 256, **f32)
+        d_nw, d_nb = torch.zeros(256, **f32), torch.zeros(256, **f32)
+        d_wd, d_b8 = torch.zeros(8 * out_dim, 256, **f32), torch.zeros(8 * out_dim, **f32)
+        dcond = torch.zeros(cond_bf.shape, **f32)
+        grads = [None] * (n_layers * _NLP)
+        with torch.cuda.device(dev):
+            wd_t = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).t().contiguous()
+            nw, nb = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous()
+            hws = _workspace(dev, "head_bwd", lib.lara_voltrans_head_backward_workspace_bytes(B, R, out_dim))
+            _check(lib.lara_voltrans_head_backward(B, R, x_last.data_ptr(), nw.data_ptr(), nb.data_ptr(), eps_final,
+                                                   wd_t.data_ptr(), out_dim, dout.data_ptr(), g.data_ptr(), d_nw.data_ptr(),
+                                                   d_nb.data_ptr(), d_wd.data_ptr(), d_b8.data_ptr(), hws.data_ptr(),
+                                                   _stream(dev)), "lara_voltrans_head_backward")
+            ws = _workspace(dev, "block_bwd", lib.lara_groupblock_backward_workspace_bytes(B, R))
+            for l in reversed(range(n_layers)):
+                p = [t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]]
+                f = _layer_bf16(p)
+                ft = _layer_bf16_t(f, p[14])
+                w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
+                w.eps = eps_block
+                wt = _fill(_BlockWeightsT(), ft, ("wq_t", "wkv_t", "wo_t", "w1_t", "w2_t", "wconv_t"))
+                gd = {n: torch.zeros(f[n].shape, **f32) for n in _GRAD_FIELDS}
+                dw = _fill(_BlockGrads(), gd, _GRAD_FIELDS)
+                _check(lib.lara_groupblock_backward(B, R, cond_dim, saved_x[l].data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
+                                                    ctypes.byref(wt), g.data_ptr(), dcond.data_ptr(), ctypes.byref(dw),
+                                                    ws.data_ptr(), _stream(dev)), "lara_groupblock_backward")
+                grads[l * _NLP:(l + 1) * _NLP] = [
+                    gd["ln1_w"], gd["ln1_b"], gd["wq"], gd["wkv"][:256], gd["wkv"][256:], gd["wo"], gd["ln2_w"], gd["ln2_b"],
+                    gd["w1"], gd["b1"], gd["w2"], gd["b2"], gd["ln3_w"], gd["ln3_b"],
+                    gd["wconv"].view(256, 3, 3, 3, 256).permute(0, 4, 1, 2, 3)]
+            # the same positional rows enter every scene (network.py:152)
+            d_pos = tokens_to_volume(g.view(B, R ** 3, 256).sum(0), 1, R)
+        d_deconv_w = d_wd.view(2, 2, 2, out_dim, 256).permute(4, 3, 0, 1, 2)
+        d_deconv_b = d_b8.view(8, out_dim).sum(0)
+        return (dcond, None, None, None, None, d_pos, d_nw, d_nb, d_deconv_w, d_deconv_b, *grads)
+
+
+class GroupAttBlock(nn.Module):
+    """Parameter container with the reference's attribute names (network.py:57-79)."""
+
+    def __init__(self, inner_dim: int, cond_dim: int, num_heads: int, eps: float = 1e-5, attn_drop: float = 0.,
+                 attn_bias: bool = False, mlp_ratio: float = 2., mlp_drop: float = 0.):
+        super().__init__()
+        if inner_dim != 256 or num_heads != 16 or attn_bias or mlp_ratio != 2. or attn_drop or mlp_drop:
+            raise ValueError("kernels are specialised for LaRa's 256-dim, 16-head, bias-free, dropout-free blocks "
+                             "(configs/base.yaml:17-20)")
+        self.norm1 = nn.LayerNorm(inner_dim)
+        self.cross_attn = nn.MultiheadAttention(embed_dim=inner_dim, num_heads=num_heads, kdim=cond_dim, vdim=cond_dim,
+                                                dropout=attn_drop, bias=attn_bias, batch_first=True)
+        self.cnn = nn.Conv3d(inner_dim, inner_dim, kernel_size=3, padding=1, bias=False)
+        self.norm2 = nn.LayerNorm(inner_dim)
+        self.norm3 = nn.LayerNorm(inner_dim)
+        self.mlp = nn.Sequential(nn.Linear(inner_dim, int(inner_dim * mlp_ratio)), nn.GELU(), nn.Dropout(mlp_drop),
+                                 nn.Linear(int(inner_dim * mlp_ratio), inner_dim), nn.Dropout(mlp_drop))
+
+    def flat_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in _LAYER_PARAMS]
+
+
+class VolTransformer(nn.Module):
+    """Trainable drop-in for the reference ``VolTransformer`` (network.py:105-164): same constructor, same
+    ``state_dict``, ``forward(image_feats [B, n_views, C, D, H, W]) -> [B, 2R, 2R, 2R, out_dim]``."""
+
+    def __init__(self, embed_dim: int, image_feat_dim: int, n_groups: list, vol_low_res: int, vol_high_res: int,
+                 out_dim: int, num_layers: int, num_heads: int, eps: float = 1e-6):
+        super().__init__()
+        if len(n_groups) != 1 or vol_low_res != 2 * n_groups[0] or vol_high_res != 2 * vol_low_res or out_dim % 16:
+            raise ValueError("kernels are specialised for one group size with block_size 2 and a x2 deconvolution "
+                             "(configs/base.yaml: n_groups [16], vol 32 -> 64)")
+        self.vol_low_res, self.vol_high_res, self.out_dim, self.n_groups = vol_low_res, vol_high_res, out_dim, list(n_groups)
+        self.embed_dim = embed_dim
+        self.pos_embed = nn.Parameter(torch.randn(1, embed_dim, vol_low_res, vol_low_res, vol_low_res) * (1. / embed_dim) ** 0.5)
+        self.layers = nn.ModuleList([GroupAttBlock(inner_dim=embed_dim, cond_dim=image_feat_dim, num_heads=num_heads, eps=eps)
+                                     for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(embed_dim, eps=eps)
+        self.deconv = nn.ConvTranspose3d(embed_dim, out_dim, kernel_size=2, stride=2, padding=0)
+
+    def forward(self, image_feats: torch.Tensor) -> torch.Tensor:
+        if not image_feats.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        B, V, C, D = image_feats.shape[:4]
+        if D != self.n_groups[0] or V != 4:
+            raise RuntimeError("kernels are specialised for one image-feature voxel per group and 4 input views")
+        cond = image_feats.float().permute(0, 3, 4, 5, 1, 2).reshape(B * D ** 3, V, C)   # network.py:145-150
+        flat = [p for layer in self.layers for p in layer.flat_params()]
+        return _VolTransFn.apply(cond, float(self.layers[0].norm1.eps), float(self.norm.eps), self.vol_low_res, self.out_dim,
+                                 self.pos_embed, self.norm.weight, self.norm.bias, self.deconv.weight, self.deconv.bias, *flat)
