@@ -32,20 +32,21 @@ namespace {
 struct TnP {
     const unsigned short *A, *B;
     float *part;     // [splits][N][T * Kc]
-    const int *nbr;  // GATHER: [T][M] rows of B
-    int M, lda, ldb, N, Kc, T, chunk;
+    const int *nbr;  // GATHER: [T][M] byte offsets of the B rows
+    int M, lda, ldb, N, Kc, T, chunk, tiles;
 };
 
-__device__ __forceinline__ bf16x8 pack_lo(const uint32_t *w) {
+// v_perm_b32 picks bytes of {S0 (bytes 4-7), S1 (bytes 0-3)}: one instruction per fragment dword
+__device__ __forceinline__ bf16x8 pack_lo(const uint32_t *w) {  // the low halves of 8 dwords
     union { uint32_t u[4]; bf16x8 v; } r;
 #pragma unroll
-    for (int d = 0; d < 4; d++) r.u[d] = (w[2 * d] & 0xffffu) | (w[2 * d + 1] << 16);
+    for (int d = 0; d < 4; d++) r.u[d] = __builtin_amdgcn_perm(w[2 * d + 1], w[2 * d], 0x05040100u);
     return r.v;
 }
-__device__ __forceinline__ bf16x8 pack_hi(const uint32_t *w) {
+__device__ __forceinline__ bf16x8 pack_hi(const uint32_t *w) {  // the high halves
     union { uint32_t u[4]; bf16x8 v; } r;
 #pragma unroll
-    for (int d = 0; d < 4; d++) r.u[d] = (w[2 * d] >> 16) | (w[2 * d + 1] & 0xffff0000u);
+    for (int d = 0; d < 4; d++) r.u[d] = __builtin_amdgcn_perm(w[2 * d + 1], w[2 * d], 0x07060302u);
     return r.v;
 }
 
@@ -54,14 +55,26 @@ __global__ void __launch_bounds__(256)
 gemm_bf16_tn_kernel(const TnP p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, kh = lane >> 5;
+    // Workgroup -> (tile, split), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each
+    // with its own L2), so id L runs on XCD L % 8.  All tiles of one split read the SAME token rows (for the
+    // convolution: the same A rows under every tap, and B rows from the same 4x4x4 voxel neighbourhoods), so a
+    // split's tiles are dealt to one XCD, where they run side by side and share those rows through its L2
+    // instead of each pulling them over the fabric (27 x 4 tiles: 7.2 GB of operand reads per launch).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // (the integer division runs on the vector unit: tell the compiler its result is wave-uniform)
+    const int sq = __builtin_amdgcn_readfirstlane(slot / p.tiles);
+    const int tile = slot - sq * p.tiles, split = sq * 8 + xcd;
     const int ctiles = (p.Kc + 127) / 128 * p.T;  // column tiles (a tile never straddles two taps)
-    const int ct = blockIdx.x % ctiles, nt = blockIdx.x / ctiles;
+    const int ct = tile % ctiles, nt = tile / ctiles;
     const int tpt = (p.Kc + 127) / 128;  // tiles per tap
     const int tap = ct / tpt, kc0 = (ct - tap * tpt) * 128;
     const int nbase = nt * 128 + (wave >> 1) * 64, kbase = kc0 + (wave & 1) * 64;
     const int an = min(nbase + 2 * r, p.N - 2), bk = min(kbase + 2 * r, p.Kc - 2);
-    const int m_start = blockIdx.y * p.chunk, m_end = min(p.M, m_start + p.chunk);
-    const unsigned short *Ap = p.A + an, *Bp = p.B + bk;
+    const int m_start = split * p.chunk, m_end = min(p.M, m_start + p.chunk);
+    // operands are < 4 GB: a uniform base + 32-bit byte offsets per lane (24-bit multiplies for the gathered
+    // rows, running adds for the dense ones) -- 64-bit address arithmetic was 2/3 of this loop's VALU work
+    const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
+    const uint32_t lda2 = (uint32_t)p.lda * 2u, ldb2 = (uint32_t)p.ldb * 2u, bcol = (uint32_t)bk * 2u;
     const int *nb = GATHER ? p.nbr + (size_t)tap * p.M : nullptr;
 
     f32x16 acc[2][2];
@@ -72,39 +85,77 @@ gemm_bf16_tn_kernel(const TnP p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    uint32_t wa[8], wb[8], na[8], nbv[8];
-    auto load = [&](const int m0, uint32_t *a, uint32_t *b) {
-        const int row0 = m0 + 8 * kh;
-        int rows[8];
+    // per-lane byte offsets of the 8 rows of its k-slice inside a 16-row slice; the slice itself advances
+    // through a uniform (scalar) base pointer, so the loop has no per-lane address arithmetic for dense operands
+    uint32_t offa[8], offb[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        offa[e] = (uint32_t)(8 * kh + e) * lda2 + (uint32_t)an * 2u;
+        offb[e] = (uint32_t)(8 * kh + e) * ldb2 + bcol;
+    }
+    uint32_t a0[8], b0[8], a1[8], b1[8], a2[8], b2[8], a3[8], b3[8];
+    // Gathered rows: the 16 table entries of a slice (byte offsets of B rows) are wave-uniform (two groups of 8:
+    // k-slices 0 and 1), so they come through the scalar cache (s_load, its own counter: waiting for them does
+    // not drain the vector loads in flight) one slice ahead of their use.
+    int tn[16];
+    auto table = [&](const int m0) {
+        const int *t = nb + min(m0, p.M - 16);
+#pragma unroll
+        for (int e = 0; e < 16; e++) tn[e] = t[e];
+    };
+    if (GATHER) table(m_start);
+    // buffer loads: base in a scalar resource descriptor, per-lane offset register that never changes, and the
+    // slice offset in the scalar offset operand
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)Ab, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)Bb, 0, -1, 0x00020000);
+    auto load = [&](const int m0, uint32_t *a, uint32_t *b) {  // slices in order (the table runs one ahead)
+        const int sa = (int)((uint32_t)m0 * lda2), sb = GATHER ? 0 : (int)((uint32_t)m0 * ldb2);
         if (GATHER) {
-            const int4 i0 = *(const int4 *)(nb + row0), i1 = *(const int4 *)(nb + row0 + 4);
-            rows[0] = i0.x; rows[1] = i0.y; rows[2] = i0.z; rows[3] = i0.w;
-            rows[4] = i1.x; rows[5] = i1.y; rows[6] = i1.z; rows[7] = i1.w;
+#pragma unroll
+            for (int e = 0; e < 8; e++) offb[e] = (uint32_t)(kh ? tn[8 + e] : tn[e]) + bcol;
+            table(m0 + 16);
         }
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            a[e] = *(const uint32_t *)(Ap + (size_t)(row0 + e) * p.lda);
-            b[e] = *(const uint32_t *)(Bp + (size_t)(GATHER ? rows[e] : row0 + e) * p.ldb);
+            a[e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)offa[e], sa, 0);
+            b[e] = __builtin_amdgcn_raw_buffer_load_b32(rb, (int)offb[e], sb, 0);
         }
     };
-    if (m_start < m_end) load(m_start, wa, wb);
-    for (int m0 = m_start; m0 < m_end; m0 += 16) {
-        const bool more = m0 + 16 < m_end;
-        if (more) load(m0 + 16, na, nbv);  // in flight while this slice is multiplied
-        const bf16x8 a0 = pack_lo(wa), a1 = pack_hi(wa), b0 = pack_lo(wb), b1 = pack_hi(wb);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        if (more) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) { wa[e] = na[e]; wb[e] = nbv[e]; }
-        }
+    auto mma = [&](const uint32_t *a, const uint32_t *b) {
+        const bf16x8 fa0 = pack_lo(a), fa1 = pack_hi(a), fb0 = pack_lo(b), fb1 = pack_hi(b);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    };
+    // Four register sets: three 16-row slices are in flight while one is multiplied.  With ~3 waves per SIMD
+    // (64 accumulator + ~100 vector registers) one slice of look-ahead left the matrix cores waiting on HBM
+    // latency most of the time.
+    const int steps = max(0, (m_end - m_start + 15) >> 4), full = steps & ~3;  // (a split may start beyond M)
+    if (full > 0) {
+        load(m_start, a0, b0);
+        load(m_start + 16, a1, b1);
+        load(m_start + 32, a2, b2);
+    }
+    for (int i = 0; i < full; i += 4) {
+        const bool more = i + 4 < full;
+        load(m_start + 16 * (i + 3), a3, b3);
+        mma(a0, b0);
+        if (more) load(m_start + 16 * (i + 4), a0, b0);
+        mma(a1, b1);
+        if (more) load(m_start + 16 * (i + 5), a1, b1);
+        mma(a2, b2);
+        if (more) load(m_start + 16 * (i + 6), a2, b2);
+        mma(a3, b3);
+    }
+    for (int i = full; i < steps; i++) {  // at most three left-over slices (the last split of a ragged M)
+        load(m_start + 16 * i, a0, b0);
+        mma(a0, b0);
     }
     // accumulator (ta, tb)[reg]: A column nbase + 2 i + ta with i = (reg&3) + 8 (reg>>2) + 4 kh, B column
     // kbase + 2 (lane&31) + tb: the two tb's of a lane are neighbours -> float2 stores
     const int ldc = p.T * p.Kc;
-    float *out = p.part + (size_t)blockIdx.y * p.N * ldc + (size_t)tap * p.Kc;
+    float *out = p.part + (size_t)split * p.N * ldc + (size_t)tap * p.Kc;
     const int col = kbase + 2 * r;
     if (col < p.Kc) {
 #pragma unroll
@@ -117,23 +168,49 @@ gemm_bf16_tn_kernel(const TnP p) {
     }
 }
 
-// dst[i] += sum over parts of part[s * stride + i]; 64 elements per workgroup, 4 slices of the parts
-__global__ void __launch_bounds__(256)
+// dst[i] += sum over parts of part[s * stride + i]; 64 elements per workgroup, blockDim / 64 slices of the
+// parts (256 threads when there are many elements and few parts, 1024 for the opposite)
+__global__ void __launch_bounds__(1024)
 accum_partials_kernel(float *__restrict__ dst, const float *__restrict__ part, const int n, const int parts,
                       const size_t stride) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, nsl = blockDim.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < n)
-        for (int q = sl; q < parts; q += 4) s += part[(size_t)q * stride + c];
-    red[sl][threadIdx.x & 63] = s;
+        for (int q = sl; q < parts; q += nsl) s += part[(size_t)q * stride + c];
+    red[sl][lane] = s;
     __syncthreads();
-    if (sl == 0 && c < n) dst[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sl == 0 && c < n) {
+        float t = red[0][lane];
+        for (int k = 1; k < nsl; k++) t += red[k][lane];
+        dst[c] += t;
+    }
 }
 
-// nbr[tap][m] = token row of voxel(m) + (dz, dy, dx), or `zero_row` outside the volume
+// the three column sums of ln_bwd_kernel's partials in one launch: blockIdx.y = quantity (its dst may be null)
+__global__ void __launch_bounds__(1024)
+accum_ln_partials_kernel(float *d0, float *d1, float *d2, const float *__restrict__ part, const int parts) {
+    __shared__ float red[16][64];
+    float *dst = blockIdx.y == 0 ? d0 : blockIdx.y == 1 ? d1 : d2;
+    if (!dst) return;
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    for (int q = sl; q < parts; q += 16) s += part[(size_t)q * 768 + blockIdx.y * 256 + c];
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t = red[0][lane];
+        for (int k = 1; k < 16; k++) t += red[k][lane];
+        dst[c] += t;
+    }
+}
+
+// nbr[tap][m] = BYTE offset (rows of `row_bytes`) of the token row of voxel(m) + (dz, dy, dx), or of row
+// `zero_row` outside the volume
 __global__ void __launch_bounds__(256)
-neighbour_table_kernel(int *__restrict__ nbr, const int M, const int R, const int zero_row) {
+neighbour_table_kernel(int *__restrict__ nbr, const int M, const int R, const int zero_row, const int row_bytes) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     int b, d, h, w;
@@ -141,15 +218,16 @@ neighbour_table_kernel(int *__restrict__ nbr, const int M, const int R, const in
     for (int tap = 0; tap < 27; tap++) {
         const int nd = d + tap / 9 - 1, nh = h + (tap / 3) % 3 - 1, nw = w + tap % 3 - 1;
         const bool in = (unsigned)nd < (unsigned)R && (unsigned)nh < (unsigned)R && (unsigned)nw < (unsigned)R;
-        nbr[(size_t)tap * M + m] = in ? voxel_to_token(b, nd, nh, nw, R) : zero_row;
+        nbr[(size_t)tap * M + m] = (in ? voxel_to_token(b, nd, nh, nw, R) : zero_row) * row_bytes;
     }
 }
 
-// ---- LayerNorm(256) backward: one wave per row, 16 rows per wave, 64 rows per workgroup ---------------
+// ---- LayerNorm(256) backward: one wave per row, 32 rows per wave, 128 rows per workgroup --------------
 // dx = rstd (a - mean(a) - xhat mean(a xhat)), a = dy gamma;  out = dx (+ skip) as fp32 and, optionally,
 // bf16; per-workgroup partial column sums of dy xhat (dgamma), dy (dbeta) and out (the bias gradient of
 // the linear layer that produced the LayerNorm's input) go to part[block][3][256].
-// dx_out may alias dy or skip (a lane reads its own four elements before it writes them).
+// dx_out may alias dy or skip (same element only): a row's loads are issued before the previous row's stores.
+constexpr int LNB_ROWS = 128;
 __global__ void __launch_bounds__(256)
 ln_bwd_kernel(const float *dy, const float *__restrict__ x, const float *__restrict__ gamma, const float eps,
               const float *skip, float *dx_out, unsigned short *__restrict__ dx_bf16, float *__restrict__ part,
@@ -158,11 +236,23 @@ ln_bwd_kernel(const float *dy, const float *__restrict__ x, const float *__restr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float4 g = ((const float4 *)gamma)[lane];
     float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, po[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < 16; i++) {
-        const int tok = blockIdx.x * 64 + wave * 16 + i;
-        if (tok >= tokens) break;
-        const float4 v = ((const float4 *)(x + (size_t)tok * 256))[lane];
-        const float4 d = ((const float4 *)(dy + (size_t)tok * 256))[lane];
+    const int tok0 = blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
+    const int nrow = min(LNB_ROWS / 4, tokens - tok0);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 vn = z4, dn = z4, kn = z4;
+    if (nrow > 0) {
+        vn = ((const float4 *)(x + (size_t)tok0 * 256))[lane];
+        dn = ((const float4 *)(dy + (size_t)tok0 * 256))[lane];
+        if (skip) kn = ((const float4 *)(skip + (size_t)tok0 * 256))[lane];
+    }
+    for (int i = 0; i < nrow; i++) {
+        const int tok = tok0 + i;
+        const float4 v = vn, d = dn, k = kn;
+        if (i + 1 < nrow) {
+            vn = ((const float4 *)(x + (size_t)(tok + 1) * 256))[lane];
+            dn = ((const float4 *)(dy + (size_t)(tok + 1) * 256))[lane];
+            if (skip) kn = ((const float4 *)(skip + (size_t)(tok + 1) * 256))[lane];
+        }
         float s = v.x + v.y + v.z + v.w;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -178,12 +268,8 @@ ln_bwd_kernel(const float *dy, const float *__restrict__ x, const float *__restr
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sh += __shfl_xor(sh, o, 64); }
         sa *= (1.0f / 256.0f); sh *= (1.0f / 256.0f);
-        float4 r = make_float4(rstd * (a0 - sa - h0 * sh), rstd * (a1 - sa - h1 * sh), rstd * (a2 - sa - h2 * sh),
-                               rstd * (a3 - sa - h3 * sh));
-        if (skip) {
-            const float4 k = ((const float4 *)(skip + (size_t)tok * 256))[lane];
-            r.x += k.x; r.y += k.y; r.z += k.z; r.w += k.w;
-        }
+        const float4 r = make_float4(rstd * (a0 - sa - h0 * sh) + k.x, rstd * (a1 - sa - h1 * sh) + k.y,
+                                     rstd * (a2 - sa - h2 * sh) + k.z, rstd * (a3 - sa - h3 * sh) + k.w);
         ((float4 *)(dx_out + (size_t)tok * 256))[lane] = r;
         if (dx_bf16) {
             ushort4 hb;
@@ -355,17 +441,23 @@ inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, int ldb, int Kc, int T, const int *nbr,
             int M, float *dst, float *part, hipStream_t s) {
     if ((M & 15) || (N & 1) || (Kc & 1) || (T > 1 && (Kc & 127))) return LARA2DGS_E_INVALID;
+    // 32-bit byte offsets and 24-bit row multiplies in the kernel
+    if ((size_t)(M + 1) * lda * 2 >= (1ull << 32) || (size_t)(M + 1) * ldb * 2 >= (1ull << 32) || M >= (1 << 24) || ldb >= (1 << 23))
+        return LARA2DGS_E_INVALID;
     const int tiles = ((N + 127) / 128) * ((Kc + 127) / 128) * T;
     const size_t out_bytes = (size_t)N * T * Kc * 4;
-    // about 1024 workgroups per launch, at least 512 token rows each (a split costs a partial tile)
-    int splits = max(1, min(min(max(1, 1024 / tiles), (int)(TN_PART_BYTES / out_bytes)), M / 512));
-    const int chunk = (((M + splits - 1) / splits) + 15) & ~15;
-    splits = (M + chunk - 1) / chunk;
+    // about 768 workgroups per launch (3 per CU = what the registers allow: one round), in multiples of 8
+    // splits (one per XCD, see the kernel), at least 256 token rows each; a split that starts beyond M writes zeros
+    int splits = max(1, min(768 / tiles, (int)(TN_PART_BYTES / out_bytes)));
+    splits = max(8, splits & ~7);
+    while (splits > 8 && M / splits < 256) splits -= 8;
+    const int chunk = (((M + splits - 1) / splits) + 63) & ~63;
     TnP p{};
     p.A = A; p.B = B; p.part = part; p.nbr = nbr; p.M = M; p.lda = lda; p.ldb = ldb; p.N = N; p.Kc = Kc; p.T = T;
-    p.chunk = chunk;
-    if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), dim3(tiles, splits), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles, splits), dim3(256), 0, s, p);
+    p.chunk = chunk; p.tiles = tiles;
+    if ((size_t)splits * out_bytes > TN_PART_BYTES) return LARA2DGS_E_INVALID;
+    if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
     const int n = N * T * Kc;
     hipLaunchKernelGGL(accum_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
@@ -374,19 +466,16 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
 // LayerNorm backward + the reductions of its partial sums into dgamma, dbeta, dbias (any may be null)
 int ln_bwd(const float *dy, const float *x, const float *gamma, float eps, const float *skip, float *dx,
            unsigned short *dx_bf16, float *dgamma, float *dbeta, float *dbias, float *part, int M, hipStream_t s) {
-    const int blocks = (M + 63) / 64;
+    const int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, x, gamma, eps, skip, dx, dx_bf16, part, M);
-    float *dst[3] = {dgamma, dbeta, dbias};
-    for (int k = 0; k < 3; k++)
-        if (dst[k])
-            hipLaunchKernelGGL(accum_partials_kernel, dim3(4), dim3(256), 0, s, dst[k], part + k * 256, 256, blocks, (size_t)768);
+    hipLaunchKernelGGL(accum_ln_partials_kernel, dim3(4, 3), dim3(1024), 0, s, dgamma, dbeta, dbias, part, blocks);
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
 }
 
 int colsum_bf16(const unsigned short *src, int rows, int C, float *dst, float *part, hipStream_t s) {
     const int blocks = (rows + 63) / 64;
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks), dim3(256), 0, s, src, part, rows, C);
-    hipLaunchKernelGGL(accum_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dst, part, C, blocks, (size_t)C);
+    hipLaunchKernelGGL(accum_partials_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, dst, part, C, blocks, (size_t)C);
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
 }
 
@@ -483,42 +572,60 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
         hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x2, w->ln3_w, w->ln3_b, w->eps, xn3, (float2 *)nullptr, M);
         if (hipMemsetAsync(xn3 + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
         if (hipMemsetAsync(gb + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
-        hipLaunchKernelGGL(neighbour_table_kernel, dim3((M + 255) / 256), dim3(256), 0, s, nbr, M, R, M);
+        hipLaunchKernelGGL(neighbour_table_kernel, dim3((M + 255) / 256), dim3(256), 0, s, nbr, M, R, M, 512);
     }
     L2D_CHECK_LAUNCH();
     // ---- x_out = pn + cnn(pn), pn = norm3(x2)  (network.py:94-100) ----
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, g, gb, (size_t)M * 64);
     {
-        L2D_PROF("gbb_conv", s);
-        hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, g, gb, (size_t)M * 64);
+        L2D_PROF("gbb_dw_conv", s);
         if ((rc = gemm_tn(gb, 256, 256, xn3, 256, 256, 27, nbr, M, dw->wconv, tnpart, s))) return rc;
+    }
+    {
+        L2D_PROF("gbb_dx_conv", s);
         GemmP p{};  // d pn = g + cnn^T(g): the same implicit GEMM with the taps mirrored and in/out swapped
         p.A = gb; p.W = wt->wconv_t; p.C = g; p.resid = g; p.M = M; p.N = 256; p.K = 27 * 256;
         p.R = R; p.Cin = 256; p.zero_off = (uint32_t)((size_t)M * 512);
         if (launch_gemm_ring<1, 1>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    }
+    {
+        L2D_PROF("gbb_ln_bwd", s);
         if ((rc = ln_bwd(g, x2, w->ln3_w, w->eps, nullptr, g, gb, dw->ln3_w, dw->ln3_b, dw->b2, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x2 = x1 + mlp(norm2(x1)) ----
     {
-        L2D_PROF("gbb_mlp", s);
+        L2D_PROF("gbb_dx_mlp", s);
         gemm_nt<7>(gb, wt->w2_t, dzb, M, 512, 256, nullptr, z, s);  // dz = (g2 W2) * gelu'(z)
-        if ((rc = gemm_tn(gb, 256, 256, h, 512, 512, 1, nullptr, M, dw->w2, tnpart, s))) return rc;
-        if ((rc = colsum_bf16(dzb, M, 512, dw->b1, lnpart, s))) return rc;
-        if ((rc = gemm_tn(dzb, 512, 512, xn2, 256, 256, 1, nullptr, M, dw->w1, tnpart, s))) return rc;
         gemm_nt<8>(dzb, wt->w1_t, tmpf, M, 256, 512, nullptr, nullptr, s);
+    }
+    {
+        L2D_PROF("gbb_dw_mlp", s);
+        if ((rc = gemm_tn(gb, 256, 256, h, 512, 512, 1, nullptr, M, dw->w2, tnpart, s))) return rc;
+        if ((rc = gemm_tn(dzb, 512, 512, xn2, 256, 256, 1, nullptr, M, dw->w1, tnpart, s))) return rc;
+        if ((rc = colsum_bf16(dzb, M, 512, dw->b1, lnpart, s))) return rc;
+    }
+    {
+        L2D_PROF("gbb_ln_bwd", s);
         if ((rc = ln_bwd(tmpf, x1, w->ln2_w, w->eps, g, g, gb, dw->ln2_w, dw->ln2_b, nullptr, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x1 = x0 + cross_attn(norm1(x0), cond, cond) ----
     {
-        L2D_PROF("gbb_attn", s);
+        L2D_PROF("gbb_dx_attn", s);
         gemm_nt<0>(gb, wt->wo_t, dob, M, 256, 256, nullptr, nullptr, s);
-        if ((rc = gemm_tn(gb, 256, 256, o, 256, 256, 1, nullptr, M, dw->wo, tnpart, s))) return rc;
         hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, s, q, kv, dob, dq, dkv, G);
-        if ((rc = gemm_tn(dq, 256, 256, xn1, 256, 256, 1, nullptr, M, dw->wq, tnpart, s))) return rc;
-        if ((rc = gemm_tn(dkv, 512, 512, cond_bf16, cond_dim, cond_dim, 1, nullptr, Mkv, dw->wkv, tnpart, s))) return rc;
         gemm_nt<1>(dkv, wt->wkv_t, dcond, Mkv, cond_dim, 512, dcond, nullptr, s);
         gemm_nt<8>(dq, wt->wq_t, tmpf, M, 256, 256, nullptr, nullptr, s);
+    }
+    {
+        L2D_PROF("gbb_dw_attn", s);
+        if ((rc = gemm_tn(gb, 256, 256, o, 256, 256, 1, nullptr, M, dw->wo, tnpart, s))) return rc;
+        if ((rc = gemm_tn(dq, 256, 256, xn1, 256, 256, 1, nullptr, M, dw->wq, tnpart, s))) return rc;
+        if ((rc = gemm_tn(dkv, 512, 512, cond_bf16, cond_dim, cond_dim, 1, nullptr, Mkv, dw->wkv, tnpart, s))) return rc;
+    }
+    {
+        L2D_PROF("gbb_ln_bwd", s);
         if ((rc = ln_bwd(tmpf, x_in, w->ln1_w, w->eps, g, g, nullptr, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
