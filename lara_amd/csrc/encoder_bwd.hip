@@ -168,6 +168,139 @@ gemm_bf16_tn_kernel(const TnP p) {
     }
 }
 
+// ---- the same product, operands staged through LDS --------------------------------------------------------
+// The direct kernel above spends its time in the texture path: sixteen 4-byte loads per lane and 16-row slice,
+// every operand column fetched by two waves (rocprof: 57 M vector-memory instructions and 228 M L1 accesses per
+// convolution weight gradient, matrix cores 18 % busy).  Here a stage of 32 token rows x 128 columns of each
+// operand (2 x 8 KB) travels global -> LDS with global_load_lds_dwordx4 (row-major image, four 1 KB pieces per
+// wave and stage), and the k-strided fragments come out of LDS with gfx950's transposing read
+// ds_read_b64_tr_b16: the 16 lanes of a group pass the addresses of a [4 rows][16 columns] block (lane l: row
+// l >> 2, columns 4 (l & 3) ..+3) and lane l receives column l of the four rows -- half of an MFMA fragment
+// (measured with tools/ubench/tr_read.hip).  LDS rows are 256 B = one bank row, so the 16-byte chunk index is
+// XORed with (row & 3) << 2 on the DMA source address and on the reads: the 4 rows x 64 B that 32 lanes touch
+// then cover all 64 banks once.  Two stages of 16 KB (the next one is in flight while this one is multiplied; 32 KB
+// per workgroup keeps four workgroups per CU, so the 108 x 8 tiles of the convolution run as one round), one
+// barrier per stage (8 MFMAs per wave).
+// Needs M % 32 == 0 and 16-byte aligned rows (lda, ldb, N, Kc multiples of 8); the host falls back to the
+// direct kernel otherwise.  Same workgroup -> (tile, split) mapping, same partial-tile output.
+constexpr int TL_ROWS = 32, TL_STAGES = 2, TL_TILE = TL_ROWS * 256, TL_STAGE = 2 * TL_TILE;
+
+template <bool GATHER>
+__global__ void __launch_bounds__(256)
+gemm_bf16_tn_lds_kernel(const TnP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TL_STAGES * TL_STAGE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int sq = __builtin_amdgcn_readfirstlane(slot / p.tiles);
+    const int tile = slot - sq * p.tiles, split = sq * 8 + xcd;
+    const int tpt = (p.Kc + 127) / 128, ctiles = tpt * p.T;
+    const int ct = tile % ctiles, nt = tile / ctiles;
+    const int tap = ct / tpt, kc0 = (ct - tap * tpt) * 128;
+    const int m_start = split * p.chunk, m_end = min(p.M, m_start + p.chunk);
+    const int nst = max(0, (m_end - m_start) / TL_ROWS);  // chunk and M are multiples of 32
+    const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
+    const uint32_t lda2 = (uint32_t)p.lda * 2u, ldb2 = (uint32_t)p.ldb * 2u;
+    const int *nb = GATHER ? p.nbr + (size_t)tap * p.M : nullptr;
+
+    // DMA: wave w moves rows 8w .. 8w+7 of a stage, as two 4-row pieces per operand; lane L lands in row
+    // 4 piece + (L >> 4), physical chunk L & 15, and fetches the logical chunk (L & 15) ^ ((row & 3) << 2)
+    const int drow = lane >> 4;  // row within a piece == row & 3
+    const int dchunk = (lane & 15) ^ (drow << 2);
+    const uint32_t acol2 = (uint32_t)min(nt * 128 + dchunk * 8, p.N - 8) * 2u;
+    const uint32_t bcol2 = (uint32_t)min(kc0 + dchunk * 8, p.Kc - 8) * 2u;
+    int tn[8];  // GATHER: byte offsets of this wave's 8 B rows of the next stage to be issued
+    auto table = [&](const int st) {
+        const int *t = nb + min(m_start + st * TL_ROWS, p.M - TL_ROWS) + 8 * wave;
+#pragma unroll
+        for (int e = 0; e < 8; e++) tn[e] = t[e];
+    };
+    auto issue = [&](const int st) {  // this wave's four pieces of stage st
+        unsigned char *buf = lds + (st % TL_STAGES) * TL_STAGE;
+        const uint32_t row0 = (uint32_t)(m_start + st * TL_ROWS + 8 * wave);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t arow = row0 + 4 * q + drow;
+            uint32_t boff;
+            if (GATHER) {
+                const int t0 = tn[4 * q], t1 = tn[4 * q + 1], t2 = tn[4 * q + 2], t3 = tn[4 * q + 3];
+                boff = (uint32_t)(drow == 0 ? t0 : drow == 1 ? t1 : drow == 2 ? t2 : t3);
+            } else {
+                boff = arow * ldb2;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ab + (arow * lda2 + acol2)),
+                                             (__attribute__((address_space(3))) void *)(buf + (2 * wave + q) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Bb + (boff + bcol2)),
+                                             (__attribute__((address_space(3))) void *)(buf + TL_TILE + (2 * wave + q) * 1024), 16, 0, 0);
+        }
+    };
+
+    // fragment addresses inside a stage: k-step s (rows 16 s ..), fragment half q (rows +4 q), 32-column tile t
+    const int g = lane >> 4, l = lane & 15, kh = g >> 1;
+    const int frow = 8 * kh + (l >> 2);                       // + 16 s + 4 q
+    const int fcolA = (wave >> 1) * 64 + 16 * (g & 1) + 4 * (l & 3);  // + 32 t
+    const int fcolB = (wave & 1) * 64 + 16 * (g & 1) + 4 * (l & 3);
+    auto faddr = [&](const int row, const int col) { return row * 256 + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2; };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    if (GATHER && nst > 0) table(0);
+    if (nst > 0) { issue(0); if (GATHER) table(1); }
+    for (int st = 0; st < nst; st++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of stage st have landed
+        __builtin_amdgcn_s_barrier();  // everybody's pieces visible; everybody is done reading stage st-1
+        if (st + 1 < nst) {  // refill the other buffer while this one is multiplied
+            issue(st + 1);
+            if (GATHER) table(st + 2);
+        }
+        const unsigned char *buf = lds + (st % TL_STAGES) * TL_STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                union { bf16x4 h[2]; bf16x8 v; } ua, ub;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int row = 16 * s2 + 4 * q + frow;
+                    ua.h[q] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(buf + faddr(row, fcolA + 32 * t)));
+                    ub.h[q] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4 *)(buf + TL_TILE + faddr(row, fcolB + 32 * t)));
+                }
+                fa[t] = ua.v; fb[t] = ub.v;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads (and the table) done before the next barrier
+    }
+    // accumulator (ta, tb)[reg]: A column nbase + 32 ta + (reg&3) + 8 (reg>>2) + 4 (lane>>5), B column kbase + 32 tb + (lane&31)
+    const int ldc = p.T * p.Kc;
+    float *out = p.part + (size_t)split * p.N * ldc + (size_t)tap * p.Kc;
+    const int nbase = nt * 128 + (wave >> 1) * 64, kbase = kc0 + (wave & 1) * 64;
+#pragma unroll
+    for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+        for (int tb = 0; tb < 2; tb++) {
+            const int col = kbase + 32 * tb + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int n = nbase + 32 * ta + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (n < p.N && col < p.Kc) out[(size_t)n * ldc + col] = acc[ta][tb][e];
+            }
+        }
+}
+
 // dst[i] += sum over parts of part[s * stride + i]; 64 elements per workgroup, blockDim / 64 slices of the
 // parts (256 threads when there are many elements and few parts, 1024 for the opposite)
 __global__ void __launch_bounds__(1024)
@@ -446,9 +579,9 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
         return LARA2DGS_E_INVALID;
     const int tiles = ((N + 127) / 128) * ((Kc + 127) / 128) * T;
     const size_t out_bytes = (size_t)N * T * Kc * 4;
-    // about 768 workgroups per launch (3 per CU = what the registers allow: one round), in multiples of 8
-    // splits (one per XCD, see the kernel), at least 256 token rows each; a split that starts beyond M writes zeros
-    int splits = max(1, min(768 / tiles, (int)(TN_PART_BYTES / out_bytes)));
+    // about 1024 workgroups per launch (4 per CU: one round), in multiples of 8 splits (one per XCD, see the
+    // kernel), at least 256 token rows each; a split that starts beyond M writes zeros
+    int splits = max(1, min(1024 / tiles, (int)(TN_PART_BYTES / out_bytes)));
     splits = max(8, splits & ~7);
     while (splits > 8 && M / splits < 256) splits -= 8;
     const int chunk = (((M + splits - 1) / splits) + 63) & ~63;
@@ -456,8 +589,14 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     p.A = A; p.B = B; p.part = part; p.nbr = nbr; p.M = M; p.lda = lda; p.ldb = ldb; p.N = N; p.Kc = Kc; p.T = T;
     p.chunk = chunk; p.tiles = tiles;
     if ((size_t)splits * out_bytes > TN_PART_BYTES) return LARA2DGS_E_INVALID;
-    if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
+    const bool staged = !((M & 31) || (N & 7) || (Kc & 7) || (lda & 7) || (ldb & 7)) && !getenv("LARA_TN_DIRECT");
+    if (staged) {
+        if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
+    } else {
+        if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
+    }
     const int n = N * T * Kc;
     hipLaunchKernelGGL(accum_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
