@@ -88,12 +88,17 @@ int lara_volume_from_tokens(int32_t scenes, int32_t R, int32_t C, const float *t
                             void *stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Backward (training).  In the reference this is torch autograd through the modules above under
- * bf16-mixed autocast.  A block saves only its input rows: lara_groupblock_backward re-runs the
- * block's forward into its workspace, then produces
- *   g      in: dL/d(block output) fp32 [M, 256]   out: dL/d(block input), in place
- *   dcond  += dL/d(cond) fp32 [M/2, cond_dim]      (the same cond feeds every layer: accumulate)
- *   dw     += the parameter gradients, fp32, in the layouts of lara_groupblock_weights
+ * Training.  In the reference the backward is torch autograd through the modules above under bf16-mixed
+ * autocast.  Here
+ *   lara_groupblock_forward_train   x_out <- GroupAttBlock(x_in, cond), out of place, and every intermediate
+ *                                   the backward needs (LayerNorm outputs, q, k|v, attention output, the
+ *                                   MLP's pre-activation and hidden rows, ...) kept in `saved`
+ *                                   (lara_groupblock_save_bytes: 7.2 KB per token row)
+ *   lara_groupblock_backward        g   in: dL/d(block output) fp32 [M, 256]   out: dL/d(block input), in place
+ *                                   dcond  += dL/d(cond) fp32 [M/2, cond_dim]   (the same cond feeds every layer)
+ *                                   dw     += the parameter gradients, fp32, layouts of lara_groupblock_weights
+ *                                   `saved`: what forward_train left, or NULL to re-run the block's forward
+ *                                   inside the backward (trades 0.6 ms per layer for the memory)
  * The caller zero-fills dcond and dw once per step.  Matrix products: bf16 operands, fp32 accumulate;
  * all reductions have a fixed order (bit-reproducible).  Requires R >= 4.
  * ---------------------------------------------------------------------------------------------- */
@@ -115,10 +120,15 @@ typedef struct lara_groupblock_grads {
 } lara_groupblock_grads;
 
 int64_t lara_groupblock_backward_workspace_bytes(int32_t scenes, int32_t R);
+int64_t lara_groupblock_save_bytes(int32_t scenes, int32_t R);
+
+int lara_groupblock_forward_train(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in, float *x_out,
+                                  const uint16_t *cond_bf16, const lara_groupblock_weights *w, void *saved,
+                                  void *stream);
 
 int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
                              const uint16_t *cond_bf16, const lara_groupblock_weights *w,
-                             const lara_groupblock_weights_t *wt, float *g, float *dcond,
+                             const lara_groupblock_weights_t *wt, const void *saved, float *g, float *dcond,
                              const lara_groupblock_grads *dw, void *workspace, void *stream);
 
 /* Backward of lara_voltrans_head_forward.  x: the rows that entered the head; dout: fp32

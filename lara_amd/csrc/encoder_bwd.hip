@@ -626,25 +626,81 @@ void gemm_nt(const unsigned short *A, const unsigned short *W, void *C, int M, i
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, EPI>), dim3((M + 127) / 128, (N + 127) / 128), dim3(256), 0, s, p);
 }
 
-// scratch layout of lara_groupblock_backward, in bytes from the workspace start
-struct BwdWs {
-    size_t xn1, q, kv, o, x1, xn2, z, h, x2, xn3, gb, tmpf, dzb, dq, dkv, dob, nbr, lnpart, tnpart, total;
+// What a block's forward leaves behind for its backward (lara_groupblock_forward_train), in bytes from the
+// start of the block's save area: 7.2 KB per token row, 0.94 GB per layer at 4 scenes x 32^3 -- 11 GB for the
+// 12 layers, which a 288 GB part holds without thinking (recomputing them instead costs 0.6 ms per layer).
+struct SaveWs {
+    size_t xn1, q, kv, o, x1, xn2, z, h, x2, xn3, stats, total;
 };
-BwdWs bwd_layout(int64_t M) {
-    BwdWs w{};
+SaveWs save_layout(int64_t M) {
+    SaveWs w{};
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
     const size_t b256 = (size_t)M * 512, f256 = (size_t)M * 1024, b512 = (size_t)M * 1024;
     w.xn1 = take(b256); w.q = take(b256); w.kv = take(b256); w.o = take(b256);
     w.x1 = take(f256); w.xn2 = take(b256); w.z = take(b512); w.h = take(b512); w.x2 = take(f256);
     w.xn3 = take(b256 + 512);  // + the zeroed row (index M) the gathers read outside the volume
-    w.gb = take(b256 + 512);   // same
+    w.stats = take((size_t)M * 8);
+    w.total = o;
+    return w;
+}
+// scratch of lara_groupblock_backward (followed by a SaveWs for the recompute mode)
+struct BwdWs {
+    size_t gb, tmpf, dzb, dq, dkv, dob, nbr, lnpart, tnpart, save, total;
+};
+BwdWs bwd_layout(int64_t M) {
+    BwdWs w{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = up256(o + bytes); return at; };
+    const size_t b256 = (size_t)M * 512, f256 = (size_t)M * 1024, b512 = (size_t)M * 1024;
+    w.gb = take(b256 + 512);   // + a zeroed row, as above
     w.tmpf = take(f256); w.dzb = take(b512); w.dq = take(b256); w.dkv = take(b256); w.dob = take(b256);
     w.nbr = take((size_t)27 * M * 4);
     w.lnpart = take(((size_t)(M + 63) / 64) * 768 * 4);
     w.tnpart = take(TN_PART_BYTES);
+    w.save = take(save_layout(M).total);
     w.total = o;
     return w;
+}
+
+// network.py:88-95 of one block, every intermediate kept in `save` (x_in is not modified)
+int block_forward_keep(int M, int cond_dim, const float *x_in, const unsigned short *cond_bf16,
+                       const lara_groupblock_weights *w, char *save, hipStream_t s) {
+    const SaveWs L = save_layout(M);
+    const int G = M / 8, Mkv = G * 4, lnb = (M + 3) / 4;
+    unsigned short *xn1 = (unsigned short *)(save + L.xn1), *q = (unsigned short *)(save + L.q), *kv = (unsigned short *)(save + L.kv);
+    unsigned short *o = (unsigned short *)(save + L.o), *xn2 = (unsigned short *)(save + L.xn2), *z = (unsigned short *)(save + L.z);
+    unsigned short *h = (unsigned short *)(save + L.h), *xn3 = (unsigned short *)(save + L.xn3);
+    float *x1 = (float *)(save + L.x1), *x2 = (float *)(save + L.x2);
+    hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x_in, w->ln1_w, w->ln1_b, w->eps, xn1, (float2 *)nullptr, M);
+    gemm_nt<0>(xn1, w->wq, q, M, 256, 256, nullptr, nullptr, s);
+    {
+        GemmP p{};
+        p.A = cond_bf16; p.W = w->wkv; p.C = kv; p.M = Mkv; p.N = 512; p.K = cond_dim;
+        if (launch_gemm_ring<0, 0>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(group_attn_kernel, dim3((G + 15) / 16), dim3(256), 0, s, q, kv, o, G);
+    gemm_nt<1>(o, w->wo, x1, M, 256, 256, x_in, nullptr, s);
+    hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x1, w->ln2_w, w->ln2_b, w->eps, xn2, (float2 *)nullptr, M);
+    {
+        GemmP p{};
+        p.A = xn2; p.W = w->w1; p.C = h; p.C2 = z; p.bias = w->b1; p.M = M; p.N = 512; p.K = 256;
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 6>), dim3((M + 127) / 128, 4), dim3(256), 0, s, p);
+    }
+    {
+        GemmP p{};
+        p.A = h; p.W = w->w2; p.C = x2; p.resid = x1; p.bias = w->b2; p.M = M; p.N = 256; p.K = 512;
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 3>), dim3((M + 127) / 128, 2), dim3(256), 0, s, p);
+    }
+    hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x2, w->ln3_w, w->ln3_b, w->eps, xn3,
+                       (float2 *)(save + L.stats), M);
+    if (hipMemsetAsync(xn3 + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
+}
+
+bool block_weights_ok(const lara_groupblock_weights *w) {
+    return w && w->ln1_w && w->ln1_b && w->wq && w->wkv && w->wo && w->ln2_w && w->ln2_b && w->w1 && w->b1 && w->w2 &&
+           w->b2 && w->ln3_w && w->ln3_b && w->wconv;
 }
 
 }  // namespace
@@ -656,15 +712,49 @@ int64_t lara_groupblock_backward_workspace_bytes(int32_t scenes, int32_t R) {
     return (int64_t)bwd_layout((int64_t)scenes * R * R * R).total;
 }
 
+int64_t lara_groupblock_save_bytes(int32_t scenes, int32_t R) {
+    if (scenes < 0 || R < 4 || (R & 1)) return LARA2DGS_E_INVALID;
+    return (int64_t)save_layout((int64_t)scenes * R * R * R).total;
+}
+
+int lara_groupblock_forward_train(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in, float *x_out,
+                                  const uint16_t *cond_bf16, const lara_groupblock_weights *w, void *saved,
+                                  void *stream) {
+    if (scenes < 0 || R < 4 || (R & 1) || cond_dim <= 0 || (cond_dim % 32) != 0 || !block_weights_ok(w)) return LARA2DGS_E_INVALID;
+    if (scenes == 0) return LARA2DGS_OK;
+    if (!x_in || !x_out || x_in == x_out || !cond_bf16 || !saved) return LARA2DGS_E_INVALID;
+    const int64_t M64 = (int64_t)scenes * R * R * R;
+    if (M64 * 2056 + 512 >= (1ll << 32)) return LARA2DGS_E_INVALID;
+    const int M = (int)M64;
+    hipStream_t s = (hipStream_t)stream;
+    const SaveWs L = save_layout(M);
+    char *save = (char *)saved;
+    int rc;
+    {
+        L2D_PROF("gbt_forward", s);
+        if ((rc = block_forward_keep(M, cond_dim, x_in, cond_bf16, w, save, s))) return rc;
+    }
+    {
+        L2D_PROF("gb_conv3d", s);
+        GemmP p{};
+        p.A = (const unsigned short *)(save + L.xn3); p.W = w->wconv; p.C = x_out; p.resid = (const float *)(save + L.x2);
+        p.M = M; p.N = 256; p.K = 27 * 256; p.R = R; p.Cin = 256; p.stats = (const float2 *)(save + L.stats);
+        p.gamma = w->ln3_w; p.beta = w->ln3_b; p.zero_off = (uint32_t)((size_t)M * 512);
+        if (launch_gemm_ring<1, 4>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
 int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
                              const uint16_t *cond_bf16, const lara_groupblock_weights *w,
-                             const lara_groupblock_weights_t *wt, float *g, float *dcond,
+                             const lara_groupblock_weights_t *wt, const void *saved, float *g, float *dcond,
                              const lara_groupblock_grads *dw, void *workspace, void *stream) {
-    if (scenes < 0 || R < 4 || (R & 1) || cond_dim <= 0 || (cond_dim % 32) != 0 || !w || !wt || !dw) return LARA2DGS_E_INVALID;
+    if (scenes < 0 || R < 4 || (R & 1) || cond_dim <= 0 || (cond_dim % 32) != 0 || !block_weights_ok(w) || !wt || !dw)
+        return LARA2DGS_E_INVALID;
     if (scenes == 0) return LARA2DGS_OK;
     if (!x_in || !cond_bf16 || !g || !dcond || !workspace) return LARA2DGS_E_INVALID;
-    if (!w->ln1_w || !w->ln1_b || !w->wq || !w->wkv || !w->wo || !w->ln2_w || !w->ln2_b || !w->w1 || !w->b1 || !w->w2 ||
-        !w->b2 || !w->ln3_w || !w->ln3_b || !w->wconv || !wt->wq_t || !wt->wkv_t || !wt->wo_t || !wt->w1_t || !wt->w2_t ||
+    if (!wt->wq_t || !wt->wkv_t || !wt->wo_t || !wt->w1_t || !wt->w2_t ||
         !wt->wconv_t || !dw->ln1_w || !dw->ln1_b || !dw->wq || !dw->wkv || !dw->wo || !dw->ln2_w || !dw->ln2_b ||
         !dw->w1 || !dw->b1 || !dw->w2 || !dw->b2 || !dw->ln3_w || !dw->ln3_b || !dw->wconv)
         return LARA2DGS_E_INVALID;
@@ -673,46 +763,28 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     const int M = (int)M64, G = M / 8, Mkv = G * 4;
     hipStream_t s = (hipStream_t)stream;
     const BwdWs L = bwd_layout(M);
+    const SaveWs S = save_layout(M);
     char *ws = (char *)workspace;
-    unsigned short *xn1 = (unsigned short *)(ws + L.xn1), *q = (unsigned short *)(ws + L.q), *kv = (unsigned short *)(ws + L.kv);
-    unsigned short *o = (unsigned short *)(ws + L.o), *xn2 = (unsigned short *)(ws + L.xn2), *z = (unsigned short *)(ws + L.z);
-    unsigned short *h = (unsigned short *)(ws + L.h), *xn3 = (unsigned short *)(ws + L.xn3), *gb = (unsigned short *)(ws + L.gb);
+    int rc;
+    if (!saved) {  // nothing kept from the forward: run it again into our own save area
+        L2D_PROF("gbb_recompute", s);
+        if ((rc = block_forward_keep(M, cond_dim, x_in, cond_bf16, w, ws + L.save, s))) return rc;
+    }
+    const char *sv = saved ? (const char *)saved : ws + L.save;
+    const unsigned short *xn1 = (const unsigned short *)(sv + S.xn1), *q = (const unsigned short *)(sv + S.q);
+    const unsigned short *kv = (const unsigned short *)(sv + S.kv), *o = (const unsigned short *)(sv + S.o);
+    const unsigned short *xn2 = (const unsigned short *)(sv + S.xn2), *h = (const unsigned short *)(sv + S.h);
+    const unsigned short *xn3 = (const unsigned short *)(sv + S.xn3);
+    unsigned short *z = (unsigned short *)(sv + S.z);  // (read only; the GEMM parameter block is not const-correct)
+    const float *x1 = (const float *)(sv + S.x1), *x2 = (const float *)(sv + S.x2);
+    unsigned short *gb = (unsigned short *)(ws + L.gb);
     unsigned short *dzb = (unsigned short *)(ws + L.dzb), *dq = (unsigned short *)(ws + L.dq), *dkv = (unsigned short *)(ws + L.dkv);
     unsigned short *dob = (unsigned short *)(ws + L.dob);
-    float *x1 = (float *)(ws + L.x1), *x2 = (float *)(ws + L.x2), *tmpf = (float *)(ws + L.tmpf);
+    float *tmpf = (float *)(ws + L.tmpf);
     float *lnpart = (float *)(ws + L.lnpart), *tnpart = (float *)(ws + L.tnpart);
     int *nbr = (int *)(ws + L.nbr);
-    const int lnb = (M + 3) / 4;
-    int rc;
-
-    // ---- the block's forward again, keeping what the backward needs (network.py:88-95) ----
-    {
-        L2D_PROF("gbb_recompute", s);
-        hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x_in, w->ln1_w, w->ln1_b, w->eps, xn1, (float2 *)nullptr, M);
-        gemm_nt<0>(xn1, w->wq, q, M, 256, 256, nullptr, nullptr, s);
-        {
-            GemmP p{};
-            p.A = cond_bf16; p.W = w->wkv; p.C = kv; p.M = Mkv; p.N = 512; p.K = cond_dim;
-            if (launch_gemm_ring<0, 0>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
-        }
-        hipLaunchKernelGGL(group_attn_kernel, dim3((G + 15) / 16), dim3(256), 0, s, q, kv, o, G);
-        gemm_nt<1>(o, w->wo, x1, M, 256, 256, x_in, nullptr, s);
-        hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x1, w->ln2_w, w->ln2_b, w->eps, xn2, (float2 *)nullptr, M);
-        {
-            GemmP p{};
-            p.A = xn2; p.W = w->w1; p.C = h; p.C2 = z; p.bias = w->b1; p.M = M; p.N = 512; p.K = 256;
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 6>), dim3((M + 127) / 128, 4), dim3(256), 0, s, p);
-        }
-        {
-            GemmP p{};
-            p.A = h; p.W = w->w2; p.C = x2; p.resid = x1; p.bias = w->b2; p.M = M; p.N = 256; p.K = 512;
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 3>), dim3((M + 127) / 128, 2), dim3(256), 0, s, p);
-        }
-        hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x2, w->ln3_w, w->ln3_b, w->eps, xn3, (float2 *)nullptr, M);
-        if (hipMemsetAsync(xn3 + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
-        if (hipMemsetAsync(gb + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
-        hipLaunchKernelGGL(neighbour_table_kernel, dim3((M + 255) / 256), dim3(256), 0, s, nbr, M, R, M, 512);
-    }
+    if (hipMemsetAsync(gb + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    hipLaunchKernelGGL(neighbour_table_kernel, dim3((M + 255) / 256), dim3(256), 0, s, nbr, M, R, M, 512);
     L2D_CHECK_LAUNCH();
     // ---- x_out = pn + cnn(pn), pn = norm3(x2)  (network.py:94-100) ----
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, g, gb, (size_t)M * 64);

@@ -46,7 +46,11 @@ def _lib():
         lib.lara_groupblock_backward_workspace_bytes.argtypes = [i32, i32]
         lib.lara_groupblock_backward.restype = ctypes.c_int
         lib.lara_groupblock_backward.argtypes = [i32, i32, i32, vp, vp, ctypes.POINTER(_BlockWeights),
-                                                 ctypes.POINTER(_BlockWeightsT), vp, vp, ctypes.POINTER(_BlockGrads), vp, vp]
+                                                 ctypes.POINTER(_BlockWeightsT), vp, vp, vp, ctypes.POINTER(_BlockGrads), vp, vp]
+        lib.lara_groupblock_save_bytes.restype = i64
+        lib.lara_groupblock_save_bytes.argtypes = [i32, i32]
+        lib.lara_groupblock_forward_train.restype = ctypes.c_int
+        lib.lara_groupblock_forward_train.argtypes = [i32, i32, i32, vp, vp, vp, ctypes.POINTER(_BlockWeights), vp, vp]
         lib.lara_voltrans_head_backward_workspace_bytes.restype = i64
         lib.lara_voltrans_head_backward_workspace_bytes.argtypes = [i32, i32, i32]
         lib.lara_voltrans_head_backward.restype = ctypes.c_int
@@ -61,6 +65,14 @@ def _lib():
         lib.lara_groupattn_core_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp]
         _configured = True
     return lib
+
+
+def _keep_activations() -> bool:
+    """Default: keep every block's intermediates in HBM between forward and backward (0.94 GB per layer at
+    4 scenes x 32^3).  LARA_ENCODER_RECOMPUTE=1 saves only each block's input rows and re-runs its forward
+    inside the backward instead (slower by the cost of one forward)."""
+    import os
+    return os.environ.get("LARA_ENCODER_RECOMPUTE", "0") != "1"
 
 
 def _stream(dev):
@@ -103,12 +115,11 @@ def _layer_bf16(p):
     return f
 
 
-def _layer_bf16_t(f, wc):
-    bf = torch.bfloat16
+def _layer_bf16_t(f):
     return {"wq_t": f["wq"].t().contiguous(), "wkv_t": f["wkv"].t().contiguous(), "wo_t": f["wo"].t().contiguous(),
             "w1_t": f["w1"].t().contiguous(), "w2_t": f["w2"].t().contiguous(),
-            # [in][mirrored tap][out]: wconv_t[ci][t][co] = cnn.weight[co, ci, 26 - t]
-            "wconv_t": wc.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(256, 27 * 256).to(bf).contiguous()}
+            # [in][mirrored tap][out]: wconv_t[ci][t][co] = wconv[co][26 - t][ci] = cnn.weight[co, ci, 26 - t]
+            "wconv_t": f["wconv"].view(256, 27, 256).flip(1).permute(2, 1, 0).reshape(256, 27 * 256).contiguous()}
 
 
 def _fill(struct, tensors, names):
@@ -134,17 +145,33 @@ class _VolTransFn(torch.autograd.Function):
         cond_dim = cond.shape[2]
         cond_bf = cond.detach().to(torch.bfloat16).contiguous()
         x = volume_to_tokens(pos_embed.detach().float()).repeat(B, 1)       # network.py:152
-        saved_x = []
-        ws = _workspace(dev, "fwd", lib.lara_groupblock_workspace_bytes(B, R))
+        track = any(ctx.needs_input_grad)          # False under torch.no_grad(): plain in-place forward
+        keep = track and _keep_activations()
+        saved_x, saved_act, saved_w = [], [], []
+        nsave = lib.lara_groupblock_save_bytes(B, R)
+        if nsave < 0:
+            _check(int(nsave), "lara_groupblock_save_bytes")
+        ws = None if keep else _workspace(dev, "fwd", lib.lara_groupblock_workspace_bytes(B, R))
         with torch.cuda.device(dev):
             for l in range(n_layers):
-                saved_x.append(x.clone())
                 f = _layer_bf16([t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]])
-                w = _fill(_BlockWeights(), f, ("ln1_w", "ln1_b", "wq", "wkv", "wo", "ln2_w", "ln2_b", "w1", "b1", "w2",
-                                               "b2", "ln3_w", "ln3_b", "wconv"))
+                w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
                 w.eps = eps_block
-                _check(lib.lara_groupblock_forward(B, R, cond_dim, x.data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
-                                                   ws.data_ptr(), _stream(dev)), "lara_groupblock_forward")
+                if keep:   # out of place; the block's intermediates stay in HBM for the backward
+                    act = torch.empty(nsave, dtype=torch.uint8, device=dev)
+                    x_out = torch.empty_like(x)
+                    _check(lib.lara_groupblock_forward_train(B, R, cond_dim, x.data_ptr(), x_out.data_ptr(), cond_bf.data_ptr(),
+                                                             ctypes.byref(w), act.data_ptr(), _stream(dev)),
+                           "lara_groupblock_forward_train")
+                    saved_x.append(x)
+                    saved_act.append(act)
+                    saved_w.append(f)
+                    x = x_out
+                else:      # in place; the backward re-runs the block's forward from its input rows
+                    if track:
+                        saved_x.append(x.clone())
+                    _check(lib.lara_groupblock_forward(B, R, cond_dim, x.data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
+                                                       ws.data_ptr(), _stream(dev)), "lara_groupblock_forward")
             wd = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).contiguous()
             nw, nb, db = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous(), deconv_b.detach().float().contiguous()
             out = torch.empty(B, 2 * R, 2 * R, 2 * R, out_dim, dtype=torch.float32, device=dev)
@@ -152,8 +179,11 @@ class _VolTransFn(torch.autograd.Function):
             _check(lib.lara_voltrans_head_forward(B, R, x.data_ptr(), nw.data_ptr(), nb.data_ptr(), float(eps_final),
                                                   wd.data_ptr(), db.data_ptr(), out_dim, out.data_ptr(), hws.data_ptr(),
                                                   _stream(dev)), "lara_voltrans_head_forward")
+        if not track:
+            return out
         ctx.save_for_backward(cond_bf, x, pos_embed, norm_w, norm_b, deconv_w, *saved_x, *layer_params)
         ctx.meta = (float(eps_block), float(eps_final), R, out_dim, B, n_layers, cond_dim)
+        ctx.saved_act, ctx.saved_w = saved_act, saved_w   # raw scratch / bf16 weight copies, not graph tensors
         return out
 
     @staticmethod
@@ -184,15 +214,16 @@ class _VolTransFn(torch.autograd.Function):
             ws = _workspace(dev, "block_bwd", lib.lara_groupblock_backward_workspace_bytes(B, R))
             for l in reversed(range(n_layers)):
                 p = [t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]]
-                f = _layer_bf16(p)
-                ft = _layer_bf16_t(f, p[14])
+                f = ctx.saved_w[l] if ctx.saved_w else _layer_bf16(p)
+                ft = _layer_bf16_t(f)
                 w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
                 w.eps = eps_block
                 wt = _fill(_BlockWeightsT(), ft, ("wq_t", "wkv_t", "wo_t", "w1_t", "w2_t", "wconv_t"))
                 gd = {n: torch.zeros(f[n].shape, **f32) for n in _GRAD_FIELDS}
                 dw = _fill(_BlockGrads(), gd, _GRAD_FIELDS)
+                act = ctx.saved_act[l].data_ptr() if ctx.saved_act else None
                 _check(lib.lara_groupblock_backward(B, R, cond_dim, saved_x[l].data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
-                                                    ctypes.byref(wt), g.data_ptr(), dcond.data_ptr(), ctypes.byref(dw),
+                                                    ctypes.byref(wt), act, g.data_ptr(), dcond.data_ptr(), ctypes.byref(dw),
                                                     ws.data_ptr(), _stream(dev)), "lara_groupblock_backward")
                 grads[l * _NLP:(l + 1) * _NLP] = [
                     gd["ln1_w"], gd["ln1_b"], gd["wq"], gd["wkv"][:256], gd["wkv"][256:], gd["wo"], gd["ln2_w"], gd["ln2_b"],
