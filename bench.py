@@ -23,7 +23,7 @@ current stream, i.e. exactly as the reference's Python loop would issue it.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed, algorithmic bytes
 from DESIGN.md / SURVEY.md section 8d), "cpu_baseline" (the CPU oracle on a bounded sample),
-"single_stream", "attention" and "encoder" (MFMA legs, reported beside the raster).
+"single_stream", "attention", "encoder" and "encoder_train" (MFMA legs, reported beside the raster).
 """
 import argparse
 import contextlib
@@ -199,7 +199,7 @@ def measure_roofline(scenes, settings, gc, ga, args):
     # their own, so they are collected by tools/gpu_traffic.sh and committed under profiles/
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01g.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01h.json")))
         if args.regime == "init" and args.grid == 64 and args.res == 512:
             traffic = tj["bytes_per_launch"][dom]["total"]
     except Exception:
@@ -305,6 +305,41 @@ def encoder_leg(device, scenes):
             "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(flops / ms / 1e9 / 2500.0, 4), "bound": "mfma",
             "conv3d_us": round(conv_us, 1), "conv3d_TFLOPs": round(2 * M * 27 * 256 * 256 / conv_us / 1e6, 1)}
+
+
+def encoder_train_leg(device, scenes):
+    """The trainable drop-in (lara_amd.encoder_train.VolTransformer: fp32 master parameters with the
+    reference's state_dict, HIP forward AND backward) on this rank's scenes: one forward + backward per step,
+    gradients for every parameter and for the image features.  Reported beside the raster."""
+    from lara_amd.encoder_train import VolTransformer
+    torch.manual_seed(0)
+    vt = VolTransformer(256, 800, [16], 32, 64, 80, 12, 16).to(device)  # the reference's own initialisation
+    feats = torch.randn(scenes, 4, 800, 16, 16, 16, device=device, requires_grad=True)
+    dout = torch.randn(scenes, 64, 64, 64, 80, device=device)
+
+    def one():
+        vt(feats).backward(dout)
+        vt.zero_grad(set_to_none=True)
+        feats.grad = None
+
+    torch.cuda.reset_peak_memory_stats(device)
+    one()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        one()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    M, G = scenes * 32 ** 3, scenes * 4096
+    per_layer = 2 * M * 256 * 256 * 2 + 2 * G * 4 * 800 * 512 + 2 * 2 * 8 * 4 * 16 * 16 * G + 2 * M * 256 * 512 * 2 + 2 * M * 27 * 256 * 256
+    flops = 3 * (12 * per_layer + 2 * M * 256 * 640)   # backward = 2 x forward (dX and dW for every product)
+    return {"workload": f"VolTransformer forward + backward, {scenes} scenes x 32^3 voxels, 12 layers, bf16 MFMA / fp32 "
+                        f"accumulate, fp32 master parameters, all parameter and image-feature gradients",
+            "ms_per_step": round(ms, 2), "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(flops / ms / 1e9 / 2500.0, 4), "bound": "mfma",
+            "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}
 
 
 def rays_leg(device, scenes, views, res):
@@ -466,6 +501,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         out["attention"] = attention_leg(device, args.scenes)
         out["encoder"] = encoder_leg(device, args.scenes)
+        out["encoder_train"] = encoder_train_leg(device, args.scenes)
         out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

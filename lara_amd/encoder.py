@@ -12,7 +12,8 @@ Differences in *how*, not *what*:
 * matmuls / the convolution run in bf16 with fp32 accumulation (what ``precision="bf16-mixed"``
   gives the reference, train_lightning.py:74); LayerNorm, softmax, GELU, residuals in fp32.
 
-Forward only in this round: tensors that require grad raise (no silent fallback to torch).
+Inference classes (bf16 weight buffers, no autograd): tensors that require grad raise -- training goes
+through ``lara_amd.encoder_train`` (same kernels + the HIP backward, fp32 master parameters).
 """
 from __future__ import annotations
 
@@ -54,7 +55,7 @@ def _require_device(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
     if t.requires_grad and torch.is_grad_enabled():
-        raise RuntimeError("lara_amd.encoder is forward-only in this round")
+        raise RuntimeError("lara_amd.encoder holds the inference classes; use lara_amd.encoder_train.VolTransformer to train")
 
 
 def volume_to_tokens(volume: torch.Tensor) -> torch.Tensor:
