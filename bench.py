@@ -342,6 +342,67 @@ def encoder_train_leg(device, scenes):
             "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}
 
 
+def render_img_leg(device, args):
+    """One scene's 8 views through the whole of `Renderer.render_img` (renderer_2dgs.py:167-268), forward +
+    backward with a gradient on every returned map: (a) the reference's sequence on the drop-in rasteriser --
+    activations per view and ~15 torch kernels of post-processing per view (restated in torch here, as the
+    reference's class does it); (b) `lara_amd.renderer.Renderer` -- activations once per scene, one fused HIP
+    kernel per direction.  Single stream, as the reference's Python loop issues it."""
+    import torch.nn.functional as F
+    from lara_amd import batch, cameras, synthetic
+    from lara_amd.renderer import Renderer
+    sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=123, device=device)
+    c2w = cameras.turntable_c2w(args.views).to(device)
+    cams = cameras.make_cameras(c2w, args.res, args.res, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8, device=device)
+    ixt = batch.fov_to_ixt(torch.tensor([0.75, 0.75], device=device), (args.res, args.res))
+    rays = batch.build_rays(c2w, ixt.reshape(1, 3, 3).expand(args.views, 3, 3).contiguous(), args.res, args.res)
+    keys = ("image", "depth", "acc_map", "rend_normal", "depth_normal", "rend_dist")
+    r = Renderer(sh_degree=1, white_background=True)
+
+    def ref_style(cam, ray, p):
+        rast = r.set_rasterizer(cam, device=device)
+        sp = torch.zeros_like(p["centers"], requires_grad=True) + 0
+        col, _, allmap = rast(means3D=p["centers"], means2D=sp, shs=p["shs"], opacities=torch.sigmoid(p["opacity"]),
+                              scales=torch.exp(p["scales"]), rotations=F.normalize(p["rotations"]), cov3D_precomp=None)
+        image = col.clamp(0, 1)
+        alpha = allmap[1:2]
+        normal = (allmap[2:5].permute(1, 2, 0) @ (cam.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+        median = torch.nan_to_num(allmap[5:6], 0, 0)
+        expected = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
+        surf = expected * (1 - 0.0) + 0.0 * median
+        pts = (ray[..., :3].reshape(-1, 3) + surf.reshape(-1, 1) * ray[..., 3:].reshape(-1, 3)).reshape(*surf.shape[1:], 3)
+        out = torch.zeros_like(pts)
+        dx = pts[2:, 1:-1] - pts[:-2, 1:-1]
+        dy = pts[1:-1, 2:] - pts[1:-1, :-2]
+        out[1:-1, 1:-1, :] = F.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+        dn = out.permute(2, 0, 1) * alpha.detach()
+        return {"image": image.permute(1, 2, 0), "depth": surf.permute(1, 2, 0), "acc_map": alpha.squeeze(0),
+                "rend_normal": normal.permute(1, 2, 0), "depth_normal": dn.permute(1, 2, 0), "rend_dist": allmap[6]}
+
+    def one(mode):
+        p = {k: v.detach().requires_grad_(True) for k, v in sc.items()}
+        loss = 0
+        for cam, ray in zip(cams, rays):
+            o = (r.render_img(cam, ray, p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], device)
+                 if mode == "fused" else ref_style(cam, ray, p))
+            for k in keys:
+                loss = loss + o[k].sum() * 1e-6
+        loss.backward()
+
+    res = {}
+    for mode in ("reference_style", "fused"):
+        one(mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            one(mode)
+        torch.cuda.synchronize()
+        res[mode] = round(2 * args.views / (time.perf_counter() - t0), 1)
+    return {"workload": f"Renderer.render_img fwd+bwd, 1 scene x {args.views} views @{args.res}x{args.res}, gradients on all six "
+                        f"returned maps, one stream", "unit": "frames/s", "reference_style_torch_postprocessing": res["reference_style"],
+            "fused_renderer": res["fused"]}
+
+
 def rays_leg(device, scenes, views, res):
     """Device-side generation of the step's tar_rays + tar_rays_down (dataLoader/utils.py:21-34):
     a pure store stream, priced against the HBM peak."""
@@ -503,6 +564,7 @@ def main():
         out["encoder"] = encoder_leg(device, args.scenes)
         out["encoder_train"] = encoder_train_leg(device, args.scenes)
         out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
+        out["render_img"] = render_img_leg(device, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -1,0 +1,148 @@
+"""Opt-in replacement for the reference's ``Renderer`` (lightning/renderer_2dgs.py:91-268): the same
+``render_img(cam, rays, centers, shs, opacity, scales, rotations, device, cov3D_precomp=None, prex='',
+depth_ratio=0.0)`` returning the same dictionary, with
+
+* the rasteriser call going to the HIP path (``lara_amd.GaussianRasterizer``), and
+* everything after it (renderer_2dgs.py:220-268: clamp, expected / median depth, normals to world space,
+  ``depth_to_normal``, the channel-last permutes) done by ONE HIP kernel per direction
+  (``lara_surface_maps_forward`` / ``_backward``, include/lara_surface.h) instead of ~15 + ~25 launch-bound
+  torch kernels per view;
+* the three activations (sigmoid / exp / normalize, renderer_2dgs.py:183-189) computed once per set of
+  Gaussians instead of once per view: the reference's loop (network.py:487-497) calls ``render_img`` for each of
+  a scene's 8 views with the same parameter tensors.
+
+SURVEY.md section 8f row 2.  Use: ``net.gs_render = lara_amd.renderer.Renderer(sh_degree=..., white_background=...)``;
+the unchanged-call-signature path (the reference's own ``Renderer`` on top of the drop-in rasteriser) keeps
+working.  No CPU path: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _check, load_library
+
+_configured = False
+
+
+def _lib():
+    global _configured
+    lib = load_library()
+    if not _configured:
+        vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+        lib.lara_surface_maps_forward.restype = ctypes.c_int
+        lib.lara_surface_maps_forward.argtypes = [i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
+        lib.lara_surface_maps_backward.restype = ctypes.c_int
+        lib.lara_surface_maps_backward.argtypes = [i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        _configured = True
+    return lib
+
+
+class _SurfaceMaps(torch.autograd.Function):
+    """(color [3,H,W], allmap [7,H,W], rays [H,W,6], rot [3,3], depth_ratio) -> image [H,W,3], depth [H,W,1],
+    acc_map [H,W], rend_normal [H,W,3], depth_normal [H,W,3], rend_dist [H,W]"""
+
+    @staticmethod
+    def forward(ctx, color, allmap, rays, rot, depth_ratio):
+        if not color.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        color, allmap = color.float().contiguous(), allmap.float().contiguous()
+        rays, rot = rays.detach().float().contiguous(), rot.detach().float().contiguous()
+        H, W = color.shape[1], color.shape[2]
+        if allmap.shape != (7, H, W) or rays.shape != (H, W, 6) or rot.shape != (3, 3):
+            raise RuntimeError("expected color [3,H,W], allmap [7,H,W], rays [H,W,6], rot [3,3]")
+        o = dict(dtype=torch.float32, device=color.device)
+        image, depth, acc = torch.empty(H, W, 3, **o), torch.empty(H, W, 1, **o), torch.empty(H, W, **o)
+        rnorm, dnorm, rdist = torch.empty(H, W, 3, **o), torch.empty(H, W, 3, **o), torch.empty(H, W, **o)
+        with torch.cuda.device(color.device):
+            _check(_lib().lara_surface_maps_forward(H, W, color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), rot.data_ptr(),
+                                                    float(depth_ratio), image.data_ptr(), depth.data_ptr(), acc.data_ptr(),
+                                                    rnorm.data_ptr(), dnorm.data_ptr(), rdist.data_ptr(),
+                                                    torch.cuda.current_stream(color.device).cuda_stream),
+                   "lara_surface_maps_forward")
+        ctx.save_for_backward(color, allmap, rays, rot)
+        ctx.depth_ratio = float(depth_ratio)
+        return image, depth, acc, rnorm, dnorm, rdist
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth, g_acc, g_rnorm, g_dnorm, g_rdist):
+        color, allmap, rays, rot = ctx.saved_tensors
+        H, W = color.shape[1], color.shape[2]
+        gs = [None if g is None else g.float().contiguous() for g in (g_image, g_depth, g_acc, g_rnorm, g_dnorm, g_rdist)]
+        d_color, d_allmap = torch.empty_like(color), torch.empty_like(allmap)
+        with torch.cuda.device(color.device):
+            _check(_lib().lara_surface_maps_backward(H, W, color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), rot.data_ptr(),
+                                                     ctx.depth_ratio, *[None if g is None else g.data_ptr() for g in gs],
+                                                     d_color.data_ptr(), d_allmap.data_ptr(),
+                                                     torch.cuda.current_stream(color.device).cuda_stream),
+                   "lara_surface_maps_backward")
+        return d_color, d_allmap, None, None, None
+
+
+def surface_maps(color, allmap, rays, rot, depth_ratio=0.0):
+    """The fused post-processing alone (see the module docstring); differentiable w.r.t. color and allmap."""
+    return _SurfaceMaps.apply(color, allmap, rays, rot, depth_ratio)
+
+
+class Renderer(nn.Module):
+    """Same constructor and ``render_img`` as the reference ``Renderer`` (renderer_2dgs.py:91-268)."""
+
+    def __init__(self, sh_degree=3, white_background=True, radius=1):
+        super().__init__()
+        self.sh_degree, self.white_background, self.radius = sh_degree, white_background, radius
+        self.scaling_activation, self.opacity_activation = torch.exp, torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+        self.bg_color = torch.tensor([1, 1, 1] if white_background else [0, 0, 0], dtype=torch.float32)
+        self._act_key, self._act_val = None, None
+
+    def set_bg_color(self, bg):
+        self.bg_color = bg
+
+    def set_rasterizer(self, viewpoint_camera, scaling_modifier=1.0, device="cuda"):   # renderer_2dgs.py:119-139
+        settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+            bg=self.bg_color.to(device), scale_modifier=scaling_modifier,
+            viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+            sh_degree=self.sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+        return GaussianRasterizer(raster_settings=settings)
+
+    def get_opacity(self, _opacity):
+        return self.opacity_activation(_opacity)
+
+    def get_scaling(self, _scaling):
+        return self.scaling_activation(_scaling)
+
+    def get_rotation(self, _rotation):
+        return self.rotation_activation(_rotation)
+
+    def _activated(self, opacity, scales, rotations):
+        """The activated tensors of the last call are reused while the caller passes the same (unmodified)
+        tensor objects in the same autograd mode: the 8 views of a scene then share one sigmoid / exp /
+        normalize node.  (Call `loss.backward()` after all views of those tensors, as network.py does: a
+        backward in between frees the shared nodes' graph.)"""
+        # (id() is stable and unique while the cache holds a reference to the tensor object itself)
+        key = tuple((id(t), t._version, t.requires_grad) if t is not None else None
+                    for t in (opacity, scales, rotations)) + (torch.is_grad_enabled(),)
+        if key != self._act_key:
+            self._act_val = (self.get_opacity(opacity), None if scales is None else self.get_scaling(scales),
+                             None if rotations is None else self.get_rotation(rotations), (opacity, scales, rotations))
+            self._act_key = key
+        return self._act_val[:3]
+
+    def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device, cov3D_precomp=None, prex='',
+                   depth_ratio=0.0):
+        rasterizer = self.set_rasterizer(cam, device=device)
+        opacity, scales, rotations = self._activated(opacity, scales, rotations)
+        screenspace_points = torch.zeros_like(centers, dtype=centers.dtype, requires_grad=True, device=device) + 0
+        rendered_image, radii, allmap = rasterizer(means3D=centers, means2D=screenspace_points, shs=shs, opacities=opacity,
+                                                   scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        if rays is None:
+            return rendered_image.clamp(0, 1)
+        rot = cam.world_view_transform[:3, :3].T          # renderer_2dgs.py:231
+        image, depth, acc, rnorm, dnorm, rdist = surface_maps(rendered_image, allmap, rays, rot, depth_ratio)
+        return {f"image{prex}": image, f"depth{prex}": depth, f"acc_map{prex}": acc, f"rend_normal{prex}": rnorm,
+                f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist}
