@@ -403,6 +403,54 @@ def render_img_leg(device, args):
             "fused_renderer": res["fused"]}
 
 
+def point_feats_leg(device, args):
+    """The fine stage's point sampler (network.py:390-411): 262 144 points (half of a scene's Gaussians pass the
+    opacity mask) into the 4 input views @res, forward + backward: the reference's torch sequence (projection,
+    cat + permute, grid_sample, and their autograd) against the fused HIP kernels."""
+    import torch.nn.functional as F
+    from lara_amd import cameras
+    from lara_amd.fine import sample_point_feats
+    g = torch.Generator().manual_seed(3)
+    V, h, w, n = 4, args.res, args.res, 262144
+    w2c = torch.linalg.inv(cameras.turntable_c2w(V).double()).float().to(device)
+    focal = 0.5 * w / math.tan(0.5 * 0.75)
+    ixt = torch.tensor([[focal, 0, w / 2], [0, focal, h / 2], [0, 0, 1.0]], dtype=torch.float32).expand(V, 3, 3).contiguous().to(device)
+    pts0 = ((torch.rand(n, 3, generator=g) * 2 - 1) * 0.5).to(device)
+    img_ref = torch.rand(V, 3, h, w, generator=g).to(device)
+    maps0 = [torch.rand(V, h, w, 3, generator=g).to(device), torch.rand(V, h, w, generator=g).to(device),
+             (1.5 + torch.rand(V, h, w, 1, generator=g)).to(device)]
+    gout = torch.randn(V, 8, n, generator=g).to(device)
+
+    def torch_path(points, image, acc, depth):
+        pc = points.reshape(1, -1, 3) @ w2c[:, :3, :3].permute(0, 2, 1) + w2c[:, :3, 3][:, None]
+        q = pc @ ixt.permute(0, 2, 1)
+        xy, z = q[..., :2] / q[..., -1:], q[..., -1:]
+        grid = (xy + 0.5) / torch.tensor([w, h], device=device) * 2 - 1.0
+        stack = torch.cat((img_ref, torch.einsum('bhwc->bchw', torch.cat((image, acc.unsqueeze(-1), depth), dim=-1))), dim=1)
+        feats = F.grid_sample(stack, grid.unsqueeze(1), align_corners=False).view(V, -1, n)
+        return torch.cat((feats[:, :-1], (feats[:, -1:] - z.view(V, -1, n)).abs()), dim=1)
+
+    def one(fused):
+        p = pts0.clone().requires_grad_(True)
+        m = [t.clone().requires_grad_(True) for t in maps0]
+        out = sample_point_feats(p, w2c, ixt, img_ref, *m) if fused else torch_path(p, *m)
+        out.backward(gout)
+
+    res = {}
+    for fused in (False, True):
+        one(fused)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            one(fused)
+        e1.record()
+        torch.cuda.synchronize()
+        res[fused] = e0.elapsed_time(e1) / 5 * 1e3
+    return {"workload": f"get_point_feats fwd+bwd, {n} points x {V} views @{h}x{w} (incl. cloning the inputs)", "unit": "us",
+            "torch_sequence_us": round(res[False], 1), "fused_us": round(res[True], 1)}
+
+
 def rays_leg(device, scenes, views, res):
     """Device-side generation of the step's tar_rays + tar_rays_down (dataLoader/utils.py:21-34):
     a pure store stream, priced against the HBM peak."""
@@ -565,6 +613,7 @@ def main():
         out["encoder_train"] = encoder_train_leg(device, args.scenes)
         out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
         out["render_img"] = render_img_leg(device, args)
+        out["point_feats"] = point_feats_leg(device, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

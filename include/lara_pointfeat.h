@@ -1,0 +1,44 @@
+/*
+ * lara_pointfeat.h -- LaRa's fine-stage point sampler as one gather kernel per direction (part of
+ * liblara2dgs.so).  SURVEY.md section 8f row 4.
+ *
+ * Replaces the body of `Network.get_point_feats` (lightning/network.py:390-411) after `points = points[mask]`:
+ * `projection` (:182-187) of the n Gaussian centres into the V input views, `F.grid_sample` (bilinear, zeros
+ * padding, align_corners=False) of the 8-channel stack [input image (3) | coarse render (3) | acc_map | depth]
+ * at the projected positions, and the depth residual -- and, for training, its autograd backward (the
+ * reference pays a [V,8,h,w] concatenation + permute, a [V,1,n,2] grid, the sampled [V,8,1,n] tensor and
+ * their backward counterparts).
+ *
+ *   p_c  = w2c[v][:3,:3] p + w2c[v][:3,3];   q = K[v] p_c;   (x, y) = q.xy / q.z;   z = q.z
+ *   s_c  = bilinear sample of channel c at pixel position (x, y)   [pixel i is centred at i: with
+ *          grid = (xy + 0.5) / (w, h) * 2 - 1 and align_corners=False the sample position is exactly (x, y)]
+ *   out[v][c][i] = s_c  (c = 0..6),   out[v][7][i] = | s_7 - z |
+ *
+ * points [n,3]; w2cs [V,4,4]; ixts [V,3,3]; img_ref [V,3,h,w] (planar, as `_inps[i]`); image [V,h,w,3],
+ * acc_map [V,h,w], depth [V,h,w,1] (channel-last, as `render_img` returns them); out [V,8,n].  fp32, device.
+ * Backward: g_out [V,8,n] -> d_points [n,3] (overwritten) and ACCUMULATES into d_image, d_acc_map, d_depth
+ * (caller zero-fills; float atomics, like torch's grid_sample backward; any of the three may be NULL).
+ * Returns 0 or a negative LARA2DGS_E_* code; work is enqueued on `stream`, no host synchronisation.
+ */
+#ifndef LARA_POINTFEAT_H
+#define LARA_POINTFEAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int lara_point_feats_forward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
+                             const float *ixts, const float *img_ref, const float *image, const float *acc_map,
+                             const float *depth, float *out, void *stream);
+
+int lara_point_feats_backward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
+                              const float *ixts, const float *img_ref, const float *image, const float *acc_map,
+                              const float *depth, const float *g_out, float *d_points, float *d_image,
+                              float *d_acc_map, float *d_depth, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LARA_POINTFEAT_H */
