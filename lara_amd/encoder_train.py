@@ -100,8 +100,17 @@ _LAYER_PARAMS = ("norm1.weight", "norm1.bias", "cross_attn.q_proj_weight", "cros
 _NLP = len(_LAYER_PARAMS)
 
 
+_wcache = {}   # (address, version) of a block's 15 parameters -> (the parameters, their bf16 / fp32 kernel operands)
+
+
 def _layer_bf16(p):
-    """fp32 reference-layout parameters of one block -> (forward weights dict, transposed weights dict)."""
+    """fp32 reference-layout parameters of one block -> the kernels' operands (bf16 matrices in the layouts of
+    lara_groupblock_weights, fp32 vectors).  Cached while the parameters are unchanged (same tensor objects, same
+    versions): micro-batches of a gradient-accumulation step and evaluation loops reuse the casts."""
+    key = tuple((t.data_ptr(), t._version) for t in p)   # (the cache keeps the tensors, hence their storage, alive)
+    hit = _wcache.get(key)
+    if hit is not None:
+        return hit[1]
     (ln1w, ln1b, wq, wk, wv, wo, ln2w, ln2b, w1, b1, w2, b2, ln3w, ln3b, wc) = p
     bf = torch.bfloat16
     f = {"ln1_w": ln1w.float().contiguous(), "ln1_b": ln1b.float().contiguous(),
@@ -110,8 +119,11 @@ def _layer_bf16(p):
          "b1": b1.float().contiguous(), "b2": b2.float().contiguous(),
          "wq": wq.to(bf).contiguous(), "wkv": torch.cat([wk, wv], 0).to(bf).contiguous(), "wo": wo.to(bf).contiguous(),
          "w1": w1.to(bf).contiguous(), "w2": w2.to(bf).contiguous(),
-         # cnn.weight [out, in, kd, kh, kw] -> [out][tap][in]
-         "wconv": wc.permute(0, 2, 3, 4, 1).reshape(256, 27 * 256).to(bf).contiguous()}
+         # cnn.weight [out, in, kd, kh, kw] -> [out][tap][in] (cast first: the re-layout then moves half the bytes)
+         "wconv": wc.to(bf).permute(0, 2, 3, 4, 1).reshape(256, 27 * 256).contiguous()}
+    if len(_wcache) >= 64:          # a few models' worth of blocks; stale entries (old versions) are dropped wholesale
+        _wcache.clear()
+    _wcache[key] = (list(p), f)
     return f
 
 
