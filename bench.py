@@ -607,7 +607,7 @@ def main():
         out["roofline"] = roof
         out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
                               "alg_GBs": round(v["alg_GBs"], 1)} for k, v in table.items()}
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:   # the side legs run at N = 1 only (the other ranks would wait)
         out["attention"] = attention_leg(device, args.scenes)
         out["encoder"] = encoder_leg(device, args.scenes)
         out["encoder_train"] = encoder_train_leg(device, args.scenes)
