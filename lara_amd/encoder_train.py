@@ -20,7 +20,7 @@ import ctypes
 import torch
 from torch import nn
 
-from .encoder import _BlockWeights, _lib as _fwd_lib, cond_tokens, tokens_to_volume, volume_to_tokens
+from .encoder import _BlockWeights, _lib as _fwd_lib, tokens_to_volume, volume_to_tokens
 from .rasterizer import _check
 
 _configured = False

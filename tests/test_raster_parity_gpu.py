@@ -15,9 +15,6 @@ stated fp tolerance.  Tolerances used here and why:
     opacity / SH, 2e-4 .. 4e-4 for means / scales / rotations at 128 px; the maxima come from a few
     steeply inclined splats whose alpha is ill-conditioned in fp32 -- see the 1024 px test).
 """
-import math
-import os
-
 import numpy as np
 import pytest
 import torch
