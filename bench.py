@@ -199,7 +199,7 @@ def measure_roofline(scenes, settings, gc, ga, args):
     # their own, so they are collected by tools/gpu_traffic.sh and committed under profiles/
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01h.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01i.json")))
         if args.regime == "init" and args.grid == 64 and args.res == 512:
             traffic = tj["bytes_per_launch"][dom]["total"]
     except Exception:
@@ -490,22 +490,62 @@ def cpu_baseline(args):
     oracle.build()
     g = np.random.default_rng(0)
     dc = g.normal(size=(3, res, res)).astype(np.float32)
-    da = g.normal(size=(7, res, res)).astype(np.float32)
+    da = (0.1 * g.normal(size=(7, res, res))).astype(np.float32)   # (the gradient mix of tests/test_raster_parity_gpu.py)
     t0 = time.perf_counter()
     D = 0
+    first = None
     for cam in cams:
         view = oracle.View(res, res, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0,
                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 1,
                            cam.camera_center.numpy())
         r = oracle.forward(view, act["means3D"], act["opacities"], shs=act["shs"], scales=act["scales"],
                            rotations=act["rotations"])
-        oracle.backward(r, dc, da)
+        gr = oracle.backward(r, dc, da)
         D = r.num_rendered
+        if first is None:
+            first = (r, gr)
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": round(len(cams) / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{len(cams)} frames (fwd+bwd, the {len(cams)} views of scene 0, {res}x{res}, "
-                      f"P={act['means3D'].shape[0]}, D~{D}) with the OpenMP fp32 oracle; {dt:.2f} s"}
+    out = {"value": round(len(cams) / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{len(cams)} frames (fwd+bwd, the {len(cams)} views of scene 0, {res}x{res}, "
+                     f"P={act['means3D'].shape[0]}, D~{D}) with the OpenMP fp32 oracle; {dt:.2f} s"}
+    # the checker's other job: the HIP frame of view 0 against the oracle's, at full size (BASELINE's "PSNR vs ref";
+    # the oracle stands in for the absent reference rasteriser)
+    from lara_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cam = cams[0]
+    rs = GaussianRasterizationSettings(
+        image_height=res, image_width=res, tanfovx=math.tan(0.375), tanfovy=math.tan(0.375), bg=torch.ones(3, device=dev),
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+        sh_degree=1, campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
+    t = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in act.items()}
+    m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+    color, radii, allmap = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                                                  scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    ((color * torch.from_numpy(dc).to(dev)).sum() + (allmap * torch.from_numpy(da).to(dev)).sum()).backward()
+    r, gr = first
+    mse = float(((color.detach().cpu().numpy() - r.color) ** 2).mean())
+    gerr, l2err = {}, {}
+    for k in ("means3D", "opacities", "scales", "rotations", "shs"):
+        d = t[k].grad.cpu().numpy().reshape(gr[k].shape).astype(np.float64) - gr[k]
+        gerr[k] = float(np.abs(d).max() / (np.abs(gr[k]).max() + 1e-20))
+        l2err[k] = float(np.sqrt((d ** 2).sum() / ((gr[k].astype(np.float64) ** 2).sum() + 1e-300)))
+    # yardstick: the fp32 oracle's own gradient after every input moved by one ulp (tools/grad_probe.py)
+    rng = np.random.default_rng(1)
+    pert = {k: (v * (1 + (rng.integers(0, 2, v.shape) * 2 - 1) * 2.0 ** -23)).astype(np.float32) for k, v in act.items()}
+    view0 = oracle.View(res, res, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0, cam.world_view_transform.numpy(),
+                        cam.full_proj_transform.numpy(), 1, cam.camera_center.numpy())
+    rp = oracle.forward(view0, pert["means3D"], pert["opacities"], shs=pert["shs"], scales=pert["scales"], rotations=pert["rotations"])
+    gp = oracle.backward(rp, dc, da)
+    self_l2 = {k: float(np.sqrt(((gp[k].astype(np.float64) - gr[k]) ** 2).sum() / ((gr[k].astype(np.float64) ** 2).sum() + 1e-300)))
+               for k in l2err}
+    out["parity_vs_oracle"] = {"view": 0, "psnr_color_dB": round(10 * math.log10(1.0 / max(mse, 1e-30)), 1),
+                               "oracle_1ulp_self": {"psnr_color_dB": round(10 * math.log10(1.0 / max(float(((rp.color - r.color) ** 2).mean()), 1e-30)), 1),
+                                                    "grad_rel_l2": {k: float(f"{v:.2e}") for k, v in self_l2.items()}},
+                               "radii_identical": bool(np.array_equal(radii.cpu().numpy(), r.radii)),
+                               "max_grad_err_rel_to_max": {k: float(f"{v:.2e}") for k, v in gerr.items()},
+                               "grad_err_rel_l2": {k: float(f"{v:.2e}") for k, v in l2err.items()}}
+    return out
 
 
 def main():
