@@ -107,6 +107,27 @@ __device__ __forceinline__ int voxel_to_token(const int b, const int d, const in
     return ((((b * Gd + (d >> 1)) * Gd + (h >> 1)) * Gd + (w >> 1)) << 3) | ((d & 1) << 2) | ((h & 1) << 1) | (w & 1);
 }
 
+// Workgroup -> (row tile, column tile), XCD-aware.  Workgroup ids are dispatched round-robin over the 8 XCDs
+// (id % 8), each with its own L2; the column tiles of one row tile read the same A rows.  With the launch's
+// natural order (all row tiles of column 0, then column 1, ...) those re-reads are far apart in time and on other
+// XCDs, i.e. they come from HBM again (xn2 four times for the 256 -> 512 MLP layer).  Here ids are dealt in groups
+// of 8 row tiles x all column tiles: row tile r lands on XCD r % 8 for every column tile, 8 ids apart, so the
+// re-reads hit that XCD's L2.  gridDim = (row tiles, column tiles) as before; a ragged last group keeps the bijection.
+__device__ __forceinline__ void xcd_tile(int &rt, int &ct) {
+    const int rtiles = gridDim.x, nc = gridDim.y;
+    const int L = blockIdx.x + rtiles * blockIdx.y;
+    const int full = (rtiles >> 3) << 3, base = full * nc;
+    if (L < base) {
+        const int q = L / (8 * nc), rem = L - q * (8 * nc);
+        ct = rem >> 3;
+        rt = q * 8 + (rem & 7);
+    } else {
+        const int t = rtiles - full, l = L - base;
+        ct = l / t;
+        rt = full + (l - ct * t);
+    }
+}
+
 // EPI 0: bf16 store            1: fp32 store of acc + resid        2: bf16 store of gelu(acc + bias)
 //     3: fp32 acc + bias + resid   4: fp32 LN(resid row) + acc (LN redone from stats, gamma, beta)
 //     5: fp32 acc + bias scattered as a stride-2, kernel-2 transposed convolution (N = 8 * Cout)
@@ -124,7 +145,9 @@ gemm_bf16_nt_kernel(const GemmP p) {
     const unsigned short *__restrict__ A = p.A, *__restrict__ W = p.W;
     const int M = p.M, N = p.N, K = p.K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int bm0 = blockIdx.x * GM, bn0 = blockIdx.y * GN;
+    int rt_, ct_;
+    xcd_tile(rt_, ct_);
+    const int bm0 = rt_ * GM, bn0 = ct_ * GN;
     const int wm = (wave >> 1) * (GM / 2), wn = (wave & 1) * (GN / 2);
     const int r = lane & 31, kh = lane >> 5;
 
@@ -328,7 +351,9 @@ gemm_ring_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // RING * RTILE bytes
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int M = p.M, N = p.N, K = p.K, Cin = AMODE ? p.Cin : 0;
-    const int bm0 = blockIdx.x * RT, bn0 = blockIdx.y * RT;
+    int rt_, ct_;
+    xcd_tile(rt_, ct_);
+    const int bm0 = rt_ * RT, bn0 = ct_ * RT;
     const int wr = wave >> 2, wc = wave & 3;  // wave tile: rows wr*128.., columns wc*64..
     const int r = lane & 31, kh = lane >> 5;
     const char *Ab = (const char *)p.A, *Wb = (const char *)p.W;
