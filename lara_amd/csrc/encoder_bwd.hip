@@ -605,7 +605,8 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     const size_t out_bytes = (size_t)N * T * Kc * 4;
     // about 1024 workgroups per launch (4 per CU: one round), in multiples of 8 splits (one per XCD, see the
     // kernel), at least 256 token rows each; a split that starts beyond M writes zeros
-    int splits = max(1, min(1024 / tiles, (int)(TN_PART_BYTES / out_bytes)));
+    static const int want = getenv("LARA_TN_WANT") ? atoi(getenv("LARA_TN_WANT")) : 1024;
+    int splits = max(1, min(want / tiles, (int)(TN_PART_BYTES / out_bytes)));
     splits = max(8, splits & ~7);
     while (splits > 8 && M / splits < 256) splits -= 8;
     const int chunk = (((M + splits - 1) / splits) + 63) & ~63;
