@@ -641,6 +641,24 @@ def main():
         out["single_stream"] = {"value": round(frames_per_step * args.steps / dt1, 3), "unit": "frames/s",
                                 "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
     if rank == 0 and world == 1 and not args.no_roofline:
+        # opt-in, not in the reference: surfels with opacity < 1/255 (never drawn) culled in the preprocess; same
+        # images to an ulp, same gradients (tests/test_raster_parity_gpu.py); nothing to cull at LaRa's initialisation,
+        # most of the volume in a trained-like scene
+        from lara_amd import rasterizer as _rz
+        prev = _rz.set_cull_transparent(True)
+        try:
+            for _ in range(2):
+                step(scenes, settings, gc, ga, args.streams)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(scenes, settings, gc, ga, args.streams)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+        finally:
+            _rz.set_cull_transparent(prev)
+        out["cull_transparent_opt_in"] = {"value": round(frames_per_step * args.steps / dt1, 3), "unit": "frames/s",
+                                          "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
         out["forward_only"] = forward_only_leg(scenes, settings, args)
     if rank == 0 and not args.no_roofline:
         roof, table, D = measure_roofline(scenes, settings, gc, ga, args)

@@ -55,7 +55,10 @@ typedef struct lara2dgs_view {
     float tanfovx;
     float tanfovy;
     float scale_modifier;
-    int32_t prefiltered;
+    int32_t prefiltered;    /* bit 0: as the reference passes it (unused by LaRa, ignored); bit 1 (opt-in, not in the
+                             * reference): cull surfels whose opacity is below 1/255 -- alpha = min(0.99, opacity * G)
+                             * can then never pass the 1/255 test, so images and gradients are unchanged while such
+                             * surfels leave the binning, sort and composite (their radii read 0) */
     int32_t debug;
     int64_t capacity;       /* max (tile, surfel) pairs the state/scratch buffers were sized for */
     const float *bg;         /* [3]  */

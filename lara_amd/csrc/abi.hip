@@ -58,6 +58,7 @@ bool make_view(const lara2dgs_view *view, ViewDev &v) {
     v.tiles = v.gx * v.gy;
     if (v.gx > 65535 || v.gy > 65535) return false;
     v.scale_modifier = view->scale_modifier;
+    v.cull_transparent = (view->prefiltered >> 1) & 1;
     v.cap = (unsigned)view->capacity;
     {
         static const unsigned dbg = getenv("LARA2DGS_DEBUG_FLAGS") ? (unsigned)strtoul(getenv("LARA2DGS_DEBUG_FLAGS"), nullptr, 0) : 0u;

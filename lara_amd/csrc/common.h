@@ -24,6 +24,7 @@ struct ViewDev {
     float scale_modifier;
     unsigned cap;  // capacity in (tile, surfel) pairs
     unsigned dbg;  // LARA2DGS_DEBUG_FLAGS (perf experiments only; 0 in production)
+    int cull_transparent;  // opt-in: surfels with opacity < 1/255 are culled in preprocess (lara2dgs_view.prefiltered bit 1)
     const float *bg, *viewmatrix, *projmatrix, *campos;
 };
 

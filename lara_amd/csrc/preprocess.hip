@@ -135,6 +135,8 @@ surfel_forward(const ViewDev &v, const int idx, const float *__restrict__ means3
     float p_view[3];
     point4x3(v.viewmatrix, p, p_view);
     if (p_view[2] <= 0.2f) return culled;
+    // opt-in (not in the reference): alpha = min(0.99, opacity * G) <= opacity, and the composite skips alpha < 1/255
+    if (v.cull_transparent && opacities[idx] < (1.0f / 255.0f)) return culled;
 
     const Pm43 Pm = build_Pm(v);
     float Tm[3][3], normal[3];

@@ -101,6 +101,23 @@ def _check(rc: int, what: str):
 
 
 # ---------------------------------------------------------------------------------------------
+# opt-in: culling of surfels that can never be drawn
+# ---------------------------------------------------------------------------------------------
+_cull_transparent = os.environ.get("LARA2DGS_CULL_TRANSPARENT", "0") == "1"
+
+
+def set_cull_transparent(on: bool) -> bool:
+    """Opt-in, not in the reference (default off, or LARA2DGS_CULL_TRANSPARENT=1): surfels whose opacity is below
+    1/255 are culled in the preprocess.  alpha = min(0.99, opacity * G) <= opacity and the composite skips every
+    alpha < 1/255, so the rendered maps are the same to an ulp and the gradients the same up to summation order; what
+    changes is `radii` (0 for the culled surfels) and the work: in a trained LaRa volume most of the 524 288
+    Gaussians are empty space and leave the binning, sort and composite.  Returns the previous setting."""
+    global _cull_transparent
+    prev, _cull_transparent = _cull_transparent, bool(on)
+    return prev
+
+
+# ---------------------------------------------------------------------------------------------
 # workspace policy
 # ---------------------------------------------------------------------------------------------
 def _dup_factor() -> int:
@@ -196,7 +213,7 @@ def _make_view(rs: GaussianRasterizationSettings, P: int, M: int, cap: int, devi
         raise RuntimeError("lara_amd: bg[3], viewmatrix[4,4], projmatrix[4,4], campos[3] expected")
     v = _View(P, int(rs.sh_degree), M, int(rs.image_height), int(rs.image_width),
               float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
-              int(bool(rs.prefiltered)), int(bool(rs.debug)), cap,
+              int(bool(rs.prefiltered)) | (2 if _cull_transparent else 0), int(bool(rs.debug)), cap,
               bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
     return v, (bg, vm, pm, cp)
 
@@ -275,6 +292,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.cap = cap
         ctx.M = M
+        ctx.prefiltered_bits = int(bool(rs.prefiltered)) | (2 if _cull_transparent else 0)   # as the forward ran
         ctx.hdr = (ev, hdr)
         ctx.flags = (sh_c is not None, col_c is not None, sc_c is not None, tm_c is not None)
         ctx.shapes = (sh.shape if sh_c is not None else None, opacities.shape)
@@ -310,7 +328,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_color = _prep(grad_color, "grad_color", device)
             grad_allmap = _prep(grad_allmap, "grad_allmap", device)
             view = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
-                         float(rs.scale_modifier), int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                         float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)),
                          ctx.cap, bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
             new = lambda *s: torch.empty(s, dtype=torch.float32, device=device)
             g_means3D = new(P, 3)

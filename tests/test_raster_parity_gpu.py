@@ -421,3 +421,47 @@ def test_quad_reduce_scatter_selftest(hip_lib):
     got = out.cpu().numpy().reshape(16, 22)
     ref = x.double().reshape(16, 4, 22).sum(1).numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_opt_in_culling_of_transparent_surfels_changes_no_pixel(hip_lib):
+    """`rasterizer.set_cull_transparent(True)`: surfels with opacity < 1/255 can never pass the composite's
+    1/255 alpha test, so culling them in the preprocess must leave every rendered map unchanged (to an ulp) and the
+    gradients equal up to summation order (round and segment boundaries move); `radii` of the culled surfels read 0 and the
+    pair count drops.  Still within the oracle's tolerance (the oracle keeps them, as the published code does)."""
+    from lara_amd import GaussianRasterizer, rasterizer
+    act, cams = small_scene(grid=16, size=128, seed=3, regime="trained")
+    cam, bg = cams[1], (0.0, 0.5, 1.0)
+    rs = raster_settings(cam, bg, device=DEV)
+    transparent = (act["opacities"].squeeze(-1) < 1.0 / 255.0)
+    assert 0.3 < float(transparent.float().mean()) < 0.99
+    g = torch.Generator().manual_seed(2)
+    res = []
+    for on in (False, True):
+        prev = rasterizer.set_cull_transparent(on)
+        try:
+            inp = {k: v.to(DEV).requires_grad_(True) for k, v in act.items()}
+            color, radii, allmap = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]),
+                                                          shs=inp["shs"], opacities=inp["opacities"], scales=inp["scales"],
+                                                          rotations=inp["rotations"])
+            if not res:
+                dc, da = torch.randn(color.shape, generator=g).to(DEV), (torch.randn(allmap.shape, generator=g) * 0.1).to(DEV)
+            ((color * dc).sum() + (allmap * da).sum()).backward()
+            st = _gpu_forward(rs, act)
+            res.append((color.detach(), allmap.detach(), radii, {k: v.grad.clone() for k, v in inp.items()},
+                        int(st["views"]["header"][0])))
+        finally:
+            rasterizer.set_cull_transparent(prev)
+    (c0, a0, r0, g0, d0), (c1, a1, r1, g1, d1) = res
+    # (a handful of pixels move by one ulp: the walk's rounds are cut at other list positions)
+    assert float((c0 - c1).abs().max()) <= 2.5e-7 and float((a0 - a1).abs().max()) <= 1e-6
+    assert float((c0 != c1).any(0).float().mean()) <= 1e-2
+    tr = transparent.to(DEV)
+    assert torch.equal(r1[~tr], r0[~tr]) and not r1[tr].any() and r0[tr].any() and d1 < d0
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max()) + 1e-12, k
+        assert not g1[k][tr].any()
+    prev = rasterizer.set_cull_transparent(True)
+    try:
+        _grad_check(act, cam, bg)           # and the oracle's tolerance still holds
+    finally:
+        rasterizer.set_cull_transparent(prev)
