@@ -452,7 +452,7 @@ def test_opt_in_culling_of_transparent_surfels_changes_no_pixel(hip_lib):
         finally:
             rasterizer.set_cull_transparent(prev)
     (c0, a0, r0, g0, d0), (c1, a1, r1, g1, d1) = res
-    # (a handful of pixels move by one ulp: the walk's rounds are cut at other list positions)
+    # (a handful of pixels move by one ulp: list positions shift, and with them the evaluation slot of a splat)
     assert float((c0 - c1).abs().max()) <= 2.5e-7 and float((a0 - a1).abs().max()) <= 1e-6
     assert float((c0 != c1).any(0).float().mean()) <= 1e-2
     tr = transparent.to(DEV)
