@@ -614,7 +614,8 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     p.A = A; p.B = B; p.part = part; p.nbr = nbr; p.M = M; p.lda = lda; p.ldb = ldb; p.N = N; p.Kc = Kc; p.T = T;
     p.chunk = chunk; p.tiles = tiles;
     if ((size_t)splits * out_bytes > TN_PART_BYTES) return LARA2DGS_E_INVALID;
-    const bool staged = !((M & 31) || (N & 7) || (Kc & 7) || (lda & 7) || (ldb & 7)) && !getenv("LARA_TN_DIRECT");
+    static const bool force_direct = getenv("LARA_TN_DIRECT") != nullptr;  // (experiments: the per-lane-load kernel)
+    const bool staged = !((M & 31) || (N & 7) || (Kc & 7) || (lda & 7) || (ldb & 7)) && !force_direct;
     if (staged) {
         if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);

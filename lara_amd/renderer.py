@@ -119,6 +119,13 @@ class Renderer(nn.Module):
     def get_rotation(self, _rotation):
         return self.rotation_activation(_rotation)
 
+    def _zero_means2D(self, centers):
+        z = getattr(self, "_zeros2d", None)
+        if z is None or z.shape != centers.shape or z.device != centers.device or z.dtype != centers.dtype:
+            z = torch.zeros_like(centers, requires_grad=False)
+            self._zeros2d = z
+        return z
+
     def _activated(self, opacity, scales, rotations):
         """The activated tensors of the last call are reused while the caller passes the same (unmodified)
         tensor objects in the same autograd mode: the 8 views of a scene then share one sigmoid / exp /
@@ -137,7 +144,9 @@ class Renderer(nn.Module):
                    depth_ratio=0.0):
         rasterizer = self.set_rasterizer(cam, device=device)
         opacity, scales, rotations = self._activated(opacity, scales, rotations)
-        screenspace_points = torch.zeros_like(centers, dtype=centers.dtype, requires_grad=True, device=device) + 0
+        # the reference builds a fresh zero tensor that requires grad per view (renderer_2dgs.py:194-205) to read
+        # screen-space gradients it no longer returns (:264-266 are commented out): one shared constant does here
+        screenspace_points = self._zero_means2D(centers)
         rendered_image, radii, allmap = rasterizer(means3D=centers, means2D=screenspace_points, shs=shs, opacities=opacity,
                                                    scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
         if rays is None:
