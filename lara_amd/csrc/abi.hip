@@ -167,9 +167,8 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
     StateView st = carve_state(v, state);
     ScratchLayout SL;
     ScratchView sc = carve_scratch(v, scratch, SL);
-    // header + tile_count + tile_fill start at zero
-    hipError_t e = hipMemsetAsync(st.header, 0, 256, s);
-    if (e == hipSuccess) e = hipMemsetAsync(sc.tile_count, 0, (size_t)(SL.sub_start - SL.tile_count), s);
+    // tile_count + tile_fill start at zero (the header is initialised by tile_scan, the first kernel to use it)
+    hipError_t e = hipMemsetAsync(sc.tile_count, 0, (size_t)(SL.sub_start - SL.tile_count), s);
     if (e != hipSuccess) { l2d_set_hip_error(e); return LARA2DGS_E_LAUNCH; }
     int rc = launch_preprocess_fwd(v, means3D, shs, colors_precomp, opacities, scales, rotations,
                                    transmat_precomp, st, sc, out_radii, s);

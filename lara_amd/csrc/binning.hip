@@ -57,6 +57,9 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
     __shared__ uint32_t bcnt[64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
+    // this kernel is the first to touch the header (words 0-3 are assigned below, the rest are the composite
+    // kernels' debug counters): zeroing it here saves the forward a memset launch
+    if (tid >= 4 && tid < 64) header[tid] = 0u;
     __syncthreads();
     uint32_t max_len = 0;
     for (int base = 0; base < v.tiles; base += 1024) {
