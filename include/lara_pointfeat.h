@@ -18,6 +18,8 @@
  * acc_map [V,h,w], depth [V,h,w,1] (channel-last, as `render_img` returns them); out [V,8,n].  fp32, device.
  * Backward: g_out [V,8,n] -> d_points [n,3] (overwritten) and ACCUMULATES into d_image, d_acc_map, d_depth
  * (caller zero-fills; float atomics, like torch's grid_sample backward; any of the three may be NULL).
+ * `workspace`: lara_point_feats_workspace_bytes(V, h, w) bytes (a packed channel-last copy of the four maps, 32
+ * bytes per pixel, and in the backward its gradient); nothing is kept between calls.
  * Returns 0 or a negative LARA2DGS_E_* code; work is enqueued on `stream`, no host synchronisation.
  */
 #ifndef LARA_POINTFEAT_H
@@ -29,14 +31,16 @@
 extern "C" {
 #endif
 
+int64_t lara_point_feats_workspace_bytes(int32_t V, int32_t h, int32_t w);
+
 int lara_point_feats_forward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
                              const float *ixts, const float *img_ref, const float *image, const float *acc_map,
-                             const float *depth, float *out, void *stream);
+                             const float *depth, float *out, void *workspace, void *stream);
 
 int lara_point_feats_backward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
                               const float *ixts, const float *img_ref, const float *image, const float *acc_map,
                               const float *depth, const float *g_out, float *d_points, float *d_image,
-                              float *d_acc_map, float *d_depth, void *stream);
+                              float *d_acc_map, float *d_depth, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

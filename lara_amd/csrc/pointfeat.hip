@@ -1,7 +1,7 @@
 // pointfeat.hip -- LaRa's fine-stage point sampler (lightning/network.py:390-411 with projection :182-187):
 // projection of the Gaussian centres into the input views + bilinear gather of the 8-channel image stack + depth
-// residual, one thread per (point, view); the backward scatters into the render-derived channels with float
-// atomics and sums the coordinate gradient over the views with lane shuffles.
+// residual, one thread per (point, view) over a packed channel-last copy of the maps; the backward scatters into a
+// stack of the same shape with float atomics and sums the coordinate gradient over the views with lane shuffles.
 // include/lara_pointfeat.h has the formulas and the contract.
 #include "common.h"
 #include "../../include/lara_pointfeat.h"
@@ -38,12 +38,35 @@ __device__ __forceinline__ Tap taps(const float x, const float y, const int h, c
     return t;
 }
 
-// channel c of view v at pixel index `pix` (c: 0-2 input image, planar; 3-5 render, channel-last; 6 acc; 7 depth)
-__device__ __forceinline__ float chan(const PfP &p, const int v, const int c, const int pix) {
-    const size_t hw = (size_t)p.h * p.w;
-    if (c < 3) return p.img_ref[((size_t)v * 3 + c) * hw + pix];
-    if (c < 6) return p.image[((size_t)v * hw + pix) * 3 + (c - 3)];
-    return c == 6 ? p.acc[(size_t)v * hw + pix] : p.depth[(size_t)v * hw + pix];
+// The four tensors are first packed into one channel-last stack [V, h, w, 8] (32 bytes per pixel: a bilinear tap
+// is then two 16-byte loads from one cache line instead of eight 4-byte loads from six different lines -- the
+// sampler is bound by the lines it touches, not by arithmetic), and the backward scatters into a stack of the
+// same shape that `unpack_grad_kernel` folds into the three gradient tensors.
+__global__ void __launch_bounds__(256)
+pack_stack_kernel(const PfP p, float4 *__restrict__ packed) {
+    const size_t hw = (size_t)p.h * p.w, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)p.V * hw) return;
+    const size_t v = i / hw, pix = i - v * hw;
+    const float *im = p.image + i * 3;
+    packed[2 * i] = make_float4(p.img_ref[(v * 3 + 0) * hw + pix], p.img_ref[(v * 3 + 1) * hw + pix],
+                                p.img_ref[(v * 3 + 2) * hw + pix], im[0]);
+    packed[2 * i + 1] = make_float4(im[1], im[2], p.acc[i], p.depth[i]);
+}
+
+__global__ void __launch_bounds__(256)
+unpack_grad_kernel(const float4 *__restrict__ dpacked, const size_t n, float *d_image, float *d_acc, float *d_depth) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = dpacked[2 * i], b = dpacked[2 * i + 1];
+    if (d_image) { d_image[3 * i] += a.w; d_image[3 * i + 1] += b.x; d_image[3 * i + 2] += b.y; }
+    if (d_acc) d_acc[i] += b.z;
+    if (d_depth) d_depth[i] += b.w;
+}
+
+// the 8 channels of view v at pixel index `pix`
+__device__ __forceinline__ void chan8(const float4 *__restrict__ packed, const size_t hw, const int v, const int pix, float (&c)[8]) {
+    const float4 a = packed[2 * ((size_t)v * hw + pix)], b = packed[2 * ((size_t)v * hw + pix) + 1];
+    c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
 }
 
 struct Proj { float x, y, z, cx, cy, cz; };  // pixel position, depth, camera-space point
@@ -64,61 +87,80 @@ __device__ __forceinline__ Proj project(const PfP &p, const int v, const float p
 // backward's sum over the views is a lane shuffle.
 template <int VP>
 __global__ void __launch_bounds__(256)
-point_feats_fwd_kernel(const PfP p, float *__restrict__ out) {
+point_feats_fwd_kernel(const PfP p, const float4 *__restrict__ packed, float *__restrict__ out) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int i = (int)(tid / VP), v = (int)(tid % VP);
     if (i >= p.n || v >= p.V) return;
+    const size_t hw = (size_t)p.h * p.w;
     const float px = p.points[3 * (size_t)i], py = p.points[3 * (size_t)i + 1], pz = p.points[3 * (size_t)i + 2];
     const Proj pr = project(p, v, px, py, pz);
     const Tap t = taps(pr.x, pr.y, p.h, p.w);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        float s = 0.f;
+    for (int k = 0; k < 4; k++)
+        if (t.in[k]) {
+            float c[8];
+            chan8(packed, hw, v, t.idx[k], c);
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (t.in[k]) s += t.wgt[k] * chan(p, v, c, t.idx[k]);
-        out[((size_t)v * 8 + c) * p.n + i] = c == 7 ? fabsf(s - pr.z) : s;
-    }
+            for (int ch = 0; ch < 8; ch++) s[ch] += t.wgt[k] * c[ch];
+        }
+#pragma unroll
+    for (int ch = 0; ch < 8; ch++) out[((size_t)v * 8 + ch) * p.n + i] = ch == 7 ? fabsf(s[ch] - pr.z) : s[ch];
 }
 
 template <int VP>
 __global__ void __launch_bounds__(256)
-point_feats_bwd_kernel(const PfP p, const float *__restrict__ g_out, float *__restrict__ d_points,
-                       float *d_image, float *d_acc, float *d_depth) {
+point_feats_bwd_kernel(const PfP p, const float4 *__restrict__ packed, const float *__restrict__ g_out,
+                       float *__restrict__ d_points, float *dpacked) {
+    // scatter staging: per thread 4 tap offsets (into the gradient stack, -1 = outside), 4 weights, 8 channel gradients
+    __shared__ int s_off[4][64][4];
+    __shared__ float s_wgt[4][64][4], s_g[4][64][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int i = (int)(tid / VP), v = (int)(tid % VP);
     const bool active = i < p.n && v < p.V;
     const size_t hw = (size_t)p.h * p.w;
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+    if (dpacked && !active) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_off[wave][lane][k] = -1;
+    }
     if (active) {
         const float px = p.points[3 * (size_t)i], py = p.points[3 * (size_t)i + 1], pz = p.points[3 * (size_t)i + 2];
         const Proj pr = project(p, v, px, py, pz);
         const Tap t = taps(pr.x, pr.y, p.h, p.w);
-        float gx = 0.f, gy = 0.f, gz = 0.f;
+        float val[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (t.in[k]) chan8(packed, hw, v, t.idx[k], val[k]);
+            else
+#pragma unroll
+                for (int c = 0; c < 8; c++) val[k][c] = 0.f;
+        }
+        float gx = 0.f, gy = 0.f, gz = 0.f, gc[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             float g = g_out[((size_t)v * 8 + c) * p.n + i];
-            float val[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) val[k] = t.in[k] ? chan(p, v, c, t.idx[k]) : 0.f;
             if (c == 7) {  // | s - z |
-                const float s = t.wgt[0] * val[0] + t.wgt[1] * val[1] + t.wgt[2] * val[2] + t.wgt[3] * val[3];
+                const float s = t.wgt[0] * val[0][c] + t.wgt[1] * val[1][c] + t.wgt[2] * val[2][c] + t.wgt[3] * val[3][c];
                 const float d = s - pr.z, sg = d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f;
                 gz -= sg * g;
                 g *= sg;
             }
+            gc[c] = g;
             // d s / d x, d s / d y (a tap outside the image contributes its zero)
-            gx += g * ((val[1] - val[0]) * (1.f - t.wy) + (val[3] - val[2]) * t.wy);
-            gy += g * ((val[2] - val[0]) * (1.f - t.wx) + (val[3] - val[1]) * t.wx);
-            if (c >= 3) {
+            gx += g * ((val[1][c] - val[0][c]) * (1.f - t.wy) + (val[3][c] - val[2][c]) * t.wy);
+            gy += g * ((val[2][c] - val[0][c]) * (1.f - t.wx) + (val[3][c] - val[1][c]) * t.wx);
+        }
+        // park this thread's scatter work for the wave-cooperative pass below
+        if (dpacked) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (!t.in[k]) continue;
-                    if (c < 6) { if (d_image) atomicAdd(d_image + ((size_t)v * hw + t.idx[k]) * 3 + (c - 3), t.wgt[k] * g); }
-                    else if (c == 6) { if (d_acc) atomicAdd(d_acc + (size_t)v * hw + t.idx[k], t.wgt[k] * g); }
-                    else { if (d_depth) atomicAdd(d_depth + (size_t)v * hw + t.idx[k], t.wgt[k] * g); }
-                }
+            for (int k = 0; k < 4; k++) {
+                s_off[wave][lane][k] = t.in[k] ? (int)(((size_t)v * hw + t.idx[k]) * 8) : -1;
+                s_wgt[wave][lane][k] = t.wgt[k];
             }
+#pragma unroll
+            for (int c = 0; c < 8; c++) s_g[wave][lane][c] = gc[c];
         }
         // (x, y, z) = (qx / qz, qy / qz, qz), q = K p_c, p_c = R p + t
         const float inv = 1.0f / pr.z;
@@ -130,6 +172,19 @@ point_feats_bwd_kernel(const PfP p, const float *__restrict__ g_out, float *__re
         dpy = m[1] * dcx + m[5] * dcy + m[9] * dcz;
         dpz = m[2] * dcx + m[6] * dcy + m[10] * dcz;
     }
+    // Scatter, wave-cooperative: 8 lanes = the 8 channels of one (thread, tap), so the atomics of a lane group
+    // fall into one 32-byte pixel of the gradient stack and one instruction touches 8 cache lines instead of 64
+    // (the L2 works per line: 21 M single-float atomics per launch became 4 M line operations).
+    if (dpacked) {
+        __builtin_amdgcn_wave_barrier();
+        const int ch = lane & 7;
+#pragma unroll 4
+        for (int r = 0; r < 32; r++) {
+            const int item = r * 8 + (lane >> 3), th = item >> 2, k = item & 3;
+            const int off = s_off[wave][th][k];
+            if (off >= 0 && ch >= 3) atomicAdd(dpacked + off + ch, s_wgt[wave][th][k] * s_g[wave][th][ch]);  // (0-2: input image)
+        }
+    }
 #pragma unroll
     for (int o = 1; o < VP; o <<= 1) {  // sum over the views of the point (neighbouring lanes; fixed order)
         dpx += __shfl_xor(dpx, o, 64); dpy += __shfl_xor(dpy, o, 64); dpz += __shfl_xor(dpz, o, 64);
@@ -140,35 +195,49 @@ point_feats_bwd_kernel(const PfP p, const float *__restrict__ g_out, float *__re
 }
 
 template <int VP>
-void launch_fwd(const PfP &p, float *out, hipStream_t s) {
+void launch_fwd(const PfP &p, const float4 *packed, float *out, hipStream_t s) {
     const size_t threads = (size_t)p.n * VP;
-    hipLaunchKernelGGL((point_feats_fwd_kernel<VP>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, out);
+    hipLaunchKernelGGL((point_feats_fwd_kernel<VP>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, packed, out);
 }
 template <int VP>
-void launch_bwd(const PfP &p, const float *g_out, float *d_points, float *d_image, float *d_acc, float *d_depth, hipStream_t s) {
+void launch_bwd(const PfP &p, const float4 *packed, const float *g_out, float *d_points, float *dpacked, hipStream_t s) {
     const size_t threads = (size_t)p.n * VP;
-    hipLaunchKernelGGL((point_feats_bwd_kernel<VP>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, g_out, d_points,
-                       d_image, d_acc, d_depth);
+    hipLaunchKernelGGL((point_feats_bwd_kernel<VP>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, packed, g_out,
+                       d_points, dpacked);
+}
+void launch_pack(const PfP &p, float4 *packed, hipStream_t s) {
+    const size_t n = (size_t)p.V * p.h * p.w;
+    hipLaunchKernelGGL(pack_stack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, packed);
 }
 
 }  // namespace
 
 extern "C" {
 
+int64_t lara_point_feats_workspace_bytes(int32_t V, int32_t h, int32_t w) {
+    if (V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)h * w >= (1ll << 31)) return LARA2DGS_E_INVALID;
+    return (int64_t)V * h * w * 32 * 2;  // the packed stack and (backward) its gradient
+}
+
 int lara_point_feats_forward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
                              const float *ixts, const float *img_ref, const float *image, const float *acc_map,
-                             const float *depth, float *out, void *stream) {
+                             const float *depth, float *out, void *workspace, void *stream) {
     if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)h * w >= (1ll << 31)) return LARA2DGS_E_INVALID;
     if (n == 0) return LARA2DGS_OK;
-    if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !out) return LARA2DGS_E_INVALID;
+    if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !out || !workspace) return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const PfP p{n, V, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth};
+    float4 *packed = (float4 *)workspace;
+    {
+        L2D_PROF("point_feats_pack", s);
+        launch_pack(p, packed, s);
+    }
     {
         L2D_PROF("point_feats_fwd", s);
-        if (V == 1) launch_fwd<1>(p, out, s);
-        else if (V == 2) launch_fwd<2>(p, out, s);
-        else if (V <= 4) launch_fwd<4>(p, out, s);
-        else launch_fwd<8>(p, out, s);
+        if (V == 1) launch_fwd<1>(p, packed, out, s);
+        else if (V == 2) launch_fwd<2>(p, packed, out, s);
+        else if (V <= 4) launch_fwd<4>(p, packed, out, s);
+        else launch_fwd<8>(p, packed, out, s);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
@@ -177,18 +246,31 @@ int lara_point_feats_forward(int32_t n, int32_t V, int32_t h, int32_t w, const f
 int lara_point_feats_backward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
                               const float *ixts, const float *img_ref, const float *image, const float *acc_map,
                               const float *depth, const float *g_out, float *d_points, float *d_image,
-                              float *d_acc_map, float *d_depth, void *stream) {
+                              float *d_acc_map, float *d_depth, void *workspace, void *stream) {
     if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)h * w >= (1ll << 31)) return LARA2DGS_E_INVALID;
     if (n == 0) return LARA2DGS_OK;
-    if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !g_out || !d_points) return LARA2DGS_E_INVALID;
+    if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !g_out || !d_points || !workspace)
+        return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const PfP p{n, V, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth};
+    const size_t npix = (size_t)V * h * w;
+    float4 *packed = (float4 *)workspace;
+    const bool maps = d_image || d_acc_map || d_depth;
+    float *dpacked = maps ? (float *)workspace + npix * 8 : nullptr;
+    {
+        L2D_PROF("point_feats_pack", s);
+        launch_pack(p, packed, s);   // (stateless: the forward's stack is rebuilt rather than kept alive)
+        if (maps && hipMemsetAsync(dpacked, 0, npix * 32, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    }
     {
         L2D_PROF("point_feats_bwd", s);
-        if (V == 1) launch_bwd<1>(p, g_out, d_points, d_image, d_acc_map, d_depth, s);
-        else if (V == 2) launch_bwd<2>(p, g_out, d_points, d_image, d_acc_map, d_depth, s);
-        else if (V <= 4) launch_bwd<4>(p, g_out, d_points, d_image, d_acc_map, d_depth, s);
-        else launch_bwd<8>(p, g_out, d_points, d_image, d_acc_map, d_depth, s);
+        if (V == 1) launch_bwd<1>(p, packed, g_out, d_points, dpacked, s);
+        else if (V == 2) launch_bwd<2>(p, packed, g_out, d_points, dpacked, s);
+        else if (V <= 4) launch_bwd<4>(p, packed, g_out, d_points, dpacked, s);
+        else launch_bwd<8>(p, packed, g_out, d_points, dpacked, s);
+        if (maps)
+            hipLaunchKernelGGL(unpack_grad_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float4 *)dpacked, npix,
+                               d_image, d_acc_map, d_depth);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -26,11 +26,20 @@ def _lib():
     if not _configured:
         vp, i32 = ctypes.c_void_p, ctypes.c_int32
         lib.lara_point_feats_forward.restype = ctypes.c_int
-        lib.lara_point_feats_forward.argtypes = [i32, i32, i32, i32] + [vp] * 9
+        lib.lara_point_feats_forward.argtypes = [i32, i32, i32, i32] + [vp] * 10
         lib.lara_point_feats_backward.restype = ctypes.c_int
-        lib.lara_point_feats_backward.argtypes = [i32, i32, i32, i32] + [vp] * 13
+        lib.lara_point_feats_backward.argtypes = [i32, i32, i32, i32] + [vp] * 14
+        lib.lara_point_feats_workspace_bytes.restype = ctypes.c_int64
+        lib.lara_point_feats_workspace_bytes.argtypes = [i32, i32, i32]
         _configured = True
     return lib
+
+
+def _workspace(device, V, h, w):
+    n = _lib().lara_point_feats_workspace_bytes(V, h, w)
+    if n < 0:
+        _check(int(n), "lara_point_feats_workspace_bytes")
+    return torch.empty(int(n), dtype=torch.uint8, device=device)
 
 
 class _PointFeats(torch.autograd.Function):
@@ -46,10 +55,11 @@ class _PointFeats(torch.autograd.Function):
             raise RuntimeError("expected points [n,3], w2cs [V,4,4], ixts [V,3,3], img_ref [V,3,h,w], image [V,h,w,3], "
                                "acc_map [V,h,w], depth [V,h,w,1]")
         out = torch.empty(V, 8, n, dtype=torch.float32, device=points.device)
+        ws = _workspace(points.device, V, h, w)
         with torch.cuda.device(points.device):
             _check(_lib().lara_point_feats_forward(n, V, h, w, points.data_ptr(), w2cs.data_ptr(), ixts.data_ptr(),
                                                    img_ref.data_ptr(), image.data_ptr(), acc_map.data_ptr(), depth.data_ptr(),
-                                                   out.data_ptr(), torch.cuda.current_stream(points.device).cuda_stream),
+                                                   out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(points.device).cuda_stream),
                    "lara_point_feats_forward")
         ctx.save_for_backward(points, w2cs, ixts, img_ref, image, acc_map, depth)
         return out
@@ -65,11 +75,12 @@ class _PointFeats(torch.autograd.Function):
         d_acc = torch.zeros_like(acc_map) if need[5] else None
         d_depth = torch.zeros_like(depth) if need[6] else None
         ptr = lambda t: None if t is None else t.data_ptr()
+        ws = _workspace(points.device, V, h, w)
         with torch.cuda.device(points.device):
             _check(_lib().lara_point_feats_backward(n, V, h, w, points.data_ptr(), w2cs.data_ptr(), ixts.data_ptr(),
                                                     img_ref.data_ptr(), image.data_ptr(), acc_map.data_ptr(), depth.data_ptr(),
                                                     g_out.data_ptr(), d_points.data_ptr(), ptr(d_image), ptr(d_acc), ptr(d_depth),
-                                                    torch.cuda.current_stream(points.device).cuda_stream),
+                                                    ws.data_ptr(), torch.cuda.current_stream(points.device).cuda_stream),
                    "lara_point_feats_backward")
         return d_points if need[0] else None, None, None, None, d_image, d_acc, d_depth
 
