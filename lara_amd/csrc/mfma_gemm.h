@@ -134,6 +134,54 @@ __device__ __forceinline__ void xcd_tile(int &rt, int &ct) {
 // (training, gemm_bf16_nt_kernel only)
 //     6: z = acc + bias -> bf16 C2, gelu(z) -> bf16 C       7: bf16 store of acc * gelu'(C2)
 //     8: fp32 store
+// The fused epilogues, applied to four consecutive columns (row, col .. col + 3) of the accumulator tile; `base_out`
+// is EPI 5's output offset of the row's voxel (2d, 2h, 2w).  Shared by both GEMM kernels.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP &p, float4 v, const int row, const int col, const int N,
+                                              const unsigned long long base_out) {
+    const size_t o = (size_t)row * N + col;
+    if (EPI == 2 || EPI == 3 || EPI == 6) {
+        const float4 bs = *(const float4 *)(p.bias + col);
+        v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+    }
+    if (EPI == 0 || EPI == 2 || EPI == 6 || EPI == 7) {
+        if (EPI == 6) {
+            ushort4 z;
+            z.x = f2bf(v.x); z.y = f2bf(v.y); z.z = f2bf(v.z); z.w = f2bf(v.w);
+            *(ushort4 *)(p.C2 + o) = z;
+        }
+        if (EPI == 7) {
+            const ushort4 z = *(const ushort4 *)(p.C2 + o);
+            v.x *= gelu_erf_grad(bf2f(z.x)); v.y *= gelu_erf_grad(bf2f(z.y));
+            v.z *= gelu_erf_grad(bf2f(z.z)); v.w *= gelu_erf_grad(bf2f(z.w));
+        }
+        if (EPI == 2 || EPI == 6) {  // erf GELU (nn.GELU's default); the result is rounded to bf16 anyway
+            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+        }
+        ushort4 h;
+        h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
+        *(ushort4 *)((unsigned short *)p.C + o) = h;
+    } else if (EPI == 8) {
+        *(float4 *)((float *)p.C + o) = v;
+    } else if (EPI == 1 || EPI == 3) {
+        const float4 rs = *(const float4 *)(p.resid + o);
+        *(float4 *)((float *)p.C + o) = make_float4(v.x + rs.x, v.y + rs.y, v.z + rs.z, v.w + rs.w);
+    } else if (EPI == 4) {
+        const float4 rs = *(const float4 *)(p.resid + o);
+        const float2 st = p.stats[row];
+        const float4 ga = *(const float4 *)(p.gamma + col), be = *(const float4 *)(p.beta + col);
+        *(float4 *)((float *)p.C + o) =
+            make_float4(v.x + (rs.x - st.x) * st.y * ga.x + be.x, v.y + (rs.y - st.x) * st.y * ga.y + be.y,
+                        v.z + (rs.z - st.x) * st.y * ga.z + be.z, v.w + (rs.w - st.x) * st.y * ga.w + be.w);
+    } else {  // EPI 5: column = tap * Cout + co, tap = (i*2 + j)*2 + k of the 2x2x2 kernel
+        const int tap = col / p.Cout, co = col - tap * p.Cout;
+        const size_t R2 = 2 * (size_t)p.R;
+        const size_t oo = (base_out + ((size_t)(tap >> 2) * R2 + ((tap >> 1) & 1)) * R2 + (tap & 1)) * p.Cout + co;
+        const float4 bs = *(const float4 *)(p.bias + co);
+        *(float4 *)((float *)p.C + oo) = make_float4(v.x + bs.x, v.y + bs.y, v.z + bs.z, v.w + bs.w);
+    }
+}
+
 template <int AMODE, int EPI, int GM = 128, int GN = 128>
 __global__ void __launch_bounds__(256)
 gemm_bf16_nt_kernel(const GemmP p) {
@@ -276,50 +324,8 @@ gemm_bf16_nt_kernel(const GemmP p) {
         for (int q = 0; q < 8; q++) {
             const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
             const int row = bm0 + wm + i * 32 + lr, col = bn0 + wn + jh * 64 + c4;
-            if (row < M && col < N) {
-                float4 v = *(const float4 *)(ep + lr * 68 + c4);
-                const size_t o = (size_t)row * N + col;
-                if (EPI == 2 || EPI == 3 || EPI == 6) {
-                    const float4 bs = *(const float4 *)(p.bias + col);
-                    v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
-                }
-                if (EPI == 0 || EPI == 2 || EPI == 6 || EPI == 7) {
-                    if (EPI == 6) {
-                        ushort4 z;
-                        z.x = f2bf(v.x); z.y = f2bf(v.y); z.z = f2bf(v.z); z.w = f2bf(v.w);
-                        *(ushort4 *)(p.C2 + o) = z;
-                    }
-                    if (EPI == 7) {
-                        const ushort4 z = *(const ushort4 *)(p.C2 + o);
-                        v.x *= gelu_erf_grad(bf2f(z.x)); v.y *= gelu_erf_grad(bf2f(z.y));
-                        v.z *= gelu_erf_grad(bf2f(z.z)); v.w *= gelu_erf_grad(bf2f(z.w));
-                    }
-                    if (EPI == 2 || EPI == 6) {  // erf GELU (nn.GELU's default); the result is rounded to bf16 anyway
-                        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-                    }
-                    ushort4 h;
-                    h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
-                    *(ushort4 *)((unsigned short *)p.C + o) = h;
-                } else if (EPI == 8) {
-                    *(float4 *)((float *)p.C + o) = v;
-                } else if (EPI == 1 || EPI == 3) {
-                    const float4 rs = *(const float4 *)(p.resid + o);
-                    *(float4 *)((float *)p.C + o) = make_float4(v.x + rs.x, v.y + rs.y, v.z + rs.z, v.w + rs.w);
-                } else if (EPI == 4) {
-                    const float4 rs = *(const float4 *)(p.resid + o);
-                    const float2 st = p.stats[row];
-                    const float4 ga = *(const float4 *)(p.gamma + col), be = *(const float4 *)(p.beta + col);
-                    *(float4 *)((float *)p.C + o) =
-                        make_float4(v.x + (rs.x - st.x) * st.y * ga.x + be.x, v.y + (rs.y - st.x) * st.y * ga.y + be.y,
-                                    v.z + (rs.z - st.x) * st.y * ga.z + be.z, v.w + (rs.w - st.x) * st.y * ga.w + be.w);
-                } else {  // EPI 5: column = tap * Cout + co, tap = (i*2 + j)*2 + k of the 2x2x2 kernel
-                    const int tap = col / p.Cout, co = col - tap * p.Cout;
-                    const size_t R2 = 2 * (size_t)p.R;
-                    const size_t oo = (rowbase[lr] + ((size_t)(tap >> 2) * R2 + ((tap >> 1) & 1)) * R2 + (tap & 1)) * p.Cout + co;
-                    const float4 bs = *(const float4 *)(p.bias + co);
-                    *(float4 *)((float *)p.C + oo) = make_float4(v.x + bs.x, v.y + bs.y, v.z + bs.z, v.w + bs.w);
-                }
-            }
+            if (row < M && col < N)
+                gemm_epilogue<EPI>(p, *(const float4 *)(ep + lr * 68 + c4), row, col, N, EPI == 5 ? rowbase[lr] : 0ull);
         }
     }
 }
@@ -480,36 +486,8 @@ gemm_ring_kernel(const GemmP p) {
         for (int q = 0; q < 8; q++) {
             const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
             const int row = bm0 + wr * 128 + i * 32 + lr, col = bn0 + wc * 64 + c4;
-            if (row < M && col < N) {
-                float4 v = *(const float4 *)(ep + lr * 68 + c4);
-                const size_t o = (size_t)row * N + col;
-                if (EPI == 2 || EPI == 3) {
-                    const float4 bs = *(const float4 *)(p.bias + col);
-                    v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
-                }
-                if (EPI == 0 || EPI == 2) {
-                    if (EPI == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-                    ushort4 h;
-                    h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
-                    *(ushort4 *)((unsigned short *)p.C + o) = h;
-                } else if (EPI == 1 || EPI == 3) {
-                    const float4 rs = *(const float4 *)(p.resid + o);
-                    *(float4 *)((float *)p.C + o) = make_float4(v.x + rs.x, v.y + rs.y, v.z + rs.z, v.w + rs.w);
-                } else if (EPI == 4) {
-                    const float4 rs = *(const float4 *)(p.resid + o);
-                    const float2 st = p.stats[row];
-                    const float4 ga = *(const float4 *)(p.gamma + col), be = *(const float4 *)(p.beta + col);
-                    *(float4 *)((float *)p.C + o) =
-                        make_float4(v.x + (rs.x - st.x) * st.y * ga.x + be.x, v.y + (rs.y - st.x) * st.y * ga.y + be.y,
-                                    v.z + (rs.z - st.x) * st.y * ga.z + be.z, v.w + (rs.w - st.x) * st.y * ga.w + be.w);
-                } else {
-                    const int tap = col / p.Cout, co = col - tap * p.Cout;
-                    const size_t R2 = 2 * (size_t)p.R;
-                    const size_t oo = (rowbase[lr] + ((size_t)(tap >> 2) * R2 + ((tap >> 1) & 1)) * R2 + (tap & 1)) * p.Cout + co;
-                    const float4 bs = *(const float4 *)(p.bias + co);
-                    *(float4 *)((float *)p.C + oo) = make_float4(v.x + bs.x, v.y + bs.y, v.z + bs.z, v.w + bs.w);
-                }
-            }
+            if (row < M && col < N)
+                gemm_epilogue<EPI>(p, *(const float4 *)(ep + lr * 68 + c4), row, col, N, EPI == 5 ? rowbase[lr] : 0ull);
         }
     }
 }
