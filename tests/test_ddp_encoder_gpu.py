@@ -1,0 +1,63 @@
+"""The trainable volume transformer behind torch's own DistributedDataParallel, two ranks (RCCL wants one GPU per
+rank; the test box has one, so both ranks share it and talk over gloo -- DDP's hooks, buckets and averaging are the
+same code either way): after backward both ranks hold the same gradients, equal to the mean of the two ranks' local
+gradients, i.e. the HIP backward feeds DDP like any torch module (train_lightning.py:72)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    from lara_amd.encoder_train import VolTransformer
+    torch.manual_seed(3)
+    return VolTransformer(embed_dim=256, image_feat_dim=800, n_groups=[2], vol_low_res=4, vol_high_res=8, out_dim=80,
+                          num_layers=2, num_heads=16).to("cuda:0")
+
+
+def _inputs(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return (torch.randn(1, 4, 800, 2, 2, 2, generator=g).to("cuda:0"), torch.randn(1, 8, 8, 8, 80, generator=g).to("cuda:0"))
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ddp = torch.nn.parallel.DistributedDataParallel(_model(), find_unused_parameters=True)
+        feats, dout = _inputs(rank)
+        (ddp(feats) * dout).sum().backward()
+        torch.cuda.synchronize()
+        out.put((rank, {n: p.grad.cpu().numpy() for n, p in ddp.module.named_parameters()}))   # (by value: this process exits)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hip_backward_feeds_torch_ddp(hip_lib):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=600) for _ in range(2))
+    got = {r: {n: torch.from_numpy(a) for n, a in d.items()} for r, d in got.items()}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    local = []
+    for rank in range(2):
+        m = _model()
+        feats, dout = _inputs(rank)
+        (m(feats) * dout).sum().backward()
+        local.append({n: p.grad.cpu() for n, p in m.named_parameters()})
+    for n in got[0]:
+        assert torch.equal(got[0][n], got[1][n]), n
+        mean = (local[0][n] + local[1][n]) / 2
+        assert float((got[0][n] - mean).abs().max()) <= 1e-6 * float(mean.abs().max()) + 1e-9, n
