@@ -71,3 +71,38 @@ def test_trainable_voltransformer_fits_a_target(hip_lib):
     with torch.no_grad():
         last = float(F.mse_loss(vt(feats), target))
     assert math.isfinite(last) and last < 0.5 * first, (first, last)
+
+
+def test_ops_are_unaffected_by_bf16_autocast(hip_lib):
+    """LaRa trains under Lightning's bf16-mixed precision (train_lightning.py:74), i.e. inside torch.autocast: the
+    custom ops take fp32 (or cast what they get) and must give the same bits inside and outside the context, with
+    half-precision inputs accepted."""
+    from lara_amd import cameras, synthetic
+    from lara_amd.encoder_train import VolTransformer
+    from lara_amd.renderer import Renderer
+    sc = synthetic.make_scene(grid=10, K=2, seed=2, device=DEV)
+    sc["scales"] = sc["scales"] + math.log(64 / 10)
+    cam = cameras.make_cameras(cameras.turntable_c2w(4), 64, 64, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8, device=DEV)[1]
+    rays = torch.cat([torch.zeros(64, 64, 3), F.normalize(torch.randn(64, 64, 3), dim=-1)], -1).to(DEV)
+    r = Renderer(sh_degree=1, white_background=True)
+    torch.manual_seed(0)
+    vt = VolTransformer(256, 800, [2], 4, 8, 80, 1, 16).to(DEV)
+    feats = torch.randn(1, 4, 800, 2, 2, 2, device=DEV)
+
+    def run(autocast):
+        p = {k: v.clone().requires_grad_(True) for k, v in sc.items()}
+        f = feats.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            shs = p["shs"].to(torch.bfloat16).float() if autocast else p["shs"].to(torch.bfloat16).float()
+            o = r.render_img(cam, rays, p["centers"], shs, p["opacity"], p["scales"], p["rotations"], DEV)
+            vol = vt(f.to(torch.bfloat16) if autocast else f.to(torch.bfloat16).float())
+            loss = o["image"].sum() + o["depth"].sum() + o["depth_normal"].sum() + vol.float().pow(2).mean()
+        loss.backward()
+        return [o["image"].detach(), o["depth"].detach(), vol.detach(), p["centers"].grad, p["shs"].grad, f.grad,
+                vt.layers[0].cnn.weight.grad.clone()]
+
+    a = run(False)
+    vt.zero_grad()
+    b = run(True)
+    for x, y in zip(a, b):
+        assert x.dtype == y.dtype and torch.equal(x, y)
