@@ -215,14 +215,14 @@ void launch_pack(const PfP &p, float4 *packed, hipStream_t s) {
 extern "C" {
 
 int64_t lara_point_feats_workspace_bytes(int32_t V, int32_t h, int32_t w) {
-    if (V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)h * w >= (1ll << 31)) return LARA2DGS_E_INVALID;
+    if (V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)V * h * w * 8 >= (1ll << 31)) return LARA2DGS_E_INVALID;  // 32-bit offsets into the stack
     return (int64_t)V * h * w * 32 * 2;  // the packed stack and (backward) its gradient
 }
 
 int lara_point_feats_forward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
                              const float *ixts, const float *img_ref, const float *image, const float *acc_map,
                              const float *depth, float *out, void *workspace, void *stream) {
-    if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)h * w >= (1ll << 31)) return LARA2DGS_E_INVALID;
+    if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)V * h * w * 8 >= (1ll << 31)) return LARA2DGS_E_INVALID;  // 32-bit offsets into the stack
     if (n == 0) return LARA2DGS_OK;
     if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !out || !workspace) return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -247,7 +247,7 @@ int lara_point_feats_backward(int32_t n, int32_t V, int32_t h, int32_t w, const 
                               const float *ixts, const float *img_ref, const float *image, const float *acc_map,
                               const float *depth, const float *g_out, float *d_points, float *d_image,
                               float *d_acc_map, float *d_depth, void *workspace, void *stream) {
-    if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)h * w >= (1ll << 31)) return LARA2DGS_E_INVALID;
+    if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)V * h * w * 8 >= (1ll << 31)) return LARA2DGS_E_INVALID;  // 32-bit offsets into the stack
     if (n == 0) return LARA2DGS_OK;
     if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !g_out || !d_points || !workspace)
         return LARA2DGS_E_INVALID;
