@@ -72,3 +72,14 @@ def test_product_path_never_imports_the_oracle():
                     src = open(os.path.join(dirpath, f)).read()
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                     assert "surfel_oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback anywhere: without liblara2dgs.so every entry point raises (on the GPU box that means a failed
+    build is visible at the first call, not a silent torch path)."""
+    import pytest
+    import lara_amd.rasterizer as rz
+    monkeypatch.setattr(rz, "LIB_PATH", str(tmp_path / "liblara2dgs.so"))
+    monkeypatch.setattr(rz, "_lib", None, raising=False)
+    with pytest.raises(RuntimeError, match="HIP library not found"):
+        rz.load_library()
