@@ -9,7 +9,9 @@
  * rays are written where they are consumed (lightning/network.py:364,493,522;
  * renderer_2dgs.py:78-89).
  *
- *   Hs = (int)(H * scale), Ws = (int)(W * scale);  K_s = diag(scale, scale, 1) * K
+ *   Hs = int(H * scale), Ws = int(W * scale) -- computed ONCE, by the caller, exactly as the reference
+ *   does in Python (double precision), and passed in: the library never re-derives the output size;
+ *   `scale` only rescales the intrinsics:  K_s = diag(scale, scale, 1) * K
  *   rays[v, y, x, 0:3] = c2w[v][0:3, 3]
  *   rays[v, y, x, 3:6] = R_v * K_s^-1 * (x + 0.5, y + 0.5, 1)^T            (R_v = c2w[v][0:3, 0:3])
  *
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-int lara_build_rays(int32_t n_views, int32_t H, int32_t W, float scale, const float *c2ws,
+int lara_build_rays(int32_t n_views, int32_t Hs, int32_t Ws, float scale, const float *c2ws,
                     const float *ixts, float *rays, void *stream);
 
 #ifdef __cplusplus

@@ -54,7 +54,8 @@ def build_rays(c2ws: torch.Tensor, ixts: torch.Tensor, H: int, W: int, scale: fl
     Hs, Ws = int(H * scale), int(W * scale)
     rays = torch.empty(V, Hs, Ws, 6, dtype=torch.float32, device=c.device)
     with torch.cuda.device(c.device):
-        rc = _lib().lara_build_rays(V, int(H), int(W), float(scale), c.data_ptr(), k.data_ptr(), rays.data_ptr(),
+        # the output size is computed once, here, as the reference does (double precision), and handed over
+        rc = _lib().lara_build_rays(V, Hs, Ws, float(scale), c.data_ptr(), k.data_ptr(), rays.data_ptr(),
                                     torch.cuda.current_stream(c.device).cuda_stream)
     _check(rc, "lara_build_rays")
     return rays

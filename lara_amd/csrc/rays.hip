@@ -46,11 +46,13 @@ build_rays_kernel(const int Hs, const int Ws, const float scale, const float *__
 
 }  // namespace
 
-extern "C" int lara_build_rays(int32_t n_views, int32_t H, int32_t W, float scale, const float *c2ws,
+extern "C" int lara_build_rays(int32_t n_views, int32_t Hs, int32_t Ws, float scale, const float *c2ws,
                                const float *ixts, float *rays, void *stream) {
-    if (n_views < 0 || H <= 0 || W <= 0 || !(scale > 0.f)) return LARA2DGS_E_INVALID;
-    const int Hs = (int)(H * scale), Ws = (int)(W * scale);
+    // Hs, Ws are the OUTPUT size, computed once by the caller (the reference's int(H*scale) is a
+    // double-precision product; recomputing it here in fp32 could disagree by one row)
+    if (n_views < 0 || Hs < 0 || Ws < 0 || !(scale > 0.f)) return LARA2DGS_E_INVALID;
     if (n_views == 0 || Hs == 0 || Ws == 0) return LARA2DGS_OK;
+    if ((int64_t)Hs * Ws > 0x7fffffff) return LARA2DGS_E_INVALID;
     if (!c2ws || !ixts || !rays || n_views > 65535) return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     {

@@ -229,9 +229,14 @@ class VolTransformer(nn.Module):
         B, R = image_feats.shape[0], self.vol_low_res
         dev = image_feats.device
         cond = cond_tokens(image_feats, self.n_groups[0])
-        if self._pos_tokens is None or self._pos_tokens.device != dev:
+        # positional volume in token order, cached with the identity of what it was computed from: a
+        # load_state_dict / copy_ into pos_embed bumps the version, and any graph captured on the old copy goes too
+        pos_key = (self.pos_embed.data_ptr(), self.pos_embed._version, dev)
+        if self._pos_tokens is None or getattr(self, "_pos_key", None) != pos_key:
             with torch.no_grad():
                 self._pos_tokens = volume_to_tokens(self.pos_embed.detach().to(dev))
+            self._pos_key = pos_key
+            self._graphs = {}
         need = B * R ** 3 * 512
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -127,6 +127,13 @@ def _layer_bf16(p):
     return f
 
 
+def invalidate_weight_cache():
+    """Drop the cached bf16 operands.  Needed only after parameters were written through `.data` (e.g. an EMA
+    swap-in `p.data.copy_(ema)`), which does not bump the version counter the cache is keyed on; optimiser steps,
+    `copy_` under no_grad and `load_state_dict` do bump it."""
+    _wcache.clear()
+
+
 def _layer_bf16_t(f):
     return {"wq_t": f["wq"].t().contiguous(), "wkv_t": f["wkv"].t().contiguous(), "wo_t": f["wo"].t().contiguous(),
             "w1_t": f["w1"].t().contiguous(), "w2_t": f["w2"].t().contiguous(),
@@ -257,6 +264,11 @@ class GroupAttBlock(nn.Module):
         if inner_dim != 256 or num_heads != 16 or attn_bias or mlp_ratio != 2. or attn_drop or mlp_drop:
             raise ValueError("kernels are specialised for LaRa's 256-dim, 16-head, bias-free, dropout-free blocks "
                              "(configs/base.yaml:17-20)")
+        if cond_dim == inner_dim:
+            # nn.MultiheadAttention then stores ONE fused in_proj_weight instead of q/k/v_proj_weight, a
+            # different state_dict layout from the one the kernels' parameter list names
+            raise ValueError("cond_dim must differ from inner_dim (LaRa: 800 vs 256); the fused in_proj_weight "
+                             "layout of nn.MultiheadAttention is not supported")
         self.norm1 = nn.LayerNorm(inner_dim)
         self.cross_attn = nn.MultiheadAttention(embed_dim=inner_dim, num_heads=num_heads, kdim=cond_dim, vdim=cond_dim,
                                                 dropout=attn_drop, bias=attn_bias, batch_first=True)

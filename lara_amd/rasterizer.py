@@ -174,7 +174,12 @@ def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor
     if t.device != device:
         raise RuntimeError(f"lara_amd: `{name}` is on {t.device}, expected {device}")
     if t.dtype != torch.float32:
-        raise RuntimeError(f"lara_amd: `{name}` must be float32, got {t.dtype}")
+        # the reference reads `.contiguous().data<float>()` and would mis-read anything else; a drop-in casts
+        # (differentiable inputs are cast OUTSIDE the autograd node, in rasterize_gaussians, so that autograd maps the
+        # gradient back to the caller's dtype; this branch serves the settings tensors and incoming gradients)
+        if not t.is_floating_point():
+            raise RuntimeError(f"lara_amd: `{name}` must be a floating-point tensor, got {t.dtype}")
+        t = t.float()
     if not t.is_contiguous():
         t = t.contiguous()
     if t.data_ptr() % 16:
@@ -356,8 +361,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         return g_means3D, g_means2D, g_sh, g_col, g_opac, g_sc, g_rot, g_tm, None
 
 
+def _as_f32(t):
+    return t.float() if (t is not None and t.is_floating_point() and t.dtype != torch.float32) else t
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings):
+    # fp32 is the rasteriser's arithmetic (as the reference's); bf16 / fp16 / fp64 inputs are cast here, through
+    # autograd (SURVEY.md section 8b asks for custom_fwd(cast_inputs=float32): torch's custom_fwd cannot rebuild the
+    # settings NamedTuple it would recurse into, and the node holds no autocast-sensitive torch op -- only raw-pointer
+    # kernel launches -- so the explicit cast is the whole of its effect)
+    means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = (
+        _as_f32(t) for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rotations, cov3Ds_precomp, raster_settings)
 

@@ -126,19 +126,35 @@ class Renderer(nn.Module):
             self._zeros2d = z
         return z
 
+    @staticmethod
+    def _tensor_key(t):
+        # what the tensor IS, not which Python object wraps it: the reference's loop (network.py:496, :524) passes
+        # `_opacity_coarse[i]` etc., a fresh view object on every call over the same storage
+        if t is None:
+            return None
+        return (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device, t._version,
+                t.requires_grad)
+
     def _activated(self, opacity, scales, rotations):
-        """The activated tensors of the last call are reused while the caller passes the same (unmodified)
-        tensor objects in the same autograd mode: the 8 views of a scene then share one sigmoid / exp /
-        normalize node.  (Call `loss.backward()` after all views of those tensors, as network.py does: a
-        backward in between frees the shared nodes' graph.)"""
-        # (id() is stable and unique while the cache holds a reference to the tensor object itself)
-        key = tuple((id(t), t._version, t.requires_grad) if t is not None else None
-                    for t in (opacity, scales, rotations)) + (torch.is_grad_enabled(),)
+        """The activated tensors of the last call are reused while the caller passes tensors over the same
+        memory (same address, layout, dtype, version counter, requires_grad) in the same autograd mode: the 8
+        views of a scene then share one sigmoid / exp / normalize node although `_opacity_coarse[i]` is a new
+        Python object per call.  The cache holds the inputs it was computed from, so their storage cannot be
+        freed and handed to another tensor while the entry lives (an address match is a real match).  Not covered:
+        writes through `.data` (they do not bump the version counter) -- call `invalidate_activations()` after
+        such a write.  The fine pass's `x[mask]` arguments are new storage per call and are recomputed per view,
+        as in the reference; `render_views` shares them explicitly.  (Call `loss.backward()` after all views of
+        those tensors, as network.py does: a backward in between frees the shared nodes' graph.)"""
+        key = tuple(self._tensor_key(t) for t in (opacity, scales, rotations)) + (torch.is_grad_enabled(),)
         if key != self._act_key:
             self._act_val = (self.get_opacity(opacity), None if scales is None else self.get_scaling(scales),
                              None if rotations is None else self.get_rotation(rotations), (opacity, scales, rotations))
             self._act_key = key
         return self._act_val[:3]
+
+    def invalidate_activations(self):
+        """Drop the cached activations (and the references to the tensors they were computed from)."""
+        self._act_key, self._act_val = None, None
 
     def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device, cov3D_precomp=None, prex='',
                    depth_ratio=0.0):

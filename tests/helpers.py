@@ -50,3 +50,79 @@ def run_oracle(view, act_np, **kw):
 def psnr(a, b, peak=1.0):
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
     return 999.0 if mse == 0 else 10.0 * math.log10(peak * peak / mse)
+
+
+def pixel_walk(ref, px, py, W):
+    """Replays pixel (px, py)'s front-to-back walk in float64 from the oracle's per-surfel records (the forward of
+    oracle/surfel_oracle.c).  Per list entry j (0-based) returns how close the walk comes to
+    each of the three DISCRETE decisions that define n_contrib / median_contributor:
+        alpha[j]  : |alpha_j - 1/255| / (1/255)            the skip test (inf where the entry is culled earlier)
+        stop[j]   : |T_j (1 - alpha_j) - 1e-4| / 1e-4      the termination test (inf where not reached / skipped)
+        median[j] : |T_j - 0.5| / 0.5                      the median test
+    """
+    gx = (W + 15) // 16
+    tile = (py // 16) * gx + px // 16
+    s, e = int(ref.ranges[tile, 0]), int(ref.ranges[tile, 1])
+    ids = ref.point_list[s:e].astype(np.int64)
+    Tm = ref.transMats[ids].astype(np.float64)
+    Tu, Tv, Tw = Tm[:, 0:3], Tm[:, 3:6], Tm[:, 6:9]
+    k = px * Tw - Tu
+    l = py * Tw - Tv
+    p = np.cross(k, l)
+    ok = p[:, 2] != 0
+    pz = np.where(ok, p[:, 2], 1.0)
+    sx, sy = p[:, 0] / pz, p[:, 1] / pz
+    rho3d = sx * sx + sy * sy
+    d = ref.means2D[ids].astype(np.float64) - np.array([px, py], np.float64)
+    rho2d = 2.0 * (d * d).sum(1)
+    rho = np.minimum(rho3d, rho2d)
+    depth = np.where(rho3d <= rho2d, sx * Tw[:, 0] + sy * Tw[:, 1] + Tw[:, 2], Tw[:, 2])
+    opa = ref.normal_opacity[ids, 3].astype(np.float64)
+    alpha = np.minimum(0.99, opa * np.exp(-0.5 * rho))
+    cand = ok & (depth >= 0.2) & (rho >= 0)
+    n = len(ids)
+    m_alpha = np.where(cand, np.abs(alpha - 1 / 255) * 255, np.inf)
+    m_stop, m_med = np.full(n, np.inf), np.full(n, np.inf)
+    T = 1.0
+    for j in range(n):
+        if not cand[j] or alpha[j] < (1 / 255) * (1 - 1e-2):
+            continue                      # (entries within 1 % of the skip threshold are walked as if blended)
+        tt = T * (1 - alpha[j])
+        m_stop[j] = abs(tt - 1e-4) / 1e-4
+        if tt < 1e-4 * (1 - 1e-2):
+            break
+        m_med[j] = abs(T - 0.5) / 0.5
+        T = tt
+    return {"alpha": m_alpha, "stop": m_stop, "median": m_med}
+
+
+def explain_contrib_mismatches(ref, n_contrib_hip, W, tol_alpha=1e-3, tol_T=5e-3, limit=4000):
+    """For every pixel whose last / median contributor (1-based list positions) differs from the oracle's, look at
+    the list entries BETWEEN the two answers: one side blended (or took as median) an entry there that the other did
+    not, so one of those entries must sit within rounding distance of a decision threshold -- alpha within
+    `tol_alpha` (relative) of 1/255, or T(1-alpha) / T within `tol_T` of 1e-4 / 0.5 (`tol_T` > 1/255: one legitimate
+    alpha flip EARLIER in the list moves every later T by a factor 1 - 1/255).  Returns a dict: mismatching pixels,
+    pixels NOT explained that way, and the worst margins among the explained."""
+    bad = np.argwhere((n_contrib_hip[0] != ref.n_contrib[0]) | (n_contrib_hip[1] != ref.n_contrib[1]))
+    out = {"mismatching_pixels": int(len(bad)), "unexplained": 0, "worst_alpha_margin": 0.0, "worst_T_margin": 0.0,
+           "by_alpha_flip": 0, "by_T_flip": 0}
+    for py, px in bad[:limit]:
+        w = pixel_walk(ref, int(px), int(py), W)
+        ok = True
+        for ch in (0, 1):
+            a, b = int(n_contrib_hip[ch, py, px]), int(ref.n_contrib[ch, py, px])
+            if a == b:
+                continue
+            lo0, hi = max(min(a, b) - 1, 0), max(a, b)
+            ma = float(w["alpha"][lo0:hi].min()) if hi > lo0 else np.inf
+            mt = float(np.minimum(w["stop"][lo0:hi], w["median"][lo0:hi] if ch == 1 else np.inf).min()) if hi > lo0 else np.inf
+            if ma <= tol_alpha:
+                out["by_alpha_flip"] += 1
+                out["worst_alpha_margin"] = max(out["worst_alpha_margin"], ma)
+            elif mt <= tol_T:
+                out["by_T_flip"] += 1
+                out["worst_T_margin"] = max(out["worst_T_margin"], mt)
+            else:
+                ok = False
+        out["unexplained"] += 0 if ok else 1
+    return out

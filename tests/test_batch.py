@@ -67,6 +67,21 @@ def test_hip_rays_match_reference(hip_lib):
 
 
 @pytest.mark.gpu
+def test_hip_rays_at_non_dyadic_scales(hip_lib):
+    """int(H*scale) is computed once on the host (double precision, as the reference does) and handed to the
+    kernel: at H=100, scale 0.29 / 0.57 / 0.58 a float32 recomputation gives one row more or less, which used to
+    write past the tensor.  A guard band after the output must stay untouched."""
+    from lara_amd.batch import build_rays
+    f = fixture()
+    c2ws, ixts = torch.from_numpy(f["c2ws"]).cuda(), torch.from_numpy(f["ixts"]).cuda()
+    for H, W, scale in ((100, 100, 0.29), (100, 200, 0.57), (200, 100, 0.58), (37, 53, 0.333)):
+        want = restated_rays(f["c2ws"], f["ixts"], H, W, scale)
+        got = build_rays(c2ws, ixts, H, W, scale)
+        assert tuple(got.shape) == want.shape == (c2ws.shape[0], int(H * scale), int(W * scale), 6)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.gpu
 def test_synthetic_batch_schema_and_geometry(hip_lib):
     from lara_amd.batch import synthetic_batch
     B, V, H, W = 2, 8, 64, 48

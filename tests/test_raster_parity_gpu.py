@@ -20,11 +20,23 @@ import pytest
 import torch
 
 import oracle
-from tests.helpers import (oracle_view, psnr, raster_settings, run_oracle, small_scene, to_numpy)
+from tests.helpers import (explain_contrib_mismatches, oracle_view, psnr, raster_settings, run_oracle, small_scene,
+                           to_numpy)
 
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+_CONTRIB_LOG = []   # one record per forward comparison: mismatching pixels and how each is explained
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_contrib_log():
+    yield
+    import json, os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "n_contrib_mismatches.json"), "w") as f:
+        json.dump(_CONTRIB_LOG, f, indent=1)
 
 
 def _gpu_forward(rs, act, **kw):
@@ -69,8 +81,14 @@ def _check_forward(r, ref, H, W):
             d = d[same]
         assert d.max() <= 5e-3 * scale, f"allmap[{ch}] max diff {d.max()}"
         assert (d > 5e-5 * scale).mean() <= 1e-3, f"allmap[{ch}]"
-    nc = views["n_contrib"][0].cpu().numpy().view(np.uint32)
-    assert (nc == ref.n_contrib[0]).mean() >= 0.999
+    # n_contrib / median_contributor: EXACT sequential semantics, except at pixels that provably sit on a
+    # decision threshold (an entry between the two answers has alpha within 1e-3 of 1/255, or T within 5e-3 of
+    # 1e-4 / 0.5 -- tests/helpers.py: explain_contrib_mismatches); those are counted and bounded
+    nc = views["n_contrib"].cpu().numpy().view(np.uint32)
+    ex = explain_contrib_mismatches(ref, nc, W)
+    _CONTRIB_LOG.append({"HxW": f"{H}x{W}", "D": D, **ex})
+    assert ex["unexplained"] == 0, ex
+    assert ex["mismatching_pixels"] <= 1e-3 * H * W, ex
     return D
 
 
@@ -327,6 +345,37 @@ def test_mark_visible_and_argument_errors(hip_lib):
     with pytest.raises(RuntimeError, match="no CPU path"):
         rast(means3D=act["means3D"], means2D=None, opacities=act["opacities"], shs=act["shs"],
              scales=act["scales"], rotations=act["rotations"])
+
+
+def test_non_fp32_inputs_are_cast_not_rejected(hip_lib):
+    """The reference reads `.contiguous().data<float>()`; a drop-in casts what is not fp32:
+    bf16 / fp64 inputs give the result of their fp32 values, gradients come back in the caller's dtype, and a
+    non-contiguous input is accepted."""
+    from lara_amd import GaussianRasterizer
+    act, cams = small_scene(grid=6, size=48, seed=1)
+    rs = raster_settings(cams[0], (1, 1, 1), device=DEV)
+    base = {k: v.to(DEV) for k, v in act.items()}
+    base["shs"] = base["shs"].to(torch.bfloat16).float()     # values representable in bf16
+
+    def run(conv):
+        inp = {k: conv(k, v).requires_grad_(True) for k, v in base.items()}
+        color, _, allmap = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]),
+                                                  shs=inp["shs"], opacities=inp["opacities"], scales=inp["scales"],
+                                                  rotations=inp["rotations"])
+        (color.sum() + allmap.sum()).backward()
+        return color.detach(), allmap.detach(), inp
+
+    c0, a0, i0 = run(lambda k, v: v.clone())
+    c1, a1, i1 = run(lambda k, v: v.to(torch.bfloat16) if k == "shs" else (v.double() if k == "means3D" else
+                                                                        v.t().contiguous().t() if k == "scales" else v.clone()))
+    assert c1.dtype == torch.float32 and torch.equal(c0, c1) and torch.equal(a0, a1)
+    assert i1["shs"].grad.dtype == torch.bfloat16 and i1["means3D"].grad.dtype == torch.float64
+    assert torch.equal(i1["means3D"].grad.float(), i0["means3D"].grad)
+    assert torch.equal(i1["shs"].grad, i0["shs"].grad.to(torch.bfloat16))
+    assert torch.equal(i1["scales"].grad, i0["scales"].grad)
+    with pytest.raises(RuntimeError, match="floating-point"):
+        GaussianRasterizer(rs)(means3D=base["means3D"], means2D=None, shs=base["shs"], opacities=base["opacities"],
+                               scales=base["scales"].long(), rotations=base["rotations"])
 
 
 def test_full_size_properties_and_oracle(hip_lib):
