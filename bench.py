@@ -1,29 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- novel-view frames/sec @512x512 (4-view in, 2DGS fwd+bwd) on MI355X.
 
-One *step* = one pass of the raster hot path over one training batch as LaRa's step issues it
-(lightning/network.py:473-497): B = 4 scenes x 8 target views (4 input + 4 novel,
-dataLoader/gobjverse.py:46-47), each view = one GaussianRasterizer forward over the scene's
-P = 524 288 surfels at 512x512 (configs/base.yaml:13,23,34) + its backward.  A *frame* is one such
-forward + backward.  `value` = frames of all ranks / max-over-ranks wall time of the timed steps,
-with scenes, cameras and incoming gradients already resident in HBM.  Data is synthetic (no
-dataset / checkpoint in this environment): SURVEY.md section 8d, lara_amd/synthetic.py.
+One *step* = one pass of the hot path (every row of SURVEY.md section 8a) over one training batch, ordered as a LaRa
+training step orders it (lightning/network.py:431-532, lightning/system.py:38-60): on every rank, for its B = 4
+scenes,
+    1. the volume transformer's forward (`encoder_train.VolTransformer`, rows A1-A3; under
+       `DistributedDataParallel` when N > 1, as train_lightning.py:68-81 does with DDPStrategy),
+    2. the raster: per scene 8 coarse views (4 input + 4 novel, dataLoader/gobjverse.py:46-47) and -- LaRa's fine
+       stage, network.py:502-525 -- 8 more over the opacity > 0.005 subset; each view = one GaussianRasterizer
+       forward over the scene's P = 524 288 surfels at 512x512 (configs/base.yaml:13,23,34),
+    3. the backward of all of it: every view's rasteriser backward, then the transformer's backward, whose
+       parameter gradients DDP all-reduces bucket by bucket (25 MB buckets, RCCL over xGMI) while the backward is
+       still running.  That all-reduce is the path's only exchange step; the raster is per view and NOT sharded
+       (BASELINE.json north_star) -> per-scene data parallel, weak scaling.
+A *frame* is one rasteriser forward + backward.  `value` = frames of all ranks /
+max-over-ranks wall time of the timed steps, with scenes, cameras, image features and incoming gradients already
+resident in HBM.  Data is synthetic (no dataset / checkpoint in this environment): SURVEY.md section 8d,
+lara_amd/synthetic.py; the encoder and the raster run on independent synthetic tensors of the right shapes (the
+decoder MLP between them is outside section 8a).  `--step raster` times the raster alone (round 1's definition);
+the default line carries it as `raster_only`.
 
-Multi-GPU: per-scene data parallel, one process per GPU (torch.distributed, backend nccl = RCCL);
-the raster itself is per view and is NOT sharded (BASELINE.json north_star) -> weak scaling, every
-rank renders its own B scenes.  The only exchange step of LaRa's training step is DDP's gradient
-all-reduce of the encoder parameters (train_lightning.py:72); the encoder is outside this path, so
-ranks all-reduce a stand-in fp32 buffer of the encoder's size (126.3 M parameters, SURVEY.md
-section 2 #12) in 25 MB buckets on a side stream, overlapped with the raster backward.
+`python bench.py --gpus N` with N > 1 launches its own N ranks (torch.distributed.run, one per GPU, backend nccl =
+RCCL) when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py --gpus N`
+it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
-The scenes of a step are independent, so they are spread over `--streams` HIP streams (default 2: the
-composite kernels end in a tail of a few heavy tiles and the binning has single-workgroup steps; a
-second stream fills those holes).  "single_stream" repeats the measurement with every call on the
-current stream, i.e. exactly as the reference's Python loop would issue it.
+The scenes of a step are independent, so their raster work is spread over `--streams` HIP streams (default 2: the
+composite kernels end in a tail of a few heavy tiles; a second stream fills those holes).
 
-Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed, algorithmic bytes
-from DESIGN.md / SURVEY.md section 8d), "cpu_baseline" (the CPU oracle on a bounded sample),
-"single_stream", "attention", "encoder" and "encoder_train" (MFMA legs, reported beside the raster).
+Extra objects on the JSON line (rank 0, N = 1): "roofline" (dominant kernel, HIP-event timed, algorithmic bytes of
+SURVEY.md section 8d; `bound` says what binds it), "cpu_baseline" (the CPU oracle of the raster AND the fixture-pinned
+fp32 restatement of the reference's encoder, both on this box's host cores), "raster_only", "single_stream",
+"forward_only", "attention", "encoder", "encoder_train", "rays", "render_img", "point_feats".
 """
 import argparse
 import contextlib
@@ -40,7 +47,6 @@ if ROOT not in sys.path:
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
-ENCODER_PARAMS = 126_300_000  # VolTransformer 39.45 M + Decoder + ViT-B/16 ~86 M
 
 
 def parse():
@@ -53,12 +59,37 @@ def parse():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--grid", type=int, default=64, help="surfels = grid^3 * 2 (64 -> 524288)")
     ap.add_argument("--regime", default="init", choices=["init", "trained"])
+    ap.add_argument("--step", default="train", choices=["train", "raster"],
+                    help="train: encoder fwd + raster fwd/bwd + encoder bwd (DDP all-reduce when N > 1); raster: the raster alone")
+    ap.add_argument("--no-fine", action="store_true", help="coarse views only (LaRa before train.start_fine)")
+    ap.add_argument("--encoder-layers", type=int, default=12, help="transformer depth (configs/base.yaml:16: 12)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent scenes of a step are spread over (1 = the reference's sequential loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-res", type=int, default=512)
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the side objects (attention, encoder, rays, ...)")
     return ap.parse_args()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks, one per GPU, and relay rank 0's line."""
+    import socket
+    import subprocess
+    backend = os.environ.get("LARA_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and os.environ.get("LARA_BENCH_PLUMBING", "0") != "1":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; RCCL wants one rank per device "
+                             "(LARA_BENCH_BACKEND=gloo lets ranks share a device for plumbing tests)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def build_batch(args, device, rank):
@@ -86,37 +117,57 @@ def build_batch(args, device, rank):
 
 
 _streams = []
+FINE_OPACITY = 0.005   # network.py:465: the fine stage keeps Gaussians with opacity > 0.005
 
 
-def step(scenes, settings, gc, ga, n_streams=1):
+def fine_subsets(scenes):
+    """Per scene: row indices of the fine stage's subset (`masks = sigmoid(opacity) > 0.005`, network.py:464-465),
+    computed once per batch like the reference does, as index tensors (a boolean mask index would synchronise the
+    host on every use)."""
+    with torch.no_grad():
+        return [(torch.sigmoid(sc["opacity"].detach()).squeeze(-1) > FINE_OPACITY).nonzero().squeeze(-1) for sc in scenes]
+
+
+def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None):
     """All forwards of the batch, then one backward through every view (as loss.backward() does).
-    Scenes are independent (the unit the north star data-parallelises over), so scene i is enqueued on
-    HIP stream i % n_streams; autograd replays each view's backward on its forward's stream.  The
-    composite kernels end with a tail of a few heavy tiles and the binning has single-workgroup
-    steps: a second stream fills those holes with the next scene's work."""
+    Per scene: the coarse views (network.py:487-497) and, with `fine_idx`, the fine views over the masked subset with
+    refined SH coefficients (network.py:508-525; the refinement itself -- `forward_fine` -- is a side leg, here the
+    subset's coefficients are offset by a constant).  Activations and subset gathers are applied per view, as the
+    reference's `render_img` / loop do.  Scenes are independent (the unit the north star data-parallelises over), so
+    scene i is enqueued on HIP stream i % n_streams; autograd replays each view's backward on its forward's stream.
+    `after(outs, grads)` appends further roots to the one backward call (the encoder's output and its gradient)."""
     from lara_amd import GaussianRasterizer
     outs, grads = [], []
     cur = torch.cuda.current_stream()
     while len(_streams) < n_streams and n_streams > 1:
         _streams.append(torch.cuda.Stream())
+
+    def render(rs, centers, shs, opacity, scales, rotations):
+        # the reference's activations, applied per view (renderer_2dgs.py:181-189)
+        means2D = torch.zeros_like(centers, requires_grad=True)
+        color, radii, allmap = GaussianRasterizer(rs)(
+            means3D=centers, means2D=means2D, shs=shs, opacities=torch.sigmoid(opacity), scales=torch.exp(scales),
+            rotations=torch.nn.functional.normalize(rotations), cov3D_precomp=None)
+        outs.extend((color, allmap))
+        grads.extend((gc, ga))
+
     for i, sc in enumerate(scenes):
         side = _streams[i % n_streams] if n_streams > 1 else None
         if side is not None:
             side.wait_stream(cur)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-          for rs in settings:
-            # the reference's activations, applied per view (renderer_2dgs.py:181-189)
-            opac = torch.sigmoid(sc["opacity"])
-            scales = torch.exp(sc["scales"])
-            rots = torch.nn.functional.normalize(sc["rotations"])
-            means2D = torch.zeros_like(sc["centers"], requires_grad=True)
-            color, radii, allmap = GaussianRasterizer(rs)(
-                means3D=sc["centers"], means2D=means2D, shs=sc["shs"], opacities=opac,
-                scales=scales, rotations=rots, cov3D_precomp=None)
-            outs += [color, allmap]
-            grads += [gc, ga]
+            for rs in settings:
+                render(rs, sc["centers"], sc["shs"], sc["opacity"], sc["scales"], sc["rotations"])
+            if fine_idx is not None:
+                idx = fine_idx[i]
+                centers_f = sc["centers"][idx]                    # network.py:514
+                shs_f = sc["shs"][idx] + 0.01                     # network.py:518 (+ forward_fine's residual)
+                for rs in settings:                               # network.py:524: subset gathers per view
+                    render(rs, centers_f, shs_f, sc["opacity"][idx], sc["scales"][idx], sc["rotations"][idx])
     for side in _streams[:n_streams if n_streams > 1 else 0]:
         cur.wait_stream(side)
+    if after is not None:
+        after(outs, grads)
     torch.autograd.backward(outs, grads)
     for side in _streams[:n_streams if n_streams > 1 else 0]:
         cur.wait_stream(side)
@@ -179,31 +230,30 @@ def measure_roofline(scenes, settings, gc, ga, args):
     D = int(r["views"]["header"][0].item())
     P = scenes[0]["centers"].shape[0]
     HW = args.res * args.res
-    # ALGORITHMIC bytes per launch (DESIGN.md section "kernels and roofs")
+    # ALGORITHMIC bytes per launch: SURVEY.md section 8d's per-unit figures (forward 175 P + 120 D + 60 HW, backward
+    # 248 P + 220 D + 100 HW per frame) split over the kernels that move them
     alg = {
-        "preprocess_fwd": 88 * P + 92 * P,
+        "preprocess_fwd": 88 * P + 87 * P,
         "tile_scan": 12 * (HW // 256),
-        "scatter": 12 * P + 8 * D,
-        "tile_sort_small": 12 * D,
+        "scatter": 12 * D,
+        "tile_sort_small": 24 * D + 8 * D,
         "tile_sort_large": 0,
-        "composite_fwd": 84 * D + 60 * HW,
-        "composite_bwd": 84 * D + 100 * HW + 144 * D,
-        "preprocess_bwd": (88 + 80 + 80) * P + 88 * P,
+        "tile_sort": 24 * D + 8 * D,
+        "composite_fwd": 76 * D + 60 * HW,
+        "composite_bwd": 76 * D + 100 * HW + 144 * D,
+        "preprocess_bwd": (88 + 72) * P + 88 * P,
     }
     table = {k: {"launches": n, "avg_us": 1e3 * t / n, "alg_bytes": alg.get(k, 0),
                  "alg_GBs": (alg.get(k, 0) / (1e-3 * t / n) / 1e9) if t > 0 else 0.0}
              for k, (n, t) in agg.items()}
     dom = max(table, key=lambda k: table[k]["avg_us"] * table[k]["launches"])
     t = table[dom]
-    # HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE): they need rocprofv3 passes of
-    # their own, so they are collected by tools/gpu_traffic.sh and committed under profiles/
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01i.json")))
-        if args.regime == "init" and args.grid == 64 and args.res == 512:
-            traffic = tj["bytes_per_launch"][dom]["total"]
-    except Exception:
-        traffic = None
+    # Counter-derived figures need rocprofv3 passes of their own (tools/gpu_traffic.sh, tools/gpu_pmc_bwd.sh); their
+    # summaries are committed under profiles/ and READ here -- they are not measured in this run and say so.
+    traffic, traffic_src, valu, valu_src = None, None, None, None
+    if args.regime == "init" and args.grid == 64 and args.res == 512:
+        traffic, traffic_src = _newest_profile("traffic_r*.json", lambda f: json.load(open(f))["bytes_per_launch"][dom]["total"])
+        valu, valu_src = _newest_profile("r*_pmc_summary.csv", lambda f: _valu_issue_frac(f, dom))
     # what a plain device-to-device copy reaches on this box (read + write bytes / time): the achievable
     # HBM rate to hold beside the vendor peak (SURVEY.md section 8d asks for both)
     buf = torch.empty(2, 1 << 28, dtype=torch.uint8, device=scenes[0]["centers"].device)
@@ -216,18 +266,46 @@ def measure_roofline(scenes, settings, gc, ga, args):
     torch.cuda.synchronize()
     copy_GBs = 5 * 2 * (1 << 28) / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del buf
-    # the whole frame against the byte model of SURVEY.md section 8d (175 P + 120 D + 60 HW forward,
-    # 248 P + 220 D + 100 HW backward)
+    # the whole frame against the byte model of SURVEY.md section 8d
     frame_bytes = (175 + 248) * P + (120 + 220) * D + 160 * HW
     frame_us = sum(v["avg_us"] for v in table.values())
-    roof = {"kernel": dom, "bound": "hbm", "achieved": round(t["alg_GBs"], 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(t["alg_GBs"] / HBM_PEAK_GBS, 5), "traffic": traffic,
+    # `bound`: the composite kernels are VALU-issue bound in the init regime (SURVEY.md section 8d predicted an ALU
+    # floor 4-7x above the HBM floor; PMC: profiles/*_pmc_summary.csv); `frac` stays the HBM-roofline fraction the
+    # north star asks for, `valu_issue_frac` is the share of SIMD issue cycles spent on vector ALU instructions
+    composite = dom.startswith("composite")
+    roof = {"kernel": dom, "bound": "valu" if composite else "hbm", "achieved": round(t["alg_GBs"], 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(t["alg_GBs"] / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "valu_issue_frac": valu, "valu_issue_source": valu_src,
             "avg_launch_us": round(t["avg_us"], 2), "alg_bytes_per_launch": t["alg_bytes"],
             "pairs_per_frame_D": D, "measured_copy_GBs": round(copy_GBs, 1),
             "whole_frame": {"alg_bytes": frame_bytes, "kernel_us": round(frame_us, 1),
                             "achieved": round(frame_bytes / frame_us / 1e3, 1),
                             "frac": round(frame_bytes / frame_us / 1e3 / HBM_PEAK_GBS, 5)}}
     return roof, table, D
+
+
+def _newest_profile(pattern, reader):
+    """(value, 'profiles/<file> (committed rocprofv3 summary, not measured in this run)') from the newest match."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            v = reader(f)
+            if v is not None:
+                return v, f"profiles/{os.path.basename(f)} (committed rocprofv3 --pmc summary; not measured in this run)"
+        except Exception:
+            continue
+    return None, None
+
+
+def _valu_issue_frac(csv_path, kernel):
+    """SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is
+    the launch's duration in shader cycles."""
+    import csv
+    for r in csv.DictReader(open(csv_path)):
+        if r["kernel"].split("<")[0] == kernel and r.get("SQ_ACTIVE_INST_VALU") and r.get("GRBM_GUI_ACTIVE"):
+            return round(4.0 * float(r["SQ_ACTIVE_INST_VALU"]) / (1024.0 * float(r["GRBM_GUI_ACTIVE"])), 4)
+    return None
 
 
 def attention_leg(device, scenes):
@@ -380,9 +458,11 @@ def render_img_leg(device, args):
                 "rend_normal": normal.permute(1, 2, 0), "depth_normal": dn.permute(1, 2, 0), "rend_dist": allmap[6]}
 
     def one(mode):
-        p = {k: v.detach().requires_grad_(True) for k, v in sc.items()}
+        # as network.py:473-497 calls it: batched tensors [B, P, ...], a FRESH `x[i]` view object per view
+        pb = {k: v.detach()[None].requires_grad_(True) for k, v in sc.items()}
         loss = 0
         for cam, ray in zip(cams, rays):
+            p = {k: v[0] for k, v in pb.items()}
             o = (r.render_img(cam, ray, p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], device)
                  if mode == "fused" else ref_style(cam, ray, p))
             for k in keys:
@@ -484,7 +564,7 @@ def cpu_baseline(args):
     from lara_amd import cameras, synthetic
     sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=0)
     act = {k: v.numpy() for k, v in synthetic.activate(sc).items()}
-    res = args.cpu_sample_res
+    res = args.res   # the sample is a subset of the workload's frames, never a smaller frame
     cams = cameras.make_cameras(cameras.turntable_c2w(args.views), res, res, 0.75, 0.75,
                                 1.906 - 0.8, 1.906 + 0.8)
     oracle.build()
@@ -548,132 +628,260 @@ def cpu_baseline(args):
     return out
 
 
+def cpu_encoder_baseline(scenes=1):
+    """The reference's CPU encoder path (BASELINE.json configs[0], north_star: "next to the reference's CPU encoder
+    path timed on the same box's host cores in the same run"): `VolTransformer.forward` (network.py:138-164) +
+    `Decoder.forward_coarse` (network.py:259-278) for ONE scene at LaRa's sizes (32^3 x 256 volume, 12 layers, 4 views
+    x 16^3 x 800 image-feature tokens -> 524 288 Gaussians), fp32, torch on all host cores.  The reference modules
+    themselves cannot travel to this box (/root/reference is absent here); what runs is oracle/voltrans_ref.py, the
+    plain-torch restatement that tests/test_voltrans.py pins to the reference's own output (3e-5).  kind = "port"."""
+    from oracle.voltrans_ref import build_decoder_coarse, build_modules, restated_decoder_coarse, restated_voltrans
+    cores = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        m = build_modules(0, 32, 12)
+        dec = build_decoder_coarse(1)
+        feats = torch.randn(scenes, 4, 800, 16, 16, 16)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            vol = restated_voltrans(m, feats)
+            t1 = time.perf_counter()
+            offset, sh, scaling, rotation, opacity = restated_decoder_coarse(dec, vol, -2.1792, math.log(0.5 * (2 / 64) / 3))
+            t2 = time.perf_counter()
+        assert tuple(vol.shape) == (scenes, 64, 64, 64, 80) and tuple(opacity.shape) == (scenes, 524288, 1)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(scenes / (t2 - t0), 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "voltransformer_s": round(t1 - t0, 3), "decoder_coarse_s": round(t2 - t1, 3),
+            "sample": f"{scenes} scene (VolTransformer 12 x GroupAttBlock on 32^3 x 256 + ConvTranspose3d, then the coarse decoder "
+                      f"MLP -> 524288 Gaussians), fp32 torch, {cores} threads; one pass, no warm-up"}
+
+
+class _PlumbingEncoder(torch.nn.Module):
+    """LARA_BENCH_PLUMBING=1 (CPU tests of the launcher): a few linear layers stand in for the HIP encoder so that the
+    spawn / process-group / DDP / barrier / max-over-ranks / JSON path can run without a GPU.  Nothing is measured."""
+
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def make_training_step(args, device, rank, world, plumbing):
+    """Returns (full_step, info): the per-rank step described in the module docstring."""
+    info = {"grad_allreduce": None, "encoder": None}
+    ddp_kw = dict(find_unused_parameters=True, bucket_cap_mb=25)     # train_lightning.py:72 + torch's default bucket
+    if plumbing:
+        torch.manual_seed(0)
+        enc = _PlumbingEncoder().to(device)
+        feats, dout = torch.randn(8, 64, device=device), torch.randn(8, 64, device=device)
+        raster = lambda after: after and torch.autograd.backward(*_roots(after))
+        frames = args.scenes * args.views * (1 if args.no_fine else 2)
+    else:
+        from lara_amd import rasterizer
+        rasterizer.load_library()
+        scenes, settings, gc, ga = build_batch(args, device, rank)
+        fine_idx = None if args.no_fine else fine_subsets(scenes)
+        frames = args.scenes * args.views * (1 if args.no_fine else 2)
+        raster = lambda after: step(scenes, settings, gc, ga, args.streams, fine_idx, after)
+        enc = None
+        if args.step == "train":
+            from lara_amd.encoder_train import VolTransformer
+            torch.manual_seed(0)      # identical initial parameters on every rank, as DDP expects
+            enc = VolTransformer(256, 800, [16], 32, 64, 80, args.encoder_layers, 16).to(device)
+            g = torch.Generator(device="cpu").manual_seed(11 + rank)
+            feats = torch.randn(args.scenes, 4, 800, 16, 16, 16, generator=g).to(device)
+            dout = (torch.randn(args.scenes, 64, 64, 64, 80, generator=g) * 1e-3).to(device)
+        info["raster_state"] = (scenes, settings, gc, ga, fine_idx)
+    model = enc
+    if enc is not None:
+        n_par = sum(p.numel() for p in enc.parameters() if p.requires_grad)
+        info["encoder"] = {"parameters": n_par, "layers": args.encoder_layers if not plumbing else 2}
+        if world > 1:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            model = DDP(enc, device_ids=[device.index] if device.type == "cuda" else None, **ddp_kw)
+            info["grad_allreduce"] = {"bytes_per_step": 4 * n_par, "bucket_cap_MB": ddp_kw["bucket_cap_mb"],
+                                      "buckets": None, "backend": os.environ.get("LARA_BENCH_BACKEND", "nccl"),
+                                      "what": "torch DistributedDataParallel over the trainable VolTransformer "
+                                              "(fp32 master gradients, all-reduced bucket by bucket while its backward runs)"}
+
+    def _enc_roots(outs, grads):
+        outs.append(info["_out"])
+        grads.append(dout)
+
+    def full_step():
+        if model is None:                       # --step raster
+            raster(None)
+            return
+        info["_out"] = model(feats)             # 1. encoder forward (DDP: also arms the reducer's hooks)
+        raster(_enc_roots)                      # 2. raster forwards; 3. ONE backward: raster, then encoder (+ all-reduce)
+        for p in enc.parameters():
+            p.grad = None
+        info["_out"] = None
+
+    def after_first_step():
+        if info["grad_allreduce"] is not None:
+            try:    # the reducer's own record of the buckets it built (bytes each), after the first backward
+                sizes = model._get_ddp_logging_data().get("bucket_sizes", "")
+                info["grad_allreduce"]["buckets"] = [int(x) for x in str(sizes).split(",") if x.strip()]
+            except Exception:
+                pass
+    info["after_first_step"] = after_first_step
+    info["frames_per_rank_step"] = frames
+    return full_step, info
+
+
+def _roots(after):
+    outs, grads = [], []
+    after(outs, grads)
+    return outs, grads
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    local = local % torch.cuda.device_count()  # (several ranks on one GPU only in the gloo self-test)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    plumbing = os.environ.get("LARA_BENCH_PLUMBING", "0") == "1"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if plumbing:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+        backend = os.environ.get("LARA_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s): RCCL wants one rank per device")
+        local = local % torch.cuda.device_count()  # (several ranks on one GPU only in the gloo self-test)
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    sync = (lambda: None) if plumbing else torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("LARA_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; gloo for plumbing tests
+        backend = "gloo" if plumbing else os.environ.get("LARA_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
 
-    from lara_amd import rasterizer
-    rasterizer.load_library()
-    scenes, settings, gc, ga = build_batch(args, device, rank)
-
-    from lara_amd import dp
-    comm_stream = torch.cuda.Stream(device) if world > 1 else None
-    grad_buf = torch.zeros(ENCODER_PARAMS, device=device) if world > 1 else None
-
-    def full_step():
-        if world > 1:  # DDP-style bucketed all-reduce, overlapped with the raster work on a side stream
-            comm_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm_stream):
-                dp.bucketed_all_reduce(grad_buf)
-        step(scenes, settings, gc, ga, args.streams)
-        if world > 1:
-            torch.cuda.current_stream().wait_stream(comm_stream)
-
-    for _ in range(args.warmup):
+    full_step, info = make_training_step(args, device, rank, world, plumbing)
+    for i in range(max(args.warmup, 1) if info["grad_allreduce"] else args.warmup):
         full_step()
-    torch.cuda.synchronize()
+        if i == 0:
+            info["after_first_step"]()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    rasterizer.check_pending(block=True)
+    joined = world
     if world > 1:
+        from lara_amd import dp
         dt = dp.max_over_ranks(dt, device)
+        cnt = torch.ones(1, device=device)
+        dist.all_reduce(cnt)
+        joined = int(cnt.item())        # ranks that actually joined the job
+    if not plumbing:
+        from lara_amd import rasterizer
+        rasterizer.check_pending(block=True)
 
-    frames_per_step = args.scenes * args.views * world
+    frames_per_step = info["frames_per_rank_step"] * joined
+    P = (args.grid ** 3) * 2
+    enc = info["encoder"]
     out = {
         "metric": "novel-view frames/sec @512x512 (4-view in, 2DGS fwd+bwd)",
         "value": round(frames_per_step * args.steps / dt, 3),
         "unit": "frames/s",
-        "n_gpus": world,
+        "n_gpus": joined,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
+        "dtype": "f32" if args.step == "raster" else "f32 raster + bf16-MFMA/f32-accumulate encoder",
+        "data": "synthetic" if not plumbing else "PLUMBING SELF-TEST (no GPU work; not a measurement)",
         "config": {
-            "workload": f"configs[2]: training-step raster fwd+bwd, {args.scenes} scenes/GPU x {args.views} "
-                        f"views @{args.res}x{args.res}, P={scenes[0]['centers'].shape[0]} surfels/scene, "
-                        f"SH degree 1, regime={args.regime}",
+            "workload": (f"configs[2]: LaRa training step on the hot path, per GPU {args.scenes} scenes: "
+                         + (f"VolTransformer fwd+bwd ({enc['layers']} layers, {enc['parameters'] / 1e6:.2f} M parameters) + "
+                            if enc else "")
+                         + f"raster fwd+bwd of {args.views} coarse" + ("" if args.no_fine else f" + {args.views} fine")
+                         + f" views/scene @{args.res}x{args.res}, P={P} surfels/scene, SH degree 1, regime={args.regime}"),
+            "step": args.step,
             "frames_per_step": frames_per_step,
-            "parallelism": f"dp{world} (per-scene; raster not sharded)",
+            "parallelism": f"dp{joined} (per-scene; raster not sharded)",
             "hip_streams": args.streams,
-            "grad_allreduce": (f"{ENCODER_PARAMS * 4 / 1e6:.0f} MB fp32 stand-in for the encoder's DDP "
-                               "gradient, 25 MB buckets, RCCL, overlapped") if world > 1 else None,
+            "grad_allreduce": info["grad_allreduce"],
         },
     }
-    if rank == 0 and world == 1 and args.streams != 1 and not args.no_roofline:
-        # the same step as the reference's loop would issue it: every scene on the current stream
-        for _ in range(2):
-            step(scenes, settings, gc, ga, 1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(scenes, settings, gc, ga, 1)
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        out["single_stream"] = {"value": round(frames_per_step * args.steps / dt1, 3), "unit": "frames/s",
-                                "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
-    if rank == 0 and world == 1 and not args.no_roofline:
-        # opt-in, not in the reference: surfels with opacity < 1/255 (never drawn) culled in the preprocess; same
-        # images to an ulp, same gradients (tests/test_raster_parity_gpu.py); nothing to cull at LaRa's initialisation,
-        # most of the volume in a trained-like scene
-        from lara_amd import rasterizer as _rz
-        prev = _rz.set_cull_transparent(True)
-        try:
+    solo = rank == 0 and world == 1 and not plumbing
+    if solo and not args.no_roofline:
+        scenes, settings, gc, ga, fine_idx = info["raster_state"]
+
+        def timed(fn, frames):
             for _ in range(2):
-                step(scenes, settings, gc, ga, args.streams)
+                fn()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                step(scenes, settings, gc, ga, args.streams)
+                fn()
             torch.cuda.synchronize()
-            dt1 = time.perf_counter() - t1
+            d = time.perf_counter() - t1
+            return {"value": round(frames * args.steps / d, 3), "unit": "frames/s", "ms_per_step": round(1e3 * d / args.steps, 3)}
+
+        coarse = args.scenes * args.views
+        # the raster alone, coarse views only: round 1's headline definition (BENCH_r01.json `value`)
+        out["raster_only"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams), coarse),
+                                  workload=f"raster fwd+bwd only, {args.scenes} scenes x {args.views} coarse views, {args.streams} HIP streams")
+        if fine_idx is not None:
+            out["raster_only_with_fine"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams, fine_idx), 2 * coarse),
+                                                workload="raster fwd+bwd only, coarse + fine views (the raster part of the headline step)",
+                                                fine_subset_fraction=round(float(sum(i.numel() for i in fine_idx)) / (P * len(fine_idx)), 4))
+        # the same as the reference's loop would issue it: every scene on the current stream
+        out["single_stream"] = timed(lambda: step(scenes, settings, gc, ga, 1), coarse)
+        # opt-in, not in the reference: surfels with opacity < 1/255 (never drawn) culled in the preprocess; same
+        # images to an ulp, same gradients (tests/test_raster_parity_gpu.py); nothing to cull at LaRa's initialisation,
+        # most of the volume in a trained-like scene
+        prev = rasterizer.set_cull_transparent(True)
+        try:
+            out["cull_transparent_opt_in"] = timed(lambda: step(scenes, settings, gc, ga, args.streams), coarse)
         finally:
-            _rz.set_cull_transparent(prev)
-        out["cull_transparent_opt_in"] = {"value": round(frames_per_step * args.steps / dt1, 3), "unit": "frames/s",
-                                          "ms_per_step": round(1e3 * dt1 / args.steps, 3)}
+            rasterizer.set_cull_transparent(prev)
         out["forward_only"] = forward_only_leg(scenes, settings, args)
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not plumbing and not args.no_roofline:
+        scenes, settings, gc, ga, fine_idx = info["raster_state"]
         roof, table, D = measure_roofline(scenes, settings, gc, ga, args)
         out["roofline"] = roof
         out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
                               "alg_GBs": round(v["alg_GBs"], 1)} for k, v in table.items()}
-    if rank == 0 and world == 1 and not args.no_roofline:   # the side legs run at N = 1 only (the other ranks would wait)
+    if solo and not args.no_roofline and not args.no_side_legs:   # the side legs run at N = 1 only (the other ranks would wait)
+        del full_step
+        info.clear()
+        torch.cuda.empty_cache()
         out["attention"] = attention_leg(device, args.scenes)
         out["encoder"] = encoder_leg(device, args.scenes)
         out["encoder_train"] = encoder_train_leg(device, args.scenes)
         out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
         out["render_img"] = render_img_leg(device, args)
         out["point_feats"] = point_feats_leg(device, args)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
+        out["cpu_baseline"]["encoder"] = cpu_encoder_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,0 +1,52 @@
+"""`python bench.py --gpus 2` starts its own two ranks (no torchrun around it), wraps the encoder stand-in in torch's
+DistributedDataParallel, times with the barrier / max-over-ranks protocol and prints ONE JSON line from rank 0 that
+says n_gpus = the ranks that actually joined and carries the all-reduce's real bucket sizes.
+
+LARA_BENCH_PLUMBING=1 replaces the HIP work by a few CPU linear layers (there is no GPU in this container; RCCL needs
+GPUs, so the process group is gloo): this is a test of the launcher and of the DDP / timing / reporting plumbing, not
+a measurement.  The same code path with the real HIP step runs in tests/test_bench_launch_gpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra):
+    env = dict(os.environ, LARA_BENCH_PLUMBING="1", OMP_NUM_THREADS="2", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]        # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_ranks_and_reports_real_buckets():
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"], {})
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["unit"] == "frames/s"
+    assert out["config"]["parallelism"].startswith("dp2")
+    assert out["config"]["frames_per_step"] == 2 * 4 * 8 * 2          # 2 ranks x 4 scenes x (8 coarse + 8 fine)
+    ar = out["config"]["grad_allreduce"]
+    n_par = 64 * 256 + 256 + 256 * 64 + 64
+    assert ar["bytes_per_step"] == 4 * n_par and ar["backend"] in ("nccl", "gloo")
+    assert ar["buckets"] and sum(ar["buckets"]) == 4 * n_par           # the reducer's own record
+    assert "PLUMBING" in out["data"]
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+
+
+def test_bench_single_rank_plumbing_has_no_collective():
+    out = _run(["--steps", "2", "--warmup", "1"], {})
+    assert out["n_gpus"] == 1 and out["config"]["grad_allreduce"] is None
+    assert out["config"]["frames_per_step"] == 4 * 8 * 2
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, LARA_BENCH_PLUMBING="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
