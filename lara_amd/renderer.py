@@ -132,12 +132,16 @@ class Renderer(nn.Module):
         # `_opacity_coarse[i]` etc., a fresh view object on every call over the same storage
         if t is None:
             return None
-        return (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device, t._version,
-                t.requires_grad)
+        # identity of the autograd variable the view was taken from (`_opacity_coarse` for `_opacity_coarse[i]`): two
+        # tensors over the same bytes can belong to different graphs (e.g. `x.detach()[None]` taken twice), and a
+        # cached activation must never be replayed into another graph
+        base = t._base if t._is_view() else t
+        return (id(base), t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device,
+                t._version, t.requires_grad)
 
     def _activated(self, opacity, scales, rotations):
         """The activated tensors of the last call are reused while the caller passes tensors over the same
-        memory (same address, layout, dtype, version counter, requires_grad) in the same autograd mode: the 8
+        memory (views of the same base tensor, same address, layout, dtype, version counter, requires_grad) in the same autograd mode: the 8
         views of a scene then share one sigmoid / exp / normalize node although `_opacity_coarse[i]` is a new
         Python object per call.  The cache holds the inputs it was computed from, so their storage cannot be
         freed and handed to another tensor while the entry lives (an address match is a real match).  Not covered:
