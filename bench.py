@@ -63,6 +63,9 @@ def parse():
                     help="train: encoder fwd + raster fwd/bwd + encoder bwd (DDP all-reduce when N > 1); raster: the raster alone")
     ap.add_argument("--no-fine", action="store_true", help="coarse views only (LaRa before train.start_fine)")
     ap.add_argument("--encoder-layers", type=int, default=12, help="transformer depth (configs/base.yaml:16: 12)")
+    ap.add_argument("--raster-api", default="views", choices=["views", "loop"],
+                    help="views: one multi-view call per scene and pass (lara_amd.rasterize_gaussians_views / Renderer.render_views, "
+                         "opt-in, SURVEY.md section 8f-2); loop: one GaussianRasterizer call per view, as the reference's loop issues them")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent scenes of a step are spread over (1 = the reference's sequential loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,15 +131,17 @@ def fine_subsets(scenes):
         return [(torch.sigmoid(sc["opacity"].detach()).squeeze(-1) > FINE_OPACITY).nonzero().squeeze(-1) for sc in scenes]
 
 
-def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None):
+def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="loop"):
     """All forwards of the batch, then one backward through every view (as loss.backward() does).
     Per scene: the coarse views (network.py:487-497) and, with `fine_idx`, the fine views over the masked subset with
     refined SH coefficients (network.py:508-525; the refinement itself -- `forward_fine` -- is a side leg, here the
     subset's coefficients are offset by a constant).  Activations and subset gathers are applied per view, as the
     reference's `render_img` / loop do.  Scenes are independent (the unit the north star data-parallelises over), so
     scene i is enqueued on HIP stream i % n_streams; autograd replays each view's backward on its forward's stream.
-    `after(outs, grads)` appends further roots to the one backward call (the encoder's output and its gradient)."""
-    from lara_amd import GaussianRasterizer
+    `after(outs, grads)` appends further roots to the one backward call (the encoder's output and its gradient).
+    api = "views": the views of a scene and pass go through ONE multi-view call (one autograd node; activations and
+    subset gathers once per scene, as `lara_amd.renderer.Renderer.render_views` does) instead of one call per view."""
+    from lara_amd import GaussianRasterizer, rasterize_gaussians_views
     outs, grads = [], []
     cur = torch.cuda.current_stream()
     while len(_streams) < n_streams and n_streams > 1:
@@ -151,19 +156,35 @@ def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None):
         outs.extend((color, allmap))
         grads.extend((gc, ga))
 
+    nv = len(settings)
+    gcs, gas = gc.expand(nv, *gc.shape), ga.expand(nv, *ga.shape)
+
+    def render_views(centers, shs, opacity, scales, rotations):
+        color, radii, allmap = rasterize_gaussians_views(
+            settings, centers, torch.zeros_like(centers), torch.sigmoid(opacity), shs=shs, scales=torch.exp(scales),
+            rotations=torch.nn.functional.normalize(rotations))
+        outs.extend((color, allmap))
+        grads.extend((gcs, gas))
+
     for i, sc in enumerate(scenes):
         side = _streams[i % n_streams] if n_streams > 1 else None
         if side is not None:
             side.wait_stream(cur)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            for rs in settings:
-                render(rs, sc["centers"], sc["shs"], sc["opacity"], sc["scales"], sc["rotations"])
+            if api == "views":
+                render_views(sc["centers"], sc["shs"], sc["opacity"], sc["scales"], sc["rotations"])
+            else:
+                for rs in settings:
+                    render(rs, sc["centers"], sc["shs"], sc["opacity"], sc["scales"], sc["rotations"])
             if fine_idx is not None:
                 idx = fine_idx[i]
                 centers_f = sc["centers"][idx]                    # network.py:514
                 shs_f = sc["shs"][idx] + 0.01                     # network.py:518 (+ forward_fine's residual)
-                for rs in settings:                               # network.py:524: subset gathers per view
-                    render(rs, centers_f, shs_f, sc["opacity"][idx], sc["scales"][idx], sc["rotations"][idx])
+                if api == "views":
+                    render_views(centers_f, shs_f, sc["opacity"][idx], sc["scales"][idx], sc["rotations"][idx])
+                else:
+                    for rs in settings:                           # network.py:524: subset gathers per view
+                        render(rs, centers_f, shs_f, sc["opacity"][idx], sc["scales"][idx], sc["rotations"][idx])
     for side in _streams[:n_streams if n_streams > 1 else 0]:
         cur.wait_stream(side)
     if after is not None:
@@ -686,7 +707,7 @@ def make_training_step(args, device, rank, world, plumbing):
         scenes, settings, gc, ga = build_batch(args, device, rank)
         fine_idx = None if args.no_fine else fine_subsets(scenes)
         frames = args.scenes * args.views * (1 if args.no_fine else 2)
-        raster = lambda after: step(scenes, settings, gc, ga, args.streams, fine_idx, after)
+        raster = lambda after: step(scenes, settings, gc, ga, args.streams, fine_idx, after, api=args.raster_api)
         enc = None
         if args.step == "train":
             from lara_amd.encoder_train import VolTransformer
@@ -826,6 +847,9 @@ def main():
             "frames_per_step": frames_per_step,
             "parallelism": f"dp{joined} (per-scene; raster not sharded)",
             "hip_streams": args.streams,
+            "raster_api": ("views: one multi-view rasteriser call per scene and pass (opt-in lara_amd API; the library runs the "
+                           "views on its own side streams)" if args.raster_api == "views" else
+                           "loop: one GaussianRasterizer call per view (the reference's loop)"),
             "grad_allreduce": info["grad_allreduce"],
         },
     }
@@ -846,20 +870,26 @@ def main():
 
         coarse = args.scenes * args.views
         # the raster alone, coarse views only: round 1's headline definition (BENCH_r01.json `value`)
-        out["raster_only"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams), coarse),
-                                  workload=f"raster fwd+bwd only, {args.scenes} scenes x {args.views} coarse views, {args.streams} HIP streams")
+        api = args.raster_api
+        out["raster_only"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams, api=api), coarse),
+                                  workload=f"raster fwd+bwd only, {args.scenes} scenes x {args.views} coarse views, {args.streams} HIP streams, api={api}")
         if fine_idx is not None:
-            out["raster_only_with_fine"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams, fine_idx), 2 * coarse),
+            out["raster_only_with_fine"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams, fine_idx, api=api), 2 * coarse),
                                                 workload="raster fwd+bwd only, coarse + fine views (the raster part of the headline step)",
                                                 fine_subset_fraction=round(float(sum(i.numel() for i in fine_idx)) / (P * len(fine_idx)), 4))
-        # the same as the reference's loop would issue it: every scene on the current stream
-        out["single_stream"] = timed(lambda: step(scenes, settings, gc, ga, 1), coarse)
+        # the multi-view call on ONE caller stream (the library's side streams only)
+        out["views_api_one_stream"] = timed(lambda: step(scenes, settings, gc, ga, 1, api="views"), coarse)
+        # one call per view, as the reference's loop issues them: two scene streams (round 1's headline) and one stream
+        out["reference_loop"] = {"two_streams": timed(lambda: step(scenes, settings, gc, ga, 2, api="loop"), coarse),
+                                 "with_fine_two_streams": (timed(lambda: step(scenes, settings, gc, ga, 2, fine_idx, api="loop"), 2 * coarse)
+                                                           if fine_idx is not None else None)}
+        out["single_stream"] = timed(lambda: step(scenes, settings, gc, ga, 1, api="loop"), coarse)
         # opt-in, not in the reference: surfels with opacity < 1/255 (never drawn) culled in the preprocess; same
         # images to an ulp, same gradients (tests/test_raster_parity_gpu.py); nothing to cull at LaRa's initialisation,
         # most of the volume in a trained-like scene
         prev = rasterizer.set_cull_transparent(True)
         try:
-            out["cull_transparent_opt_in"] = timed(lambda: step(scenes, settings, gc, ga, args.streams), coarse)
+            out["cull_transparent_opt_in"] = timed(lambda: step(scenes, settings, gc, ga, args.streams, api=api), coarse)
         finally:
             rasterizer.set_cull_transparent(prev)
         out["forward_only"] = forward_only_leg(scenes, settings, args)

@@ -17,8 +17,8 @@
  *     D2H copy of `num_rendered` once per view);
  *   - the caller owns every allocation: outputs, the `state` buffer that forward hands to
  *     backward (the reference's geomBuffer/binningBuffer/imgBuffer), and a transient `scratch`;
- *   - the library keeps no global state (bar the optional profiling log) and is re-entrant
- *     across streams;
+ *   - the library keeps no global state (bar the optional profiling log and, for the multi-view calls, the
+ *     side streams it keeps per caller stream) and is re-entrant across streams;
  *   - functions return 0 on success or a negative LARA2DGS_E_* code; nothing throws.
  *   - binning capacity: the number of (tile, surfel) pairs is data dependent and only known on the
  *     device.  The caller passes `capacity`; if a view needs more, the kernels raise the
@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LARA2DGS_ABI_VERSION 3
+#define LARA2DGS_ABI_VERSION 4
 
 #define LARA2DGS_OK 0
 #define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
@@ -132,6 +132,43 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
                       float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs, float *dL_dcolors,
                       float *dL_dopacities, float *dL_dscales, float *dL_drotations,
                       float *dL_dtransmat, void *stream);
+
+
+/* ---- multi-view calls (not in the reference, whose Python loop issues one call per view:
+ * lightning/network.py:486-497, :516-525) ------------------------------------------------------------------------
+ * One call rasterises the SAME surfels from n_views cameras.  `views` is an array of n_views records that agree in
+ * everything but the four camera pointers (and bg).  Outputs are stacked: out_color [n,3,H,W], out_allmap [n,7,H,W],
+ * out_radii [n,P]; view i's saved state lives at state + i * state_stride (state_stride >= lara2dgs_state_bytes,
+ * 256-byte multiple) -- per-camera state carved from one allocation.  The views are independent until the gradient
+ * sum, so the library deals them round-robin to LARA2DGS_VIEW_STREAMS lanes (default 2: more streams than the
+ * device's 4 hardware queues alias and serialise again): lane 0 is `stream` itself, the others are side streams the
+ * library keeps per caller stream, forked from and joined back into `stream` with events, no host synchronisation.
+ * The composite kernels end in a tail of a few heavy tiles that the other lane's kernels fill.  `scratch` holds n_scratch transient buffers of
+ * scratch_stride bytes each (>= lara2dgs_scratch_bytes); n_scratch bounds the number of views in flight. */
+int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+                           const float *shs, const float *colors_precomp, const float *opacities,
+                           const float *scales, const float *rotations, const float *transmat_precomp,
+                           float *out_color, float *out_allmap, int32_t *out_radii, void *state,
+                           int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
+                           void *stream);
+
+/* Offsets (in floats) of the gradient arrays inside one flat gradient buffer; -1 = absent. */
+typedef struct lara2dgs_grad_layout {
+    int64_t means3D, means2D, shs, colors, opacities, scales, rotations, transmat, total;
+} lara2dgs_grad_layout;
+int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int32_t has_colors,
+                             int32_t has_scale_rot, int32_t has_transmat, lara2dgs_grad_layout *out);
+
+/* Backward of lara2dgs_forward_views: dL_dcolor [n,3,H,W], dL_dallmap [n,7,H,W], radii [n,P].  Every view writes
+ * its gradients into its own slice of grad_tmp ([n_views][layout.total] floats); one kernel then adds the slices
+ * into grad_out ([layout.total] floats, fully overwritten) in a fixed order -- the sum over a scene's views that
+ * autograd otherwise forms with n-1 accumulation kernels per input, and bit-reproducible. */
+int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+                            const float *shs, const float *colors_precomp, const float *scales,
+                            const float *rotations, const float *transmat_precomp, const int32_t *radii,
+                            const float *dL_dcolor, const float *dL_dallmap, const void *state,
+                            int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
+                            float *grad_tmp, float *grad_out, void *stream);
 
 /* Replaces `_C.mark_visible(means3D, viewmatrix, projmatrix)` (GaussianRasterizer.markVisible).
  * present: uint8 [P]. */

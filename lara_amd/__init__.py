@@ -8,6 +8,6 @@ the camera-matrix helpers that feed it (``lara_amd.cameras``) and seeded synthet
 ``include/lara2dgs.h``.
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
-                         rasterize_gaussians)
+                         rasterize_gaussians, rasterize_gaussians_views)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_views"]

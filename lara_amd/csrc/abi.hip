@@ -10,6 +10,8 @@ void l2d_set_hip_error(hipError_t e) { g_last_hip_error = (int)e; }
 // ---- optional per-kernel timing --------------------------------------------------------------
 #include <atomic>
 #include <mutex>
+#include <map>
+#include <utility>
 #include <vector>
 namespace {
 // Process-wide (PyTorch runs backward on its autograd thread, not on the caller's).
@@ -248,6 +250,192 @@ int lara2dgs_profile_collect(char *names, int names_len, float *ms, int max_entr
     }
     g_prof_log.clear();
     return n;
+}
+
+}  // extern "C"
+
+// ---- multi-view calls: a per-thread pool of side streams, forked from / joined into the caller's stream ----------
+namespace {
+constexpr int MAX_SIDE = 8;
+// Lane 0 of a multi-view call is the caller's stream itself; lanes 1.. are side streams that belong to that caller
+// stream (process-wide map: PyTorch replays the backward on its autograd thread, on the forward's stream -- both
+// directions share the lanes, and two caller streams never funnel into the same side stream).
+struct SidePool {
+    int n = 0;   // side streams (= lanes - 1)
+    hipStream_t s[MAX_SIDE];
+    hipEvent_t fork, join[MAX_SIDE];
+};
+std::mutex g_side_mu;
+std::map<std::pair<int, hipStream_t>, SidePool> g_side;
+
+int lane_count() {
+    static const int n = [] {
+        const char *e = getenv("LARA2DGS_VIEW_STREAMS");
+        int k = e ? atoi(e) : 2;
+        return k < 1 ? 1 : (k > MAX_SIDE ? MAX_SIDE : k);
+    }();
+    return n;
+}
+
+// the side streams of `caller` on the current device (created on first use, kept for the life of the process)
+SidePool *side_pool(hipStream_t caller) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto it = g_side.find({dev, caller});
+    if (it != g_side.end()) return &it->second;
+    SidePool p;
+    const int n = lane_count() - 1;
+    if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < n; i++) {
+        if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    p.n = n;
+    return &(g_side[{dev, caller}] = p);
+}
+
+#define HIP_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { l2d_set_hip_error(e__); return LARA2DGS_E_LAUNCH; } } while (0)
+
+bool views_agree(int n, const lara2dgs_view *views) {
+    for (int i = 1; i < n; i++) {
+        const lara2dgs_view &a = views[0], &b = views[i];
+        if (a.P != b.P || a.sh_degree != b.sh_degree || a.sh_coeffs != b.sh_coeffs || a.image_height != b.image_height ||
+            a.image_width != b.image_width || a.capacity != b.capacity || a.prefiltered != b.prefiltered) return false;
+    }
+    return true;
+}
+
+void grad_layout(int64_t P, int M, bool sh, bool col, bool sr, bool tm, lara2dgs_grad_layout *L) {
+    int64_t o = 0;
+    auto sec = [&](bool on, int64_t n) { if (!on) return (int64_t)-1; const int64_t at = o; o = (o + n + 3) / 4 * 4; return at; };
+    L->means3D = sec(true, P * 3);
+    L->means2D = sec(true, P * 3);
+    L->shs = sec(sh, P * M * 3);
+    L->colors = sec(col, P * 3);
+    L->opacities = sec(true, P);
+    L->scales = sec(sr, P * 2);
+    L->rotations = sec(sr, P * 4);
+    L->transmat = sec(tm, P * 9);
+    L->total = o;
+}
+
+// out[i] = sum over the n slices of tmp, slice order fixed (bit-reproducible); float4 lanes
+__global__ void __launch_bounds__(256) sum_slices_kernel(const float4 *__restrict__ tmp, float4 *__restrict__ out,
+                                                         int64_t n4, int64_t stride4, int n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = tmp[i];
+        for (int k = 1; k < n; k++) {
+            const float4 b = tmp[i + k * stride4];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        out[i] = a;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int32_t has_colors,
+                             int32_t has_scale_rot, int32_t has_transmat, lara2dgs_grad_layout *out) {
+    if (!out || P < 0 || sh_coeffs < 0) return LARA2DGS_E_INVALID;
+    grad_layout(P, sh_coeffs, has_shs != 0, has_colors != 0, has_scale_rot != 0, has_transmat != 0, out);
+    return LARA2DGS_OK;
+}
+
+int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+                           const float *shs, const float *colors_precomp, const float *opacities,
+                           const float *scales, const float *rotations, const float *transmat_precomp,
+                           float *out_color, float *out_allmap, int32_t *out_radii, void *state,
+                           int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
+                           void *stream) {
+    if (n_views <= 0 || !views || n_scratch <= 0 || !state || !scratch) return LARA2DGS_E_INVALID;
+    if (!views_agree(n_views, views)) return LARA2DGS_E_INVALID;
+    const lara2dgs_view &v0 = views[0];
+    if (state_stride % 256 || scratch_stride % 256 ||
+        state_stride < lara2dgs_state_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity) ||
+        scratch_stride < lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity))
+        return LARA2DGS_E_INVALID;
+    hipStream_t caller = (hipStream_t)stream;
+    SidePool *pool = side_pool(caller);
+    if (!pool) return LARA2DGS_E_LAUNCH;
+    int lanes = pool->n + 1;
+    if (lanes > n_views) lanes = n_views;
+    if (lanes > n_scratch) lanes = n_scratch;
+    auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
+    const int64_t HW = (int64_t)v0.image_height * v0.image_width;
+    if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
+    for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
+    int rc = LARA2DGS_OK;
+    for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
+        const int k = i % lanes;  // views on one lane are serialised: they share that lane's scratch
+        rc = lara2dgs_forward(&views[i], means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp,
+                              out_color + i * 3 * HW, out_allmap + i * 7 * HW,
+                              out_radii ? out_radii + (int64_t)i * v0.P : nullptr,
+                              (char *)state + i * state_stride, (char *)scratch + k * scratch_stride, lane_stream(k));
+    }
+    // always join, also after a failure: the caller's stream must not run ahead of what was enqueued
+    for (int k = 1; k < lanes; k++) {
+        HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
+        HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
+    }
+    return rc;
+}
+
+int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+                            const float *shs, const float *colors_precomp, const float *scales,
+                            const float *rotations, const float *transmat_precomp, const int32_t *radii,
+                            const float *dL_dcolor, const float *dL_dallmap, const void *state,
+                            int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
+                            float *grad_tmp, float *grad_out, void *stream) {
+    if (n_views <= 0 || !views || n_scratch <= 0 || !state || !scratch || !grad_tmp || !grad_out) return LARA2DGS_E_INVALID;
+    if (!views_agree(n_views, views)) return LARA2DGS_E_INVALID;
+    const lara2dgs_view &v0 = views[0];
+    if (state_stride % 256 || scratch_stride % 256 ||
+        state_stride < lara2dgs_state_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity) ||
+        scratch_stride < lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity))
+        return LARA2DGS_E_INVALID;
+    if (!dL_dcolor || !dL_dallmap) return LARA2DGS_E_INVALID;
+    const bool has_sh = shs != nullptr, has_col = colors_precomp != nullptr, has_sr = scales && rotations,
+               has_tm = transmat_precomp != nullptr;
+    lara2dgs_grad_layout G;
+    grad_layout(v0.P, v0.sh_coeffs, has_sh, has_col, has_sr, has_tm, &G);
+    hipStream_t caller = (hipStream_t)stream;
+    if (v0.P == 0 || G.total == 0) return LARA2DGS_OK;
+    SidePool *pool = side_pool(caller);
+    if (!pool) return LARA2DGS_E_LAUNCH;
+    int lanes = pool->n + 1;
+    if (lanes > n_views) lanes = n_views;
+    if (lanes > n_scratch) lanes = n_scratch;
+    auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
+    const int64_t HW = (int64_t)v0.image_height * v0.image_width;
+    if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
+    for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
+    int rc = LARA2DGS_OK;
+    auto at = [&](float *base, int64_t off) { return off < 0 ? (float *)nullptr : base + off; };
+    for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
+        const int k = i % lanes;
+        float *g = grad_tmp + (int64_t)i * G.total;
+        rc = lara2dgs_backward(&views[i], means3D, shs, colors_precomp, scales, rotations, transmat_precomp,
+                               radii + (int64_t)i * v0.P, dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW,
+                               (const char *)state + i * state_stride, (char *)scratch + k * scratch_stride,
+                               at(g, G.means3D), at(g, G.means2D), at(g, G.shs), at(g, G.colors), at(g, G.opacities),
+                               at(g, G.scales), at(g, G.rotations), at(g, G.transmat), lane_stream(k));
+    }
+    for (int k = 1; k < lanes; k++) {
+        HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
+        HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
+    }
+    if (rc != LARA2DGS_OK) return rc;
+    {
+        L2D_PROF("sum_view_grads", caller);
+        const int64_t n4 = G.total / 4;
+        const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(sum_slices_kernel, dim3(grid), dim3(256), 0, caller, (const float4 *)grad_tmp,
+                           (float4 *)grad_out, n4, G.total / 4, (int)n_views);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
 }
 
 }  // extern "C"

@@ -29,7 +29,7 @@ from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class _View(ctypes.Structure):
@@ -42,6 +42,11 @@ class _View(ctypes.Structure):
         ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
         ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p),
     ]
+
+
+class GradLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "transmat", "total")]
 
 
 class StateLayout(ctypes.Structure):
@@ -79,6 +84,12 @@ def load_library():
     lib.lara2dgs_forward.argtypes = [ctypes.POINTER(_View)] + [vp] * 13
     lib.lara2dgs_backward.restype = ctypes.c_int
     lib.lara2dgs_backward.argtypes = [ctypes.POINTER(_View)] + [vp] * 20
+    lib.lara2dgs_forward_views.restype = ctypes.c_int
+    lib.lara2dgs_forward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 11 + [i64, vp, i64, i32, vp]
+    lib.lara2dgs_backward_views.restype = ctypes.c_int
+    lib.lara2dgs_backward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 10 + [i64, vp, i64, i32, vp, vp, vp]
+    lib.lara2dgs_get_grad_layout.restype = ctypes.c_int
+    lib.lara2dgs_get_grad_layout.argtypes = [i32, i32, i32, i32, i32, i32, ctypes.POINTER(GradLayout)]
     lib.lara2dgs_mark_visible.restype = ctypes.c_int
     lib.lara2dgs_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.lara2dgs_profile_enable.restype = ctypes.c_int
@@ -223,16 +234,14 @@ def _make_view(rs: GaussianRasterizationSettings, P: int, M: int, cap: int, devi
     return v, (bg, vm, pm, cp)
 
 
-def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
-    """Validate, allocate, enqueue the forward.  Returns everything backward / the tests need."""
-    lib = load_library()
+def _validate(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, sh_degree):
+    """Shape / device checks shared by the per-view and the multi-view operator; returns the kernel-ready tensors."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
         raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
     device = means3D.device
     P = means3D.shape[0]
-    H, W = int(rs.image_height), int(rs.image_width)
     means3D_c = _prep(means3D, "means3D", device)
     if means3D_c is None:  # P == 0: keep a (dataless) tensor for the autograd bookkeeping
         means3D_c = means3D.contiguous()
@@ -247,13 +256,39 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
         if sh_c.dim() != 3 or sh_c.shape[0] != P or sh_c.shape[2] != 3:
             raise RuntimeError("shs must have dimensions (num_points, num_coeffs, 3)")
         M = sh_c.shape[1]
-        if M < (int(rs.sh_degree) + 1) ** 2:
+        if M < (int(sh_degree) + 1) ** 2:
             raise RuntimeError("shs holds fewer coefficients than sh_degree needs")
     for t, n, k in ((opa_c, "opacities", 1), (sc_c, "scales", 2), (rot_c, "rotations", 4),
                     (tm_c, "cov3D_precomp", 9), (col_c, "colors_precomp", 3)):
         if t is not None and t.numel() != P * k:
             raise RuntimeError(f"{n} must hold {k} value(s) per point")
+    return device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c)
 
+
+def _watch_overflow(state_hdr_i32, cap, debug):
+    """Lazy overflow check: 64-byte header -> pinned host memory, no stall (unless debug)."""
+    hdr = torch.empty(state_hdr_i32.shape, dtype=torch.int32, pin_memory=True)
+    hdr.copy_(state_hdr_i32, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    hdrs = hdr.view(-1, 16)
+    if debug:
+        ev.synchronize()
+        for h in hdrs:
+            if int(h[1]) != 0:
+                _raise_overflow(h, cap)
+    else:
+        for h in hdrs:
+            _pending.append((ev, h, cap))
+    return ev, hdrs
+
+
+def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+    """Validate, allocate, enqueue the forward.  Returns everything backward / the tests need."""
+    lib = load_library()
+    device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c) = _validate(
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.sh_degree)
+    H, W = int(rs.image_height), int(rs.image_width)
     check_pending()
     cap = binning_capacity(P)
     with torch.cuda.device(device):
@@ -269,18 +304,8 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
                                   color.data_ptr(), allmap.data_ptr(), radii.data_ptr(),
                                   state.data_ptr(), scratch.data_ptr(), stream)
         _check(rc, "lara2dgs_forward")
-        # lazy overflow check: 64-byte header -> pinned host memory, no stall
-        hdr = torch.empty((16,), dtype=torch.int32, pin_memory=True)
-        hdr.copy_(state[:64].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        if rs.debug:
-            ev.synchronize()
-            if int(hdr[1]) != 0:
-                _raise_overflow(hdr, cap)
-        else:
-            _pending.append((ev, hdr, cap))
-    return dict(color=color, radii=radii, allmap=allmap, state=state, cap=cap, M=M, ev=ev, hdr=hdr,
+        ev, hdrs = _watch_overflow(state[:64].view(torch.int32), cap, rs.debug)
+    return dict(color=color, radii=radii, allmap=allmap, state=state, cap=cap, M=M, ev=ev, hdr=hdrs[0],
                 keep=keep, inputs=(means3D_c, sh_c, col_c, sc_c, rot_c, tm_c))
 
 
@@ -359,6 +384,150 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_opac = g_opac.view(ctx.shapes[1])
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
         return g_means3D, g_means2D, g_sh, g_col, g_opac, g_sc, g_rot, g_tm, None
+
+
+# ---------------------------------------------------------------------------------------------
+# opt-in: all views of a scene in one call
+# ---------------------------------------------------------------------------------------------
+def _view_lanes() -> int:
+    return max(1, min(8, int(os.environ.get("LARA2DGS_VIEW_STREAMS", "2"))))
+
+
+def _views_array(settings, P, M, cap, device, prefiltered_bits=None):
+    arr = (_View * len(settings))()
+    keep = []
+    for i, rs in enumerate(settings):
+        v, k = _make_view(rs, P, M, cap, device)
+        if prefiltered_bits is not None:
+            v.prefiltered = prefiltered_bits
+        arr[i] = v
+        keep.extend(k)
+    return arr, keep
+
+
+class _RasterizeViews(torch.autograd.Function):
+    """ONE autograd node for the n views of a scene: same surfels, n cameras (the reference's loop at
+    lightning/network.py:486-497 issues n nodes).  Per-camera state is carved from one allocation; the library runs
+    the views on its side streams and returns the gradient already summed over the views."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+        lib = load_library()
+        settings = tuple(settings)
+        rs0 = settings[0]
+        n = len(settings)
+        for rs in settings[1:]:
+            if (rs.image_height, rs.image_width, rs.sh_degree, bool(rs.prefiltered)) != \
+                    (rs0.image_height, rs0.image_width, rs0.sh_degree, bool(rs0.prefiltered)):
+                raise RuntimeError("lara_amd: the views of one multi-view call must agree in image size, sh_degree and prefiltered")
+        device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c) = _validate(
+            means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs0.sh_degree)
+        H, W = int(rs0.image_height), int(rs0.image_width)
+        check_pending()
+        cap = binning_capacity(P)
+        lanes = min(n, _view_lanes())
+        with torch.cuda.device(device):
+            views, keep = _views_array(settings, P, M, cap, device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            color = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
+            allmap = torch.empty((n, 7, H, W), dtype=torch.float32, device=device)
+            radii = torch.empty((n, P), dtype=torch.int32, device=device)
+            sb = (lib.lara2dgs_state_bytes(P, H, W, cap) + 255) // 256 * 256
+            qb = (lib.lara2dgs_scratch_bytes(P, H, W, cap) + 255) // 256 * 256
+            state = torch.empty((n * sb,), dtype=torch.uint8, device=device)
+            scratch = _get_scratch(device, lanes * qb)
+            rc = lib.lara2dgs_forward_views(n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c),
+                                            _ptr(sc_c), _ptr(rot_c), _ptr(tm_c), color.data_ptr(), allmap.data_ptr(),
+                                            radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb, lanes, stream)
+            _check(rc, "lara2dgs_forward_views")
+            ev, hdrs = _watch_overflow(state.view(n, sb)[:, :64].contiguous().view(torch.int32), cap,
+                                       any(rs.debug for rs in settings))
+        ctx.settings = settings
+        ctx.cap, ctx.M, ctx.sb, ctx.qb = cap, M, sb, qb
+        ctx.prefiltered_bits = int(bool(rs0.prefiltered)) | (2 if _cull_transparent else 0)
+        ctx.hdr = (ev, hdrs)
+        ctx.flags = (sh_c is not None, col_c is not None, sc_c is not None, tm_c is not None)
+        ctx.shapes = (sh.shape if sh_c is not None else None, opacities.shape)
+        empty = means3D_c.new_empty(0)
+        ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else empty, col_c if col_c is not None else empty,
+                              sc_c if sc_c is not None else empty, rot_c if rot_c is not None else empty,
+                              tm_c if tm_c is not None else empty, radii, state, *keep)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, allmap
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_allmap):
+        lib = load_library()
+        means3D, sh, col, sc, rot, tm, radii, state = ctx.saved_tensors[:8]
+        cams = ctx.saved_tensors[8:]
+        has_sh, has_col, has_sr, has_tm = ctx.flags
+        settings = ctx.settings
+        n = len(settings)
+        rs0 = settings[0]
+        device = means3D.device
+        P = means3D.shape[0]
+        H, W = int(rs0.image_height), int(rs0.image_width)
+        ev, hdrs = ctx.hdr
+        ev.synchronize()
+        for h in hdrs:
+            if int(h[1]) != 0:
+                _raise_overflow(h, ctx.cap)
+        G = GradLayout()
+        _check(lib.lara2dgs_get_grad_layout(P, ctx.M, int(has_sh), int(has_col), int(has_sr), int(has_tm), ctypes.byref(G)),
+               "lara2dgs_get_grad_layout")
+        with torch.cuda.device(device):
+            if grad_color is None:
+                grad_color = torch.zeros((n, 3, H, W), dtype=torch.float32, device=device)
+            if grad_allmap is None:
+                grad_allmap = torch.zeros((n, 7, H, W), dtype=torch.float32, device=device)
+            grad_color = _prep(grad_color, "grad_color", device)
+            grad_allmap = _prep(grad_allmap, "grad_allmap", device)
+            views = (_View * n)()
+            for i, rs in enumerate(settings):
+                bg, vm, pm, cp = cams[4 * i:4 * i + 4]
+                views[i] = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
+                                 float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)), ctx.cap,
+                                 bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
+            lanes = min(n, _view_lanes())
+            out = torch.empty((max(G.total, 4),), dtype=torch.float32, device=device)
+            tmp = torch.empty((n * max(G.total, 4),), dtype=torch.float32, device=device)
+            scratch = _get_scratch(device, lanes * ctx.qb)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = lib.lara2dgs_backward_views(
+                n, views, _ptr(means3D), _ptr(sh if has_sh else None), _ptr(col if has_col else None),
+                _ptr(sc if has_sr else None), _ptr(rot if has_sr else None), _ptr(tm if has_tm else None),
+                radii.data_ptr(), grad_color.data_ptr(), grad_allmap.data_ptr(), state.data_ptr(), ctx.sb,
+                scratch.data_ptr(), ctx.qb, lanes, tmp.data_ptr(), out.data_ptr(), stream)
+            _check(rc, "lara2dgs_backward_views")
+
+        def sec(off, k, shape):
+            return None if off < 0 else out[off:off + P * k].view(shape)
+        g_sh = sec(G.shs, ctx.M * 3, (P, ctx.M, 3)) if has_sh else None
+        if g_sh is not None and ctx.shapes[0] is not None:
+            g_sh = g_sh.view(ctx.shapes[0])
+        g_opac = sec(G.opacities, 1, (P, 1)).view(ctx.shapes[1])
+        return (sec(G.means3D, 3, (P, 3)), sec(G.means2D, 3, (P, 3)), g_sh,
+                sec(G.colors, 3, (P, 3)) if has_col else None, g_opac,
+                sec(G.scales, 2, (P, 2)) if has_sr else None, sec(G.rotations, 4, (P, 4)) if has_sr else None,
+                sec(G.transmat, 9, (P, 9)) if has_tm else None, None)
+
+
+def rasterize_gaussians_views(settings, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                              rotations=None, cov3D_precomp=None):
+    """All views of a scene in one call: ``settings`` is a sequence of GaussianRasterizationSettings (one per camera,
+    same image size / sh_degree); returns ``(color [n,3,H,W], radii [n,P], allmap [n,7,H,W])``.  Same results per view
+    as ``GaussianRasterizer(settings[i])(...)``; the gradients are the sums over the views."""
+    if len(settings) == 0:
+        raise RuntimeError("lara_amd: rasterize_gaussians_views needs at least one view")
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+    means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp = (
+        _as_f32(t) for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
+    return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                 tuple(settings))
 
 
 def _as_f32(t):

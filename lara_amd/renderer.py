@@ -23,7 +23,8 @@ import math
 import torch
 from torch import nn
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _check, load_library
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, _check, load_library,
+                         rasterize_gaussians_views)
 
 _configured = False
 
@@ -101,14 +102,16 @@ class Renderer(nn.Module):
     def set_bg_color(self, bg):
         self.bg_color = bg
 
-    def set_rasterizer(self, viewpoint_camera, scaling_modifier=1.0, device="cuda"):   # renderer_2dgs.py:119-139
-        settings = GaussianRasterizationSettings(
+    def _settings(self, viewpoint_camera, scaling_modifier=1.0, device="cuda", bg=None):
+        return GaussianRasterizationSettings(
             image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
             tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
-            bg=self.bg_color.to(device), scale_modifier=scaling_modifier,
+            bg=(self.bg_color if bg is None else bg).to(device), scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=self.sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-        return GaussianRasterizer(raster_settings=settings)
+
+    def set_rasterizer(self, viewpoint_camera, scaling_modifier=1.0, device="cuda"):   # renderer_2dgs.py:119-139
+        return GaussianRasterizer(raster_settings=self._settings(viewpoint_camera, scaling_modifier, device))
 
     def get_opacity(self, _opacity):
         return self.opacity_activation(_opacity)
@@ -175,3 +178,28 @@ class Renderer(nn.Module):
         image, depth, acc, rnorm, dnorm, rdist = surface_maps(rendered_image, allmap, rays, rot, depth_ratio)
         return {f"image{prex}": image, f"depth{prex}": depth, f"acc_map{prex}": acc, f"rend_normal{prex}": rnorm,
                 f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist}
+
+    def render_views(self, cams, rays, centers, shs, opacity, scales, rotations, device, bg_colors=None,
+                     cov3D_precomp=None, prex='', depth_ratio=0.0):
+        """All views of a scene in ONE rasteriser call (one autograd node, per-camera state carved from one
+        allocation, gradients summed over the views inside the library): what the reference's inner loop
+        (lightning/network.py:486-497 coarse, :516-525 fine) does with one ``render_img`` per view.  ``cams`` is a
+        sequence of cameras, ``rays`` the matching sequence of ray maps (or a stacked tensor), ``bg_colors`` the
+        per-view backgrounds the loop passes through ``set_bg_color`` (default: this renderer's colour).  Returns the
+        list of per-view dictionaries ``render_img`` would have returned."""
+        n = len(cams)
+        bgs = [None] * n if bg_colors is None else list(bg_colors)
+        settings = [self._settings(cam, device=device, bg=bg) for cam, bg in zip(cams, bgs)]
+        opacity, scales, rotations = self._activated(opacity, scales, rotations)
+        color, radii, allmap = rasterize_gaussians_views(settings, centers, self._zero_means2D(centers), opacity, shs=shs,
+                                                         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        out = []
+        for i, cam in enumerate(cams):
+            if rays is None:
+                out.append(color[i].clamp(0, 1))
+                continue
+            rot = cam.world_view_transform[:3, :3].T
+            image, depth, acc, rnorm, dnorm, rdist = surface_maps(color[i], allmap[i], rays[i], rot, depth_ratio)
+            out.append({f"image{prex}": image, f"depth{prex}": depth, f"acc_map{prex}": acc, f"rend_normal{prex}": rnorm,
+                        f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist})
+        return out

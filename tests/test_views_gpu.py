@@ -1,0 +1,136 @@
+"""The multi-view operator (one call = the n views of a scene) against the per-view operator the
+reference's loop issues (lightning/network.py:486-497): same kernels, so every per-view output must be the same bits,
+and the gradients must be the per-view gradients added in view order (the library's `sum_view_grads` kernel)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import raster_settings, small_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _inputs(act):
+    return {k: v.to(DEV).clone().requires_grad_(True) for k, v in act.items()}
+
+
+@pytest.mark.parametrize("n_views,size", [(4, 128), (8, 96), (1, 64), (5, 80)])
+def test_views_match_the_per_view_loop(n_views, size):
+    from lara_amd import GaussianRasterizer, rasterize_gaussians_views
+    act, cams = small_scene(grid=12, size=size, n_views=n_views, seed=3)
+    bgs = [[1.0, 1.0, 1.0], [0.0, 0.0, 0.0], [0.5, 0.5, 0.5]]
+    settings = [raster_settings(c, bgs[i % 3], device=DEV) for i, c in enumerate(cams)]
+    g = torch.Generator().manual_seed(5)
+    dcs = [torch.randn(3, size, size, generator=g).to(DEV) for _ in cams]
+    das = [(torch.randn(7, size, size, generator=g) * 0.1).to(DEV) for _ in cams]
+
+    # the reference's loop: one node per view, one backward per view so that the per-view gradients are visible
+    per_view, outs = [], []
+    for i, rs in enumerate(settings):
+        inp = _inputs(act)
+        m2 = torch.zeros_like(inp["means3D"], requires_grad=True)
+        c, r, a = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=m2, shs=inp["shs"], opacities=inp["opacities"],
+                                         scales=inp["scales"], rotations=inp["rotations"])
+        ((c * dcs[i]).sum() + (a * das[i]).sum()).backward()
+        outs.append((c.detach(), r, a.detach()))
+        per_view.append({k: v.grad.clone() for k, v in inp.items()} | {"means2D": m2.grad.clone()})
+
+    inp = _inputs(act)
+    m2 = torch.zeros_like(inp["means3D"], requires_grad=True)
+    color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], m2, inp["opacities"], shs=inp["shs"],
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+    assert color.shape == (n_views, 3, size, size) and allmap.shape == (n_views, 7, size, size)
+    assert radii.shape == (n_views, act["means3D"].shape[0])
+    loss = sum((color[i] * dcs[i]).sum() + (allmap[i] * das[i]).sum() for i in range(n_views))
+    loss.backward()
+    torch.cuda.synchronize()
+    for i in range(n_views):
+        assert torch.equal(color[i].detach(), outs[i][0]), f"view {i}: colour differs from the per-view call"
+        assert torch.equal(radii[i], outs[i][1])
+        assert torch.equal(allmap[i].detach(), outs[i][2])
+    got = {k: v.grad for k, v in inp.items()} | {"means2D": m2.grad}
+    for k in got:
+        want = per_view[0][k].clone()
+        for pv in per_view[1:]:
+            want = want + pv[k]            # view order, as sum_slices_kernel adds
+        assert torch.equal(got[k], want), f"grad {k}: max diff {(got[k] - want).abs().max().item():.3e}"
+
+
+def test_views_repeatable_and_independent_of_stream_count(monkeypatch):
+    """Same bits run to run, and whether the library spreads the views over 1 or 4 side streams."""
+    from lara_amd import rasterize_gaussians_views
+    act, cams = small_scene(grid=12, size=96, n_views=6, seed=4)
+    settings = [raster_settings(c, [1.0, 1.0, 1.0], device=DEV) for c in cams]
+
+    def run():
+        inp = _inputs(act)
+        m2 = torch.zeros_like(inp["means3D"], requires_grad=True)
+        c, r, a = rasterize_gaussians_views(settings, inp["means3D"], m2, inp["opacities"], shs=inp["shs"],
+                                            scales=inp["scales"], rotations=inp["rotations"])
+        (c.sum() + 0.1 * a.sum()).backward()
+        torch.cuda.synchronize()
+        return c.detach().clone(), {k: v.grad.clone() for k, v in inp.items()}
+
+    c0, g0 = run()
+    c1, g1 = run()
+    monkeypatch.setenv("LARA2DGS_VIEW_STREAMS", "1")   # read by the Python side per call (scratch lanes)
+    c2, g2 = run()
+    assert torch.equal(c0, c1) and torch.equal(c0, c2)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]) and torch.equal(g0[k], g2[k]), k
+
+
+def test_views_argument_errors():
+    from lara_amd import rasterize_gaussians_views
+    act, cams = small_scene(grid=8, size=64, n_views=2, seed=1)
+    t = {k: v.to(DEV) for k, v in act.items()}
+    s_ok = raster_settings(cams[0], [1.0, 1.0, 1.0], device=DEV)
+    s_other = raster_settings(cams[1], [1.0, 1.0, 1.0], device=DEV)._replace(image_height=48)
+    m2 = torch.zeros_like(t["means3D"])
+    with pytest.raises(RuntimeError, match="must agree"):
+        rasterize_gaussians_views([s_ok, s_other], t["means3D"], m2, t["opacities"], shs=t["shs"], scales=t["scales"],
+                                  rotations=t["rotations"])
+    with pytest.raises(Exception, match="excatly one"):
+        rasterize_gaussians_views([s_ok], t["means3D"], m2, t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    with pytest.raises(RuntimeError, match="at least one view"):
+        rasterize_gaussians_views([], t["means3D"], m2, t["opacities"], shs=t["shs"], scales=t["scales"],
+                                  rotations=t["rotations"])
+
+
+def test_render_views_matches_render_img_loop():
+    """`Renderer.render_views` = the reference loop's n `render_img` calls (network.py:486-497)."""
+    from lara_amd import synthetic
+    from lara_amd.renderer import Renderer
+    from lara_amd import cameras
+    import math
+    sc = synthetic.make_scene(grid=12, K=2, regime="init", seed=2)
+    size, n = 96, 4
+    cams = cameras.make_cameras(cameras.turntable_c2w(n), size, size, 0.75, 0.75, 0.5, 2.5, device=DEV)
+    raw = {k: v.to(DEV) for k, v in sc.items()}
+    g = torch.Generator().manual_seed(9)
+    rays = [torch.nn.functional.normalize(torch.randn(size, size, 6, generator=g), dim=-1).to(DEV) for _ in cams]
+    bgs = [torch.tensor([1.0, 1.0, 1.0]), torch.tensor([0.0, 0.0, 0.0]), torch.tensor([0.5, 0.5, 0.5]), torch.tensor([1.0, 1.0, 1.0])]
+
+    def leafs():
+        return {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+
+    ren = Renderer(sh_degree=1, white_background=True)
+    a = leafs()
+    frames = []
+    for cam, r, bg in zip(cams, rays, bgs):
+        ren.set_bg_color(bg)
+        frames.append(ren.render_img(cam, r, a["centers"], a["shs"], a["opacity"], a["scales"], a["rotations"], DEV))
+    sum(f["image"].sum() + f["depth"].sum() + 0.1 * f["rend_normal"].sum() for f in frames).backward()
+    b = leafs()
+    ren2 = Renderer(sh_degree=1, white_background=True)
+    frames2 = ren2.render_views(cams, rays, b["centers"], b["shs"], b["opacity"], b["scales"], b["rotations"], DEV, bg_colors=bgs)
+    sum(f["image"].sum() + f["depth"].sum() + 0.1 * f["rend_normal"].sum() for f in frames2).backward()
+    torch.cuda.synchronize()
+    for f, f2 in zip(frames, frames2):
+        for k in f:
+            assert torch.equal(f[k], f2[k]), k
+    for k in a:
+        # same per-view gradients, added in a different order by autograd (loop) and by the library (views)
+        ga, gb = a[k].grad, b[k].grad
+        assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-6 * float(ga.abs().max())), k
