@@ -552,6 +552,73 @@ def point_feats_leg(device, args):
             "torch_sequence_us": round(res[False], 1), "fused_us": round(res[True], 1)}
 
 
+def fine_decoder_leg(device):
+    """`Decoder.forward_fine` (network.py:280-284) on one scene's 524 288 Gaussians (the init regime keeps 99.9 % of
+    them), forward + backward with gradients to both inputs and all ten parameters: the reference's torch sequence
+    (LayerNorm, nn.MultiheadAttention with one query and four keys, Linear-ReLU-Linear) under bf16 autocast as the
+    reference trains it, the same in fp32, and the fused HIP kernels (fp32)."""
+    from torch import nn
+    from lara_amd import rasterizer
+    from lara_amd.fine import forward_fine
+
+    class Dec(nn.Module):       # the reference's declarations, network.py:234-240
+        def __init__(self):
+            super().__init__()
+            self.norm = nn.LayerNorm(80)
+            self.cross_att = nn.MultiheadAttention(embed_dim=80, num_heads=8, kdim=8, vdim=8, dropout=0.0, bias=False, batch_first=True)
+            self.mlp_fine = nn.Sequential(nn.Linear(80, 64), nn.ReLU(), nn.Linear(64, 12))
+
+        def forward_fine(self, volume_feat, point_feats):
+            volume_feat = self.norm(volume_feat.unsqueeze(1))
+            x = self.cross_att(volume_feat, point_feats, point_feats, need_weights=False)[0]
+            return self.mlp_fine(x).float()
+
+    torch.manual_seed(0)
+    dec = Dec().to(device)
+    n = 524288
+    vol0 = torch.randn(n, 80, device=device)
+    pf0 = torch.randn(4, 8, n, device=device)
+    gout = torch.randn(n, 1, 12, device=device)
+
+    def one(mode):
+        vol, pfp = vol0.clone().requires_grad_(True), pf0.clone().requires_grad_(True)
+        pf = torch.einsum('lcb->blc', pfp)
+        if mode == "fused":
+            sh = forward_fine(dec, vol, pf)
+        else:
+            # torch's scaled-dot-product kernels reject 524 288 x 8 (batch x heads) problems in one launch on this
+            # build (hipErrorInvalidValue), so the reference sequence is fed 16 chunks of 32 768 points
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(mode == "torch_bf16")):
+                sh = torch.cat([dec.forward_fine(v, q) for v, q in zip(vol.split(32768), pf.split(32768))])
+        sh.backward(gout)
+        for p in dec.parameters():
+            p.grad = None
+
+    res = {}
+    for mode in ("torch_bf16", "torch_fp32", "fused"):
+        one(mode)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            one(mode)
+        e1.record()
+        torch.cuda.synchronize()
+        res[mode] = e0.elapsed_time(e1) / 3 * 1e3
+    rasterizer.profile_enable(True)
+    one("fused")
+    torch.cuda.synchronize()
+    k = {}
+    for name, ms in rasterizer.profile_collect():
+        k[name] = round(ms * 1e3, 1)
+    rasterizer.profile_enable(False)
+    flop = n * 2 * (64 * 80 + 64 * 64 + 12 * 64 + 600)
+    return {"workload": f"Decoder.forward_fine fwd+bwd, {n} points (one scene), gradients to inputs and parameters (incl. cloning the inputs)",
+            "unit": "us", "torch_sequence_bf16_autocast_us": round(res["torch_bf16"], 1), "torch_sequence_fp32_us": round(res["torch_fp32"], 1),
+            "fused_us": round(res["fused"], 1), "kernels_us": k,
+            "fwd_kernel_TFLOPs_f32": round(flop / (k.get("fine_decoder_fwd", 1e9) * 1e-6) / 1e12, 1) if "fine_decoder_fwd" in k else None}
+
+
 def rays_leg(device, scenes, views, res):
     """Device-side generation of the step's tar_rays + tar_rays_down (dataLoader/utils.py:21-34):
     a pure store stream, priced against the HBM peak."""
@@ -909,6 +976,7 @@ def main():
         out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
         out["render_img"] = render_img_leg(device, args)
         out["point_feats"] = point_feats_leg(device, args)
+        out["fine_decoder"] = fine_decoder_leg(device)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
         out["cpu_baseline"]["encoder"] = cpu_encoder_baseline()

@@ -1,0 +1,52 @@
+/*
+ * lara_finedec.h -- LaRa's fine-stage decoder `Decoder.forward_fine` as one kernel per direction (part of
+ * liblara2dgs.so).  SURVEY.md section 8f row 4, second half.
+ *
+ * Replaces lightning/network.py:280-284 (modules declared at :234-240), called at :518 on the <= 524 288 surviving
+ * Gaussians of a scene, directly behind the point sampler (lara_pointfeat.h):
+ *
+ *     volume_feat = self.norm(volume_feat.unsqueeze(1))                       LayerNorm(80)
+ *     x  = self.cross_att(volume_feat, point_feats, point_feats)[0]           MultiheadAttention(80, 8 heads, kdim=vdim=8,
+ *                                                                             bias=False): ONE query against the 4 views
+ *     sh = self.mlp_fine(x).float()                                           Linear(80,64) + ReLU + Linear(64,12)
+ *
+ * With one query per point the attention is linear algebra around a 4-way softmax, and the projections fold
+ * (in exact arithmetic; the Python wrapper forms the folded matrices with autograd, so gradients reach the
+ * reference's own parameters):
+ *     t[h]   = Wqk[h] xn,            Wqk[h]  = Wk[h]^T Wq[h] / sqrt(10)     [8 x 80] per head  -> Wqk  [64,80]
+ *     p[h,j] = softmax_j( t[h] . pf[j] ),      u[h] = sum_j p[h,j] pf[j]    (pf[j] = the 8 sampled channels of view j)
+ *     hid    = relu(W1ov u + b1),    W1ov    = W1 Wo blockdiag(Wv[h])       [64,64]   (out-projection and first MLP
+ *                                                                            layer have no non-linearity between them)
+ *     sh     = W2 hid + b2
+ * Per point: 80 + 32 floats in, 12 out, ~10.6 k FMAs (the unfolded sequence: ~25 k and eight [n,80]-sized
+ * intermediates).  fp32 arithmetic (the reference trains these layers under bf16 autocast; fp32 is at least as
+ * precise).  Layouts: xn [n,80] = the LayerNorm output; pf [4][8][n] = the sampler's own output layout (the
+ * reference permutes it to [n,4,8] with an einsum, network.py:515); sh [n,12].
+ *
+ * Backward: d_sh [n,12] -> d_xn [n,80], d_pf [4][8][n], plus the four per-point factor arrays the weight gradients are
+ * GEMMs of (caller allocates [n,64] each; the wrapper runs the GEMMs with the library BLAS):
+ *     U, HID (post-ReLU), DH = dL/d(pre-ReLU), DT = dL/dt:
+ *     dWqk = DT^T xn,  dW1ov = DH^T U,  db1 = colsum(DH),  dW2 = d_sh^T HID,  db2 = colsum(d_sh).
+ * Returns 0 or a negative LARA2DGS_E_* code; work is enqueued on `stream`, no host synchronisation.
+ * Only the reference's sizes are built (80 / 8 heads x 10 / 4 views x 8 channels / 64 / 12).
+ */
+#ifndef LARA_FINEDEC_H
+#define LARA_FINEDEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int lara_fine_decoder_forward(int32_t n, const float *xn, const float *pf, const float *Wqk, const float *W1ov,
+                              const float *b1, const float *W2, const float *b2, float *sh, void *stream);
+
+int lara_fine_decoder_backward(int32_t n, const float *xn, const float *pf, const float *Wqk, const float *W1ov,
+                               const float *b1, const float *W2, const float *b2, const float *d_sh, float *d_xn,
+                               float *d_pf, float *U, float *HID, float *DH, float *DT, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LARA_FINEDEC_H */

@@ -8,6 +8,12 @@ rasteriser pass); the input images get none, as in the reference where they are 
 
 Opt-in: bind it over the reference's method, e.g. ``Network.get_point_feats = lara_amd.fine.get_point_feats``.
 No CPU path: tensors must live on the GPU.
+
+Second half of the row: ``Decoder.forward_fine`` (network.py:280-284) -- LayerNorm, a one-query / four-view
+cross-attention (8 heads of 10) and a two-layer MLP on every surviving Gaussian -- as one HIP kernel per direction
+(``lara_fine_decoder_forward`` / ``_backward``, include/lara_finedec.h).  ``forward_fine(decoder, volume_feat,
+point_feats)`` takes the reference's own ``Decoder`` (its parameters stay the trainable ones) and the same two
+arguments; bind it with ``Decoder.forward_fine = lara_amd.fine.forward_fine``.
 """
 from __future__ import annotations
 
@@ -31,6 +37,10 @@ def _lib():
         lib.lara_point_feats_backward.argtypes = [i32, i32, i32, i32] + [vp] * 14
         lib.lara_point_feats_workspace_bytes.restype = ctypes.c_int64
         lib.lara_point_feats_workspace_bytes.argtypes = [i32, i32, i32]
+        lib.lara_fine_decoder_forward.restype = ctypes.c_int
+        lib.lara_fine_decoder_forward.argtypes = [i32] + [vp] * 9
+        lib.lara_fine_decoder_backward.restype = ctypes.c_int
+        lib.lara_fine_decoder_backward.argtypes = [i32] + [vp] * 15
         _configured = True
     return lib
 
@@ -99,3 +109,95 @@ def get_point_feats(self, idx, img_ref, renderings, n_views_sel, batch, points, 
     feats = sample_point_feats(points, src_w2cs, src_ixts, img_ref, renderings['image'], renderings['acc_map'],
                                renderings['depth'])
     return feats, mask
+
+
+# ---------------------------------------------------------------------------------------------
+# Decoder.forward_fine (network.py:280-284)
+# ---------------------------------------------------------------------------------------------
+_FD, _NH, _HD, _CD, _NV, _HID = 80, 8, 10, 8, 4, 64   # the only sizes the kernel is built for (configs/base.yaml)
+
+
+class _FineDecoder(torch.autograd.Function):
+    """(xn [n,80], pf [4,8,n], Wqk [64,80], W1ov [64,64], b1 [64], W2 [12,64], b2 [12]) -> sh [n,12]."""
+
+    @staticmethod
+    def forward(ctx, xn, pf, Wqk, W1ov, b1, W2, b2):
+        if not xn.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        f = lambda t: t.detach().float().contiguous()
+        xn, pf, Wqk, W1ov, b1, W2, b2 = map(f, (xn, pf, Wqk, W1ov, b1, W2, b2))
+        n = xn.shape[0]
+        sh = torch.empty(n, W2.shape[0], dtype=torch.float32, device=xn.device)
+        with torch.cuda.device(xn.device):
+            _check(_lib().lara_fine_decoder_forward(n, xn.data_ptr(), pf.data_ptr(), Wqk.data_ptr(), W1ov.data_ptr(),
+                                                    b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), sh.data_ptr(),
+                                                    torch.cuda.current_stream(xn.device).cuda_stream),
+                   "lara_fine_decoder_forward")
+        ctx.save_for_backward(xn, pf, Wqk, W1ov, b1, W2, b2)
+        return sh
+
+    @staticmethod
+    def backward(ctx, d_sh):
+        xn, pf, Wqk, W1ov, b1, W2, b2 = ctx.saved_tensors
+        n = xn.shape[0]
+        d_sh = d_sh.float().contiguous()
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=xn.device)
+        d_xn, d_pf = new(n, _FD), new(_NV, _CD, n)
+        U, H, DH, DT = new(n, 64), new(n, _HID), new(n, _HID), new(n, 64)
+        with torch.cuda.device(xn.device):
+            _check(_lib().lara_fine_decoder_backward(n, xn.data_ptr(), pf.data_ptr(), Wqk.data_ptr(), W1ov.data_ptr(),
+                                                     b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), d_sh.data_ptr(),
+                                                     d_xn.data_ptr(), d_pf.data_ptr(), U.data_ptr(), H.data_ptr(),
+                                                     DH.data_ptr(), DT.data_ptr(),
+                                                     torch.cuda.current_stream(xn.device).cuda_stream),
+                   "lara_fine_decoder_backward")
+        # the weight gradients are plain GEMMs over the points (library BLAS): [64,n] x [n,80] etc.
+        return (d_xn, d_pf, _tn_over_points(DT, xn), _tn_over_points(DH, U), DH.sum(0), _tn_over_points(d_sh, H), d_sh.sum(0))
+
+
+def _tn_over_points(a, b, chunk=1024):
+    """a^T b for a [n,p], b [n,q] with n in the hundreds of thousands and p, q <= 80: one output tile, so a plain GEMM
+    call runs on one or two workgroups (measured 1 ms for [64,524288] x [524288,80]).  Split the point axis into
+    `chunk`-sized slabs -> a batched GEMM that fills the chip, then add the slabs (fixed order: reproducible)."""
+    n = a.shape[0]
+    m = n // chunk * chunk
+    out = None
+    if m:
+        out = torch.bmm(a[:m].view(-1, chunk, a.shape[1]).transpose(1, 2), b[:m].view(-1, chunk, b.shape[1])).sum(0)
+    if m < n:
+        tail = a[m:].t() @ b[m:]
+        out = tail if out is None else out + tail
+    return out
+
+
+def _fold_fine_weights(decoder):
+    """The folded matrices of include/lara_finedec.h, formed WITH autograd from the reference Decoder's parameters
+    (network.py:234-240), in fp32."""
+    att = decoder.cross_att
+    E = att.embed_dim
+    if (E != _FD or att.num_heads != _NH or att.kdim != _CD or att.vdim != _CD or att.in_proj_bias is not None
+            or att.out_proj.bias is not None or decoder.mlp_fine[0].out_features != _HID):
+        raise RuntimeError("lara_amd.fine.forward_fine is built for LaRa's sizes only: embed 80, 8 heads, kdim = vdim = 8, "
+                           "no biases in the attention, hidden 64")
+    Wq = att.q_proj_weight.float().view(_NH, _HD, E)            # [h, d, i]
+    Wk = att.k_proj_weight.float().view(_NH, _HD, _CD)          # [h, d, c]
+    Wv = att.v_proj_weight.float().view(_NH, _HD, _CD)
+    Wo = att.out_proj.weight.float().view(E, _NH, _HD)          # [o, h, d]
+    Wqk = torch.einsum("hdc,hdi->hci", Wk, Wq).reshape(_NH * _CD, E) * (_HD ** -0.5)
+    Wov = torch.einsum("ohd,hdc->ohc", Wo, Wv).reshape(E, _NH * _CD)
+    W1, b1 = decoder.mlp_fine[0].weight.float(), decoder.mlp_fine[0].bias.float()
+    W2, b2 = decoder.mlp_fine[2].weight.float(), decoder.mlp_fine[2].bias.float()
+    return Wqk, W1 @ Wov, b1, W2, b2
+
+
+def forward_fine(decoder, volume_feat, point_feats):
+    """Same arguments and return value as ``Decoder.forward_fine`` (network.py:280-284): volume_feat [n,80],
+    point_feats [n,4,8] (the reference passes the sampler's [4,8,n] output through `einsum('lcb->blc')`, a view --
+    its storage is used as it is) -> sh [n,1,12] fp32."""
+    if point_feats.dim() != 3 or point_feats.shape[1:] != (_NV, _CD) or volume_feat.shape[-1] != _FD:
+        raise RuntimeError("expected volume_feat [n,80] and point_feats [n,4,8]")
+    xn = torch.nn.functional.layer_norm(volume_feat.float(), (_FD,), decoder.norm.weight.float(), decoder.norm.bias.float(),
+                                        decoder.norm.eps)
+    pf = point_feats.float().permute(1, 2, 0)      # [4,8,n]; contiguous() is a no-op on the sampler's own layout
+    sh = _FineDecoder.apply(xn, pf, *_fold_fine_weights(decoder))
+    return sh.unsqueeze(1)
