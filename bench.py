@@ -321,11 +321,11 @@ def _newest_profile(pattern, reader):
 
 def _valu_issue_frac(csv_path, kernel):
     """SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is
-    the launch's duration in shader cycles."""
+    the launch's duration in shader cycles summed over the 8 XCDs (rocprofv3 adds the per-XCD instances)."""
     import csv
     for r in csv.DictReader(open(csv_path)):
         if r["kernel"].split("<")[0] == kernel and r.get("SQ_ACTIVE_INST_VALU") and r.get("GRBM_GUI_ACTIVE"):
-            return round(4.0 * float(r["SQ_ACTIVE_INST_VALU"]) / (1024.0 * float(r["GRBM_GUI_ACTIVE"])), 4)
+            return round(4.0 * float(r["SQ_ACTIVE_INST_VALU"]) / (1024.0 * float(r["GRBM_GUI_ACTIVE"]) / 8.0), 4)
     return None
 
 

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/traffic_${TAG}_$C -o pmc -- \
-      python $REPO/bench.py --steps 1 --warmup 0 --scenes 1 --no-cpu-baseline --no-roofline $EXTRA > $OUT/traffic_${TAG}_$C.log 2>&1
+      python $REPO/bench.py --steps 1 --warmup 0 --scenes 1 --step raster --raster-api loop --streams 1 --no-fine --no-cpu-baseline --no-roofline $EXTRA > $OUT/traffic_${TAG}_$C.log 2>&1
 done
 find $OUT/traffic_${TAG}_* -type f -size +8M -delete
 find $OUT/traffic_${TAG}_* -type f | head

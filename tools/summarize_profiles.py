@@ -15,7 +15,7 @@ def short(name):
 
 def pmc_table(pattern):
     agg, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
-    for f in glob.glob(pattern):
+    for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -23,10 +23,14 @@ def pmc_table(pattern):
     return agg, cnt
 
 
-st = os.path.join(out, f"prof_{tag}_stats", "stats_kernel_stats.csv")
-if os.path.exists(st):
+sts = glob.glob(os.path.join(out, f"prof_{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
+st = sts[0] if sts else ""
+if st:
     shutil.copy(st, os.path.join(prof, f"{tag}_kernel_stats.csv"))
-agg, cnt = pmc_table(os.path.join(out, f"prof_{tag}_pmc", "pmc_counter_collection.csv"))
+sts = glob.glob(os.path.join(out, f"prof_{tag}_stats_train", "**", "*kernel_stats.csv"), recursive=True)
+if sts:
+    shutil.copy(sts[0], os.path.join(prof, f"{tag}_kernel_stats_train_step.csv"))
+agg, cnt = pmc_table(os.path.join(out, f"prof_{tag}_pmc*", "**", "*counter_collection.csv"))
 if agg:
     cols = sorted({c for d in agg.values() for c in d})
     with open(os.path.join(prof, f"{tag}_pmc_summary.csv"), "w") as f:
@@ -36,7 +40,7 @@ if agg:
             f.write(f"{k},{n}," + ",".join(str(int(d.get(c, 0) / max(cnt[(k, c)], 1))) for c in cols) + "\n")
 traffic = {}
 for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-    agg, cnt = pmc_table(os.path.join(out, f"traffic_{tag}_{c}", "pmc_counter_collection.csv"))
+    agg, cnt = pmc_table(os.path.join(out, f"traffic_{tag}_{c}", "**", "*counter_collection.csv"))
     for k, d in agg.items():
         if "lara" in k or k.endswith("_fwd") or k.endswith("_bwd") or "tile_" in k or "scatter" in k or "<" in k:
             name = re.sub(r"<.*", "", k)
