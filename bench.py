@@ -257,8 +257,6 @@ def measure_roofline(scenes, settings, gc, ga, args):
         "preprocess_fwd": 88 * P + 87 * P,
         "tile_scan": 12 * (HW // 256),
         "scatter": 12 * D,
-        "tile_sort_small": 24 * D + 8 * D,
-        "tile_sort_large": 0,
         "tile_sort": 24 * D + 8 * D,
         "composite_fwd": 76 * D + 60 * HW,
         "composite_bwd": 76 * D + 100 * HW + 144 * D,

@@ -103,6 +103,8 @@ ScratchView carve_scratch(const ViewDev &v, void *scratch, ScratchLayout &L) {
     s.tile_count = (uint32_t *)(b + L.tile_count);
     s.tile_fill = (uint32_t *)(b + L.tile_fill);
     s.sub_start = (uint32_t *)(b + L.sub_start);
+    s.sort_parts = (uint32_t *)(b + L.sort_parts);
+    s.sort_items = (uint2 *)(b + L.sort_items);
     s.rect = (uint4 *)(b + L.rect);
     s.keys = (uint64_t *)(b + L.keys);
     s.block_tot = (uint32_t *)(b + L.block_tot);

@@ -45,17 +45,50 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, const uint32_t n, const uint
     }
 }
 
+// how many workgroups share the sort of a list of `len` entries (see tile_sort_kernel)
+constexpr int L2D_SORT_PARTS = 2;
+__device__ __forceinline__ uint32_t l2d_sort_parts(const uint32_t len) {
+    return len <= 4096u || len > 8192u ? 1u : 2u;
+}
+
 // ---- 2. exclusive scan of tile counts -> ranges ------------------------------------------------
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ sub_start,
                  uint2 *__restrict__ ranges, uint32_t *__restrict__ header,
                  uint32_t *__restrict__ tile_order, uint32_t *__restrict__ block_tot,
                  uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt,
-                 uint32_t *__restrict__ bwd_order, uint2 *__restrict__ bwd_items) {
+                 uint32_t *__restrict__ bwd_order, uint2 *__restrict__ bwd_items,
+                 uint32_t *__restrict__ sort_parts, uint2 *__restrict__ sort_items) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s, s_max;
     __shared__ uint32_t bcnt[64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (blockIdx.x == 1) {   // the second workgroup: a scan that does not depend on the tiles, run beside the others
+        // exclusive scan (in place) of the per-surfel-block pair totals -> surfel-major pair numbering
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        const int nblk = (v.P + 255) / 256;
+        for (int base = 0; base < nblk; base += 1024) {
+            const int i = base + tid;
+            const uint32_t c = i < nblk ? block_tot[i] : 0u;
+            uint32_t x = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) wave_sums[wid] = x;
+            __syncthreads();
+            uint32_t wave_off = 0;
+            for (int w = 0; w < wid; w++) wave_off += wave_sums[w];
+            const uint32_t incl = carry_s + wave_off + x;
+            if (i < nblk) block_tot[i] = incl - c;
+            __syncthreads();
+            if (tid == 1023) carry_s = incl;
+            __syncthreads();
+        }
+        return;
+    }
     if (tid == 0) carry_s = 0;
     // this kernel is the first to touch the header (words 0-3 are assigned below, the rest are the composite
     // kernels' debug counters): zeroing it here saves the forward a memset launch
@@ -211,15 +244,17 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         const uint32_t pl = len - seg_cnt[i] * L2D_SEG;
         bwd_order[atomicAdd(&bcnt[63u - (uint32_t)(((uint64_t)min(pl, (uint32_t)L2D_SEG) * 64u) / (L2D_SEG + 1u))], 1u)] = (uint32_t)i;
     }
-    // exclusive scan (in place) of the per-surfel-block pair totals -> surfel-major pair numbering
+    // The sort's work list: a list longer than 2048 entries is shared by several workgroups (tile_sort_kernel), one
+    // extra work item per additional part; at most `tiles` items (a tile that finds the list full gets fewer parts).
     __syncthreads();
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    const int nblk = (v.P + 255) / 256;
-    for (int base = 0; base < nblk; base += 1024) {
+    for (int base = 0; base < v.tiles; base += 1024) {
         const int i = base + tid;
-        const uint32_t c = i < nblk ? block_tot[i] : 0u;
-        uint32_t x = c;
+        uint32_t len = 0;
+        if (i < v.tiles) { const uint2 rg = ranges[i]; len = rg.y - rg.x; }
+        const uint32_t want = l2d_sort_parts(len) - 1u;
+        uint32_t x = want;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(x, d, 64);
@@ -229,12 +264,18 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         __syncthreads();
         uint32_t wave_off = 0;
         for (int w = 0; w < wid; w++) wave_off += wave_sums[w];
-        const uint32_t incl = carry_s + wave_off + x;
-        if (i < nblk) block_tot[i] = incl - c;
+        const uint32_t incl = carry_s + wave_off + x, first = incl - want;
+        if (i < v.tiles) {
+            const uint32_t room = first < (uint32_t)v.tiles ? (uint32_t)v.tiles - first : 0u;
+            const uint32_t got = want < room ? want : room;
+            sort_parts[i] = 1u + got;
+            for (uint32_t q = 0; q < got; q++) sort_items[first + q] = make_uint2((uint32_t)i, q + 1u);
+        }
         __syncthreads();
         if (tid == 1023) carry_s = incl;
         __syncthreads();
     }
+    if (tid == 0) sort_parts[v.tiles] = carry_s < (uint32_t)v.tiles ? carry_s : (uint32_t)v.tiles;
 }
 
 // ---- 3. scatter (depth bits, id) into the tile segments ----------------------------------------
@@ -390,37 +431,235 @@ __device__ __forceinline__ void sort_tile(const uint64_t *__restrict__ seg, cons
         }
 }
 
-// LARGE = false: tiles with n <= 2048 (16 KB LDS); LARGE = true: 2048 < n (64 KB LDS; lists longer
-// than 8192 fall back to the generic network run directly on the global segment)
-template <bool LARGE>
-__global__ void __launch_bounds__(LARGE ? 1024 : 512)
+// One launch of 512-thread workgroups in longest-list-first order; up to 4096 keys are sorted in 32 KB of LDS (four
+// workgroups per CU) by sort_keys().  A longer list (round 1: a second launch of 1024-thread workgroups for those
+// few lists lasted 64 us on its own) is cut by KEY RANGE into L2D_SORT_PARTS parts that different workgroups sort
+// independently: part k takes the keys whose
+// depth falls into the k-th of S equal slices of the list's [min, max] depth interval, knows where its output starts
+// (the number of keys in lower slices, counted on its own pass over the segment: no communication between
+// workgroups), compacts its keys into LDS in arbitrary order and sorts them.  Concatenated parts = the sorted list,
+// whatever the depth distribution (a skewed one only balances worse; a slice beyond the LDS buffer makes part 0 sort
+// the whole list in place).  Lists beyond 8192 entries (not reached at LaRa's sizes) take that in-place path too.
+constexpr uint32_t L2D_SORT_LDS_KEYS = 4096;   // 32 KB: four 512-thread workgroups per CU, as many as its wave slots hold
+
+// Sort m <= 4096 keys (from the global segment, or already compacted into `lds`) and write ids + pair_pos at `off`.
+//
+// Bucket sort: the keys are dealt into B ~ m/4 buckets by depth (equal slices of the [min, max] interval -- LaRa's
+// depths inside a tile are close to uniform), each bucket is put in order by one thread with an insertion sort on the
+// full 64-bit (depth, id) word -- ties come out id-ascending, the reference's stable-sort order, without any
+// stability requirement on the passes before -- and the concatenated buckets are the sorted list.  ~60 operations and
+// 7 barriers per key against ~55 compare-exchange stages (most of them with a cross-lane or LDS exchange) of the
+// bitonic network it replaces; that network remains the fallback for a depth distribution that overfills a bucket
+// (a wall of equal depths).
+constexpr int L2D_SORT_BUCKETS = 1024, L2D_SORT_BUCKET_MAX = 48;
+
+template <int E>
+__device__ __forceinline__ void sort_keys(const uint64_t *src, const uint32_t m, uint32_t *__restrict__ out,
+                                          const uint32_t off, uint64_t *lds, uint32_t *bkt, uint32_t *sh, const PairMap &pm) {
+    const int t = threadIdx.x, lane = t & 63;
+    uint64_t x[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = (t + e * 512 < (int)m) ? src[t + e * 512] : ~0ull;
+    if (t == 0) { sh[0] = ~0u; sh[1] = 0u; sh[2] = 0u; }
+    const uint32_t B = m <= 256u ? 64u : (m <= 1024u ? 256u : (uint32_t)L2D_SORT_BUCKETS);
+    for (uint32_t b = t; b < B; b += 512) bkt[b] = 0u;
+    __syncthreads();   // (also: every key of `src` is in registers, `lds` may be overwritten from here on)
+    uint32_t lo = ~0u, hi = 0u;
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if (t + e * 512 < (int)m) {
+            const uint32_t d = (uint32_t)(x[e] >> 32);
+            lo = d < lo ? d : lo;
+            hi = d > hi ? d : hi;
+        }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) {
+        const uint32_t a = __shfl_xor(lo, k, 64), b = __shfl_xor(hi, k, 64);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if (lane == 0) { atomicMin(&sh[0], lo); atomicMax(&sh[1], hi); }
+    __syncthreads();
+    const uint32_t dmin = sh[0];
+    // bucket = floor((d - dmin) * B / (range + 1)) as a multiply-high by a per-tile constant (monotone in d, < B)
+    const uint64_t scale = ((uint64_t)B << 32) / ((uint64_t)(sh[1] - dmin) + 1ull);
+    uint32_t bk[E], slot[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        bk[e] = 0u; slot[e] = 0u;
+        if (t + e * 512 < (int)m) {
+            const uint64_t q = (uint64_t)((uint32_t)(x[e] >> 32) - dmin) * scale;
+            bk[e] = (uint32_t)(q >> 32);
+            bk[e] = bk[e] < B ? bk[e] : B - 1u;   // (scale is rounded down: the product cannot reach B; belt and braces)
+            slot[e] = atomicAdd(&bkt[bk[e]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the B bucket sizes (two per thread), the largest bucket on the side
+    {
+        const uint32_t c0 = 2 * t < (int)B ? bkt[2 * t] : 0u, c1 = 2 * t + 1 < (int)B ? bkt[2 * t + 1] : 0u;
+        uint32_t incl = c0 + c1, big = c0 > c1 ? c0 : c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) { const uint32_t y = __shfl_xor(big, k, 64); big = y > big ? y : big; }
+        if (lane == 63) sh[4 + (t >> 6)] = incl;
+        if (lane == 0) atomicMax(&sh[2], big);
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < (t >> 6); w++) wave_off += sh[4 + w];
+        __syncthreads();
+        if (2 * t < (int)B) bkt[2 * t] = wave_off + incl - c0 - c1;
+        if (2 * t + 1 < (int)B) bkt[2 * t + 1] = wave_off + incl - c1;
+        if (t == 511) bkt[B] = wave_off + incl;   // = m
+    }
+    __syncthreads();
+    if (sh[2] > (uint32_t)L2D_SORT_BUCKET_MAX) {   // uniform: a degenerate depth distribution -> the sorting network
+        __syncthreads();
+        block_sort<E, 512>(x, lds);
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if ((uint32_t)(t * E + e) < m) {
+                out[off + t * E + e] = (uint32_t)x[e];
+                pm.put((uint32_t)x[e], off + t * E + e);
+            }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if (t + e * 512 < (int)m) lds[bkt[bk[e]] + slot[e]] = x[e];
+    __syncthreads();
+    for (uint32_t b = t; b < B; b += 512) {      // one thread per bucket: insertion sort on the 64-bit words
+        const uint32_t s0 = bkt[b], s1 = bkt[b + 1];
+        for (uint32_t i = s0 + 1; i < s1; i++) {
+            const uint64_t key = lds[i];
+            uint32_t j = i;
+            while (j > s0 && lds[j - 1] > key) { lds[j] = lds[j - 1]; j--; }
+            lds[j] = key;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < m; i += 512) {
+        const uint32_t id = (uint32_t)lds[i];
+        out[off + i] = id;
+        pm.put(id, off + i);
+    }
+}
+
+template <int DUMMY = 0>
+__device__ __forceinline__ void sort_dispatch(const uint64_t *src, const uint32_t m, uint32_t *__restrict__ out,
+                                              const uint32_t off, uint64_t *lds, uint32_t *bkt, uint32_t *sh, const PairMap &pm) {
+    if (m <= 512u) sort_keys<1>(src, m, out, off, lds, bkt, sh, pm);
+    else if (m <= 1024u) sort_keys<2>(src, m, out, off, lds, bkt, sh, pm);
+    else if (m <= 2048u) sort_keys<4>(src, m, out, off, lds, bkt, sh, pm);
+    else sort_keys<8>(src, m, out, off, lds, bkt, sh, pm);
+}
+
+__global__ void __launch_bounds__(512)
 tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ header,
                  const uint32_t *__restrict__ tile_order, uint64_t *__restrict__ keys,
                  uint32_t *__restrict__ point_list, const uint4 *__restrict__ rect,
-                 const uint32_t *__restrict__ pair_base, uint32_t *__restrict__ pair_pos) {
-    __shared__ uint64_t lds[LARGE ? 8192 : 2048];
-    const int tile = (int)tile_order[blockIdx.x];
+                 const uint32_t *__restrict__ pair_base, uint32_t *__restrict__ pair_pos,
+                 const uint32_t *__restrict__ sort_parts, const uint2 *__restrict__ sort_items) {
+    __shared__ uint64_t lds[L2D_SORT_LDS_KEYS];
+    __shared__ uint32_t bkt[L2D_SORT_BUCKETS + 1], sh[16];
+    __shared__ uint32_t s_min, s_max, s_mine, s_hist[L2D_SORT_PARTS];
+    // Grid: `tiles` extra work items first (tile_scan's list of (tile, part >= 1) for the long lists; the unused ones
+    // exit on one load), then part 0 of every tile in longest-list-first order.  (A grid of parts x tiles workgroups
+    // that find out for themselves that they are not needed costs 20 us in dependent loads before they exit.)
+    int part = 0, tile;
+    if ((int)blockIdx.x < v.tiles) {
+        if (blockIdx.x >= sort_parts[v.tiles]) return;
+        const uint2 it = sort_items[blockIdx.x];
+        tile = (int)it.x; part = (int)it.y;
+    } else {
+        tile = (int)tile_order[(int)blockIdx.x - v.tiles];
+    }
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
     if (header[1]) return;  // capacity overflow: lists are incomplete, outputs get poisoned instead
-    if (n == 0 || (LARGE ? (n <= 2048u) : (n > 2048u))) return;  // the other kernel's tile
+    if (n == 0) return;
+    const int S = (int)sort_parts[tile];
     uint64_t *seg = keys + rg.x;
     uint32_t *out = point_list + rg.x;
     const PairMap pm{rect, pair_base, pair_pos, tile % v.gx, tile / v.gx, rg.x};
-    if (!LARGE) {
-        if (n <= 512u) sort_tile<1, 512>(seg, n, out, lds, pm);
-        else if (n <= 1024u) sort_tile<2, 512>(seg, n, out, lds, pm);
-        else sort_tile<4, 512>(seg, n, out, lds, pm);
-    } else {  // 1024 threads: long lists are few, give each of them 16 waves
-        if (n <= 4096u) sort_tile<4, 1024>(seg, n, out, lds, pm);
-        else if (n <= 8192u) sort_tile<8, 1024>(seg, n, out, lds, pm);
-        else {
-            bitonic_sort(seg, n, next_pow2(n));
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-                out[i] = (uint32_t)seg[i];
-                pm.put((uint32_t)seg[i], i);
-            }
+    bool whole_list_in_place = S == 1 && n > L2D_SORT_LDS_KEYS;   // beyond 8192 entries, or no work items left for this tile
+    if (S == 1 && !whole_list_in_place) {
+        sort_dispatch(seg, n, out, 0u, lds, bkt, sh, pm);
+        return;
+    }
+    if (S > 1) {
+        // ---- the S equal slices of the list's depth interval; every part counts all of them (same data, same
+        //      result in every workgroup of the tile: no communication needed to agree on the fallback below)
+        if (threadIdx.x == 0) { s_min = ~0u; s_max = 0u; s_mine = 0u; }
+        if (threadIdx.x < L2D_SORT_PARTS) s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t lo = ~0u, hi = 0u;
+        for (uint32_t i = threadIdx.x; i < n; i += 512) {
+            const uint32_t d = (uint32_t)(seg[i] >> 32);
+            lo = d < lo ? d : lo;
+            hi = d > hi ? d : hi;
         }
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) {
+            const uint32_t a = __shfl_xor(lo, k, 64), b = __shfl_xor(hi, k, 64);
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+        __syncthreads();
+        const uint32_t dmin = s_min;
+        const uint64_t width = (uint64_t)(s_max - dmin) + 1ull;
+        uint32_t cnt[L2D_SORT_PARTS];
+#pragma unroll
+        for (int b = 0; b < L2D_SORT_PARTS; b++) cnt[b] = 0u;
+        for (uint32_t i = threadIdx.x; i < n; i += 512) {   // (the segment is re-read from L2: 8 B per key)
+            const int bin = (int)(((uint64_t)((uint32_t)(seg[i] >> 32) - dmin) * (uint64_t)S) / width);
+#pragma unroll
+            for (int b = 0; b < L2D_SORT_PARTS; b++) cnt[b] += bin == b ? 1u : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < L2D_SORT_PARTS; b++) {
+#pragma unroll
+            for (int k = 32; k > 0; k >>= 1) cnt[b] += __shfl_xor(cnt[b], k, 64);
+            if ((threadIdx.x & 63) == 0 && cnt[b]) atomicAdd(&s_hist[b], cnt[b]);
+        }
+        __syncthreads();
+        uint32_t off = 0, biggest = 0;
+        for (int b = 0; b < S; b++) {
+            off += b < part ? s_hist[b] : 0u;
+            biggest = s_hist[b] > biggest ? s_hist[b] : biggest;
+        }
+        if (biggest > L2D_SORT_LDS_KEYS) {       // a slice that does not fit the LDS (a wall of equal depths): part 0 sorts
+            if (part != 0) return;               // the whole list in place instead, every other part stands down
+            whole_list_in_place = true;
+        } else {
+            const uint32_t m = s_hist[part];
+            if (m == 0) return;
+            for (uint32_t i0 = 0; i0 < n; i0 += 512) {      // (uniform trip count: the ballot below needs the whole wave)
+                const uint32_t i = i0 + threadIdx.x;
+                const uint64_t key = i < n ? seg[i] : 0ull;
+                const int bin = i < n ? (int)(((uint64_t)((uint32_t)(key >> 32) - dmin) * (uint64_t)S) / width) : -1;
+                // one LDS atomic per wave, slots inside the wave by rank (not one same-address atomic per key; the order is arbitrary anyway: the sort follows
+                const unsigned long long mine = __ballot(bin == part);
+                uint32_t base = 0;
+                if ((threadIdx.x & 63) == 0 && mine) base = atomicAdd(&s_mine, (uint32_t)__builtin_popcountll(mine));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (bin == part) lds[base + (uint32_t)__builtin_popcountll(mine & ((1ull << (threadIdx.x & 63)) - 1ull))] = key;
+            }
+            __syncthreads();
+            sort_dispatch(lds, m, out, off, lds, bkt, sh, pm);
+            return;
+        }
+    }
+    // generic network run directly on the global segment (lists beyond 8192 entries, degenerate depth distributions)
+    bitonic_sort(seg, n, next_pow2(n));
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        out[i] = (uint32_t)seg[i];
+        pm.put((uint32_t)seg[i], i);
     }
 }
 
@@ -429,9 +668,9 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s) {
     {
         L2D_PROF("tile_scan", s);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(v.P > 0 ? 2 : 1), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
                            st.ranges, st.header, st.tile_order, sc.block_tot, st.seg_base, st.seg_cnt, st.bwd_order,
-                           st.bwd_items);
+                           st.bwd_items, sc.sort_parts, sc.sort_items);
     }
     L2D_CHECK_LAUNCH();
     if (v.P == 0) return LARA2DGS_OK;
@@ -444,17 +683,9 @@ int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s
     }
     L2D_CHECK_LAUNCH();
     {
-        L2D_PROF("tile_sort_small", s);
-        hipLaunchKernelGGL((tile_sort_kernel<false>), dim3(v.tiles), dim3(512), 0, s, v, st.ranges,
-                           st.header, st.tile_order, sc.keys, st.point_list, sc.rect, st.pair_base,
-                           st.pair_pos);
-    }
-    L2D_CHECK_LAUNCH();
-    {
-        L2D_PROF("tile_sort_large", s);
-        hipLaunchKernelGGL((tile_sort_kernel<true>), dim3(v.tiles), dim3(1024), 0, s, v, st.ranges,
-                           st.header, st.tile_order, sc.keys, st.point_list, sc.rect, st.pair_base,
-                           st.pair_pos);
+        L2D_PROF("tile_sort", s);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(v.tiles * 2), dim3(512), 0, s, v, st.ranges, st.header, st.tile_order,
+                           sc.keys, st.point_list, sc.rect, st.pair_base, st.pair_pos, sc.sort_parts, sc.sort_items);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

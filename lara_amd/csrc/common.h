@@ -50,6 +50,8 @@ struct ScratchView {
     uint32_t *tile_count;  // [tiles][L2D_SLICES]  population per (tile, surfel-block slice)
     uint32_t *tile_fill;   // [tiles][L2D_SLICES]  scatter cursors
     uint32_t *sub_start;   // [tiles][L2D_SLICES]  first slot of each (tile, slice) sub-segment
+    uint32_t *sort_parts;  // [tiles+1]  workgroups sharing a tile's sort (1 for short lists); [tiles] = number of sort_items
+    uint2 *sort_items;     // [tiles]  (tile, part >= 1): the extra sort workgroups of the long lists
     uint4 *rect;           // [P] tile rectangle (4 x u16 in .x,.y) + depth bits (.z)
     uint64_t *keys;        // [cap]  (depth bits << 32) | surfel id, grouped per tile, unsorted
     uint32_t *block_tot;   // [ceil(P/256)] pairs per surfel block, then (in place) their exclusive scan
@@ -86,13 +88,15 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->total = o;
 }
 
-struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, rect, keys, block_tot, pair_grad, pair_valid, total; };
+struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, sort_parts, sort_items, rect, keys, block_tot, pair_grad, pair_valid, total; };
 static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     int64_t o = 0;
     L->tile_count = o;  o = align_up(o + tiles * 4 * L2D_SLICES, 256);
     L->tile_fill = o;   o = align_up(o + tiles * 4 * L2D_SLICES, 256);
     L->sub_start = o;   o = align_up(o + tiles * 4 * L2D_SLICES, 256);
+    L->sort_parts = o;  o = align_up(o + (tiles + 1) * 4, 256);
+    L->sort_items = o;  o = align_up(o + tiles * 8, 256);
     const int64_t fwd0 = o;
     L->rect = o;        o = align_up(o + (int64_t)P * 16, 256);
     L->keys = o;        o = align_up(o + cap * 8, 256);

@@ -117,6 +117,30 @@ def test_forward_ragged_image_and_big_splats(hip_lib):
     assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 2048  # exercised the large-tile sort
 
 
+@pytest.mark.parametrize("n_wall,n_rest", [(5000, 1500), (2600, 3000), (9000, 200)])
+def test_sort_parts_wall_of_equal_depths_and_tie_order(hip_lib, n_wall, n_rest):
+    """The per-tile sort cuts long lists by depth range into parts sorted by different workgroups (binning.hip).  A wall
+    of surfels with EXACTLY equal depth cannot be cut: more than 4096 of them in one slice must take the in-place
+    fallback, fewer ride in one part; either way ties keep the reference's order (surfel id ascending), bit for bit.
+    9000 + 200 also exceeds the 8192-entry limit of the parts scheme."""
+    g = torch.Generator().manual_seed(n_wall)
+    from lara_amd import cameras
+    cam = cameras.make_cameras(cameras.turntable_c2w(4)[:1], 64, 64, 0.75, 0.75, 0.5, 2.5)[0]
+    P = n_wall + n_rest
+    means = torch.zeros(P, 3)
+    means[n_wall:] = (torch.rand(n_rest, 3, generator=g) - 0.5) * 0.15          # a small cloud around the origin
+    perm = torch.randperm(P, generator=g)                                         # wall and cloud interleaved in id order
+    act = {"means3D": means[perm].contiguous(),
+           "scales": torch.full((P, 2), 0.004), "rotations": torch.nn.functional.normalize(torch.randn(P, 4, generator=g)),
+           "opacities": torch.full((P, 1), 0.02), "shs": torch.randn(P, 4, 3, generator=g) * 0.3}
+    ref = run_oracle(oracle_view(cam, (1, 1, 1)), to_numpy(act))
+    assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > min(n_wall, 8192) - 1
+    r = _gpu_forward(raster_settings(cam, (1, 1, 1), device=DEV), act)
+    D = ref.num_rendered
+    np.testing.assert_array_equal(r["views"]["ranges"].cpu().numpy().view(np.uint32), ref.ranges)
+    np.testing.assert_array_equal(r["views"]["point_list"][:D].cpu().numpy().view(np.uint32), ref.point_list)
+
+
 @pytest.mark.parametrize("deg", [0, 2, 3])
 def test_forward_sh_degrees(hip_lib, deg):
     act, cams = small_scene(grid=10, size=96, seed=7 + deg, sh_coeffs=16)

@@ -44,8 +44,6 @@ for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     for k, d in agg.items():
         if "lara" in k or k.endswith("_fwd") or k.endswith("_bwd") or "tile_" in k or "scatter" in k or "<" in k:
             name = re.sub(r"<.*", "", k)
-            if k.startswith("tile_sort"):
-                name = "tile_sort_large" if "true" in k else "tile_sort_small"
             traffic.setdefault(name, {})[key] = int(d[c] / cnt[(k, c)] * 1024)  # counter unit: KB
 if traffic:
     for v in traffic.values():
