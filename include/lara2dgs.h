@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LARA2DGS_ABI_VERSION 4
+#define LARA2DGS_ABI_VERSION 5
 
 #define LARA2DGS_OK 0
 #define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
@@ -92,6 +92,9 @@ typedef struct lara2dgs_state_layout {
     int64_t bwd_items;   /* uint32[capacity/512+1][2]: (tile, segment) of every full segment (tile = ~0: unused) */
     int64_t ckpt;        /* float[capacity/1024+1][10][256]: the ten per-pixel running sums as the forward walk
                           * crosses a segment boundary; lets segments of one tile run on different CUs */
+    int64_t pair_mask;   /* uint64[capacity]: per list position, the forward's candidate mask of the entry over the tile's
+                          * 8x8 grid of 2x2 pixel blocks (bit gy*8+gx); the backward reads it instead of scan-converting
+                          * the surfel's footprint a second time */
     int64_t total;
 } lara2dgs_state_layout;
 

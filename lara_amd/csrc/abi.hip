@@ -93,6 +93,7 @@ StateView carve_state(const ViewDev &v, void *state) {
     s.bwd_order = (uint32_t *)(b + L.bwd_order);
     s.bwd_items = (uint2 *)(b + L.bwd_items);
     s.ckpt = (float *)(b + L.ckpt);
+    s.pair_mask = (uint2 *)(b + L.pair_mask);
     return s;
 }
 

@@ -44,6 +44,7 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     uint32_t *bwd_order;  // [tiles] tile ids by length of their last (partial) segment, longest first
     uint2 *bwd_items;     // [cap/L2D_SEG+1] (tile, segment) of every full segment
     float *ckpt;          // [cap/L2D_SEG+1][L2D_CKPT_F][256] per-pixel prefix sums at segment boundaries
+    uint2 *pair_mask;     // [cap] per list position: the forward's 64-bit candidate mask (lo, hi) of the entry
 };
 
 struct ScratchView {
@@ -85,6 +86,7 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->bwd_order = o;   o = align_up(o + tiles * 4, 256);
     L->bwd_items = o;   o = align_up(o + nseg * 8, 256);
     L->ckpt = o;        o = align_up(o + l2d_ckpt_slots(cap) * L2D_CKPT_F * 256 * 4, 256);
+    L->pair_mask = o;   o = align_up(o + cap * 8, 256);
     L->total = o;
 }
 

@@ -56,7 +56,7 @@ template <int CHUNK>
 __device__ __forceinline__ uint32_t stage_entry(const float4 *__restrict__ geom, const uint32_t id,
                                                 const float4 cb, const bool valid, const float X0,
                                                 const float Y0, float4 *rec, uint32_t *ids,
-                                                const int e = threadIdx.x) {
+                                                const int e = threadIdx.x, uint2 *mask_out = nullptr) {
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
     uint32_t mask_lo = 0, mask_hi = 0, rectpack = 0;
     int gx0 = 0, gx1 = -1, gy0 = 0, gy1 = -1;
@@ -139,7 +139,37 @@ __device__ __forceinline__ uint32_t stage_entry(const float4 *__restrict__ geom,
     rec[0 * CHUNK + e] = r0; rec[1 * CHUNK + e] = r1; rec[2 * CHUNK + e] = r2;
     rec[3 * CHUNK + e] = r3; rec[4 * CHUNK + e] = r4; rec[5 * CHUNK + e] = r5;
     if (ids) ids[e] = valid ? id : 0u;
+    if (mask_out && valid) *mask_out = make_uint2(mask_lo, mask_hi);   // kept for the backward (stage_entry_masked)
     return rectpack;
+}
+
+// phase S of the backward: the same planes from the mask the forward stored for this list position -- no cull box, no
+// logarithm, no per-row conics; the record is only fetched for entries some block of the tile can see.
+template <int CHUNK>
+__device__ __forceinline__ void stage_entry_masked(const float4 *__restrict__ geom, const uint32_t id, const uint2 mask,
+                                                   const bool valid, const float X0, const float Y0, float4 *rec,
+                                                   uint32_t *ids, const int e) {
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
+    if (valid && (mask.x | mask.y)) {
+        const float4 *g = geom + (size_t)id * 5;
+        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
+        const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
+        const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
+        const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
+        float A[3], B[3], C[3];
+        cross3(k0, l0, A);
+        cross3(Tw, l0, B);
+        cross3(k0, Tw, C);
+        r0 = make_float4(A[0], A[1], A[2], B[0]);
+        r1 = make_float4(B[1], B[2], C[0], C[1]);
+        r2 = make_float4(C[2], g2.y - X0, g2.z - Y0, Tw[0]);
+        r3 = make_float4(Tw[1], Tw[2], g2.w, __uint_as_float(mask.x));
+        r4 = make_float4(g3.x, g3.y, g3.z, g4.x);
+        r5 = make_float4(g4.y, g4.z, __uint_as_float(mask.y), 0.f);
+    }
+    rec[0 * CHUNK + e] = r0; rec[1 * CHUNK + e] = r1; rec[2 * CHUNK + e] = r2;
+    rec[3 * CHUNK + e] = r3; rec[4 * CHUNK + e] = r4; rec[5 * CHUNK + e] = r5;
+    ids[e] = valid ? id : 0u;
 }
 
 struct Hit {
@@ -238,7 +268,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
-                     float *__restrict__ ckpt,
+                     float *__restrict__ ckpt, uint2 *__restrict__ pair_mask,
                      float *__restrict__ out_color, float *__restrict__ out_allmap) {
     constexpr int CHUNK = FWD_CHUNK;
     static_assert(L2D_SEG % FWD_CHUNK == 0, "segment boundaries must fall on round boundaries");
@@ -308,7 +338,8 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             id1[q] = id2[q];
             id2[q] = base + 2 * CHUNK + o < total ? point_list[range.x + base + 2 * CHUNK + o] : 0u;
             cb1[q] = base + CHUNK + o < total ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
-            stage_entry<CHUNK>(geom, id0, cb0, base + o < total, X0, Y0, rec, nullptr, o);
+            stage_entry<CHUNK>(geom, id0, cb0, base + o < total, X0, Y0, rec, nullptr, o,
+                               base + o < total ? pair_mask + range.x + base + o : nullptr);
         }
         __syncthreads();
         if (__ballot(!px.done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
@@ -455,6 +486,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
                      const uint32_t *__restrict__ bwd_order,
                      const uint2 *__restrict__ bwd_items, const float *__restrict__ ckpt,
+                     const uint2 *__restrict__ pair_mask,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                      float4 *__restrict__ pair_grad, uint32_t *__restrict__ pair_valid) {
     constexpr int WIN = SLAB_WIN;
@@ -561,21 +593,23 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     }
 
     // Windows of WIN entries, back to front; window slot e <-> list position whi - 1 - e.  Surfel
-    // ids are fetched two windows ahead, cull boxes one window ahead.
+    // ids and the forward's candidate masks are fetched two windows ahead.
     uint32_t id1 = total - 1 - tid >= lo ? point_list[range.x + total - 1 - tid] : 0u;
     uint32_t id2 = total - WIN - 1 - tid >= lo ? point_list[range.x + total - WIN - 1 - tid] : 0u;
-    float4 cb1 = total - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 mk1 = total - 1 - tid >= lo ? pair_mask[range.x + total - 1 - tid] : make_uint2(0u, 0u);
+    uint2 mk2 = total - WIN - 1 - tid >= lo ? pair_mask[range.x + total - WIN - 1 - tid] : make_uint2(0u, 0u);
     int dirty = SLAB_POOL;  // pool slots that may hold data (all of them before the first round)
     for (int whi = total; whi > lo; whi -= WIN) {
         const int wcnt = min(WIN, whi - lo);
         const uint32_t id0 = id1;
-        const float4 cb0 = cb1;
+        const uint2 mk0 = mk1;
         id1 = id2;
+        mk1 = mk2;
         id2 = whi - 2 * WIN - 1 - tid >= lo ? point_list[range.x + whi - 2 * WIN - 1 - tid] : 0u;
-        cb1 = whi - WIN - 1 - tid >= lo ? cullbox[id1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mk2 = whi - 2 * WIN - 1 - tid >= lo ? pair_mask[range.x + whi - 2 * WIN - 1 - tid] : make_uint2(0u, 0u);
         __syncthreads();  // the previous window's last round is done with rec / s_id
         DBG_PHASE(whi == total ? 0 : 4);
-        if (tid < WIN) (void)stage_entry<WIN>(geom, id0, cb0, tid < wcnt, X0, Y0, rec, s_id);
+        if (tid < WIN) stage_entry_masked<WIN>(geom, id0, mk0, tid < wcnt, X0, Y0, rec, s_id, tid);
 
         // Slab rounds over the window.  An entry's slab has four slots (the 2x2 pixels) per candidate
         // block of its mask, in mask-bit order: slot = base + 4 * rank(block) + pixel-in-block with
@@ -861,7 +895,7 @@ int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float
         hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
                            (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt,
-                           out_color, out_allmap);
+                           st.pair_mask, out_color, out_allmap);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
@@ -877,7 +911,7 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
                            (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.bwd_order,
-                           st.bwd_items, st.ckpt, dL_dcolor, dL_dallmap, sc.pair_grad, sc.pair_valid);
+                           st.bwd_items, st.ckpt, st.pair_mask, dL_dcolor, dL_dallmap, sc.pair_grad, sc.pair_valid);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

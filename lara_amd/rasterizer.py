@@ -29,7 +29,7 @@ from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class _View(ctypes.Structure):
@@ -52,7 +52,7 @@ class GradLayout(ctypes.Structure):
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "pair_base", "pair_pos", "final_T", "n_contrib",
-                 "seg_base", "seg_cnt", "bwd_order", "bwd_items", "ckpt", "total")]
+                 "seg_base", "seg_cnt", "bwd_order", "bwd_items", "ckpt", "pair_mask", "total")]
 
 
 _lib = None
