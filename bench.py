@@ -178,10 +178,13 @@ def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="
                     render(rs, sc["centers"], sc["shs"], sc["opacity"], sc["scales"], sc["rotations"])
             if fine_idx is not None:
                 idx = fine_idx[i]
-                centers_f = sc["centers"][idx]                    # network.py:514
-                shs_f = sc["shs"][idx] + 0.01                     # network.py:518 (+ forward_fine's residual)
+                if api != "views":
+                    centers_f = sc["centers"][idx]                # network.py:514
+                    shs_f = sc["shs"][idx] + 0.01                 # network.py:518 (+ forward_fine's residual)
                 if api == "views":
-                    render_views(centers_f, shs_f, sc["opacity"][idx], sc["scales"][idx], sc["rotations"][idx])
+                    from lara_amd.fine import take_rows      # (the indices of a mask are unique: no sort in the backward)
+                    render_views(take_rows(sc["centers"], idx), take_rows(sc["shs"], idx) + 0.01, take_rows(sc["opacity"], idx),
+                                 take_rows(sc["scales"], idx), take_rows(sc["rotations"], idx))
                 else:
                     for rs in settings:                           # network.py:524: subset gathers per view
                         render(rs, centers_f, shs_f, sc["opacity"][idx], sc["scales"][idx], sc["rotations"][idx])

@@ -116,3 +116,18 @@ def test_hip_forward_fine_empty_and_cpu_inputs():
     assert sh.shape == (0, 1, 12)
     with pytest.raises(RuntimeError, match="no CPU path"):
         _FineDecoder.apply(torch.zeros(3, 80), torch.zeros(4, 8, 3), *[w.detach().cpu() for w in _fold_fine_weights(dec)])
+
+
+@pytest.mark.gpu
+def test_take_rows_matches_advanced_indexing():
+    from lara_amd.fine import take_rows
+    torch.manual_seed(0)
+    x = torch.randn(1000, 4, 3, device="cuda", requires_grad=True)
+    y = x.detach().clone().requires_grad_(True)
+    idx = (torch.rand(1000, device="cuda") > 0.4).nonzero().squeeze(-1)
+    g = torch.randn(idx.numel(), 4, 3, device="cuda")
+    a, b = take_rows(x, idx), y[idx]
+    assert torch.equal(a, b)
+    a.backward(g)
+    b.backward(g)
+    assert torch.equal(x.grad, y.grad)
