@@ -483,6 +483,13 @@ def render_img_leg(device, args):
         # as network.py:473-497 calls it: batched tensors [B, P, ...], a FRESH `x[i]` view object per view
         pb = {k: v.detach()[None].requires_grad_(True) for k, v in sc.items()}
         loss = 0
+        if mode == "views":     # the whole loop as ONE call (Renderer.render_views: one rasteriser node for the 8 views)
+            p = {k: v[0] for k, v in pb.items()}
+            for o in r.render_views(cams, rays, p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], device):
+                for k in keys:
+                    loss = loss + o[k].sum() * 1e-6
+            loss.backward()
+            return
         for cam, ray in zip(cams, rays):
             p = {k: v[0] for k, v in pb.items()}
             o = (r.render_img(cam, ray, p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], device)
@@ -492,7 +499,7 @@ def render_img_leg(device, args):
         loss.backward()
 
     res = {}
-    for mode in ("reference_style", "fused"):
+    for mode in ("reference_style", "fused", "views"):
         one(mode)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -502,7 +509,7 @@ def render_img_leg(device, args):
         res[mode] = round(2 * args.views / (time.perf_counter() - t0), 1)
     return {"workload": f"Renderer.render_img fwd+bwd, 1 scene x {args.views} views @{args.res}x{args.res}, gradients on all six "
                         f"returned maps, one stream", "unit": "frames/s", "reference_style_torch_postprocessing": res["reference_style"],
-            "fused_renderer": res["fused"]}
+            "fused_renderer": res["fused"], "fused_renderer_render_views": res["views"]}
 
 
 def point_feats_leg(device, args):

@@ -46,6 +46,18 @@ int lara_fine_decoder_backward(int32_t n, const float *xn, const float *pf, cons
                                const float *b1, const float *W2, const float *b2, const float *d_sh, float *d_xn,
                                float *d_pf, float *U, float *HID, float *DH, float *DT, void *stream);
 
+/* The LayerNorm in front (network.py:281, `self.norm`): rows of 80 features are too short for torch's row-per-
+ * workgroup kernels (0.55 ms forward / 0.9 ms backward for 524 288 rows); here one thread owns a row.
+ *   forward : x [n,80] -> xn [n,80] = (x - mean) * rstd * gamma + beta, stats [n,2] = (mean, rstd)   (eps as given)
+ *   backward: d_xn [n,80] -> d_x [n,80]; partials [blocks][160]: per workgroup, the sums over its rows of
+ *             d_xn * xhat (80) and d_xn (80) -- d_gamma / d_beta are their column sums (fixed order: reproducible).
+ *             `blocks` = lara_fine_ln_blocks(n). */
+int32_t lara_fine_ln_blocks(int32_t n);
+int lara_fine_ln_forward(int32_t n, const float *x, const float *gamma, const float *beta, float eps, float *xn,
+                         float *stats, void *stream);
+int lara_fine_ln_backward(int32_t n, const float *x, const float *gamma, const float *stats, const float *d_xn,
+                          float *d_x, float *partials, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,6 +253,103 @@ fine_decoder_bwd_kernel(const int n, const float *__restrict__ xn_g, const float
     }
 }
 
+
+// ---- LayerNorm over rows of 80 features, one thread per row ------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fine_ln_fwd_kernel(const int n, const float *__restrict__ x_g, const float *__restrict__ gamma, const float *__restrict__ beta,
+                   const float eps, float *__restrict__ xn_g, float2 *__restrict__ stats) {
+    __shared__ float sg[FD], sb[FD];
+    if (threadIdx.x < FD) { sg[threadIdx.x] = gamma[threadIdx.x]; sb[threadIdx.x] = beta[threadIdx.x]; }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 *x4 = (const float4 *)(x_g + i * FD);
+    float4 v[FD / 4];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < FD / 4; k++) { v[k] = x4[k]; sum += (v[k].x + v[k].y) + (v[k].z + v[k].w); }
+    const float mean = sum * (1.0f / FD);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < FD / 4; k++) {
+        const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+        var += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(var * (1.0f / FD) + eps);
+    float4 *o4 = (float4 *)(xn_g + i * FD);
+#pragma unroll
+    for (int k = 0; k < FD / 4; k++) {
+        float4 o;
+        o.x = (v[k].x - mean) * rstd * sg[4 * k] + sb[4 * k];
+        o.y = (v[k].y - mean) * rstd * sg[4 * k + 1] + sb[4 * k + 1];
+        o.z = (v[k].z - mean) * rstd * sg[4 * k + 2] + sb[4 * k + 2];
+        o.w = (v[k].w - mean) * rstd * sg[4 * k + 3] + sb[4 * k + 3];
+        o4[k] = o;
+    }
+    stats[i] = make_float2(mean, rstd);
+}
+
+// wave-wide sum in six DPP adds; the total lands in lane 63 (the shuffle-based butterfly is six LDS permutes per value:
+// with 160 values per wave the kernel was bound by them)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float x) {
+    x += dpp_term<0xB1, 0xf>(x);    // quad_perm [1,0,3,2]
+    x += dpp_term<0x4E, 0xf>(x);    // quad_perm [2,3,0,1]
+    x += dpp_term<0x141, 0xf>(x);   // row_half_mirror
+    x += dpp_term<0x140, 0xf>(x);   // row_mirror: every lane of a 16-lane row holds the row's sum
+    x += dpp_term<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+    x += dpp_term<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+__global__ void __launch_bounds__(256)
+fine_ln_bwd_kernel(const int n, const float *__restrict__ x_g, const float *__restrict__ gamma, const float2 *__restrict__ stats,
+                   const float *__restrict__ dxn_g, float *__restrict__ dx_g, float *__restrict__ partials) {
+    __shared__ float sg[FD];
+    __shared__ float part[4][2 * FD];
+    if (threadIdx.x < FD) sg[threadIdx.x] = gamma[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 xh[FD / 4], g[FD / 4];
+    float2 st = make_float2(0.f, 0.f);
+    if (on) st = stats[i];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < FD / 4; k++) {
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
+        if (on) { xv = ((const float4 *)(x_g + i * FD))[k]; dv = ((const float4 *)(dxn_g + i * FD))[k]; }
+        xh[k] = make_float4((xv.x - st.x) * st.y, (xv.y - st.x) * st.y, (xv.z - st.x) * st.y, (xv.w - st.x) * st.y);
+        // the workgroup's sums of d_xn * xhat and d_xn for d_gamma / d_beta (rows beyond n contribute zeros)
+        const float pg[4] = {dv.x * xh[k].x, dv.y * xh[k].y, dv.z * xh[k].z, dv.w * xh[k].w};
+        const float pb[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float a = wave_sum_to_lane63(pg[q]), b = wave_sum_to_lane63(pb[q]);
+            if (lane == 63) { part[wave][4 * k + q] = a; part[wave][FD + 4 * k + q] = b; }
+        }
+        g[k] = make_float4(dv.x * sg[4 * k], dv.y * sg[4 * k + 1], dv.z * sg[4 * k + 2], dv.w * sg[4 * k + 3]);
+        s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+        s2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+    }
+    if (on) {
+        const float m1 = s1 * (1.0f / FD), m2 = s2 * (1.0f / FD);
+        float4 *o4 = (float4 *)(dx_g + i * FD);
+#pragma unroll
+        for (int k = 0; k < FD / 4; k++)
+            o4[k] = make_float4(st.y * (g[k].x - m1 - xh[k].x * m2), st.y * (g[k].y - m1 - xh[k].y * m2),
+                                st.y * (g[k].z - m1 - xh[k].z * m2), st.y * (g[k].w - m1 - xh[k].w * m2));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * FD)
+        partials[(size_t)blockIdx.x * 2 * FD + threadIdx.x] =
+            ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+
 unsigned fd_grid(int n) {
     const unsigned tiles = (unsigned)((n + 255) / 256);
     return tiles < 1024u ? tiles : 1024u;
@@ -288,6 +385,38 @@ int lara_fine_decoder_backward(int32_t n, const float *xn, const float *pf, cons
         L2D_PROF("fine_decoder_bwd", s);
         hipLaunchKernelGGL(fine_decoder_bwd_kernel, dim3(fd_grid(n)), dim3(256), 0, s, n, xn, pf, Wqk, W1ov, b1, W2, b2,
                            d_sh, d_xn, d_pf, U, HID_, DH, DT);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int32_t lara_fine_ln_blocks(int32_t n) { return n <= 0 ? 0 : (n + 255) / 256; }
+
+int lara_fine_ln_forward(int32_t n, const float *x, const float *gamma, const float *beta, float eps, float *xn,
+                         float *stats, void *stream) {
+    if (n < 0) return LARA2DGS_E_INVALID;
+    if (n == 0) return LARA2DGS_OK;
+    if (!x || !gamma || !beta || !xn || !stats) return LARA2DGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        L2D_PROF("fine_ln_fwd", s);
+        hipLaunchKernelGGL(fine_ln_fwd_kernel, dim3((unsigned)lara_fine_ln_blocks(n)), dim3(256), 0, s, n, x, gamma, beta, eps, xn,
+                           (float2 *)stats);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int lara_fine_ln_backward(int32_t n, const float *x, const float *gamma, const float *stats, const float *d_xn,
+                          float *d_x, float *partials, void *stream) {
+    if (n < 0) return LARA2DGS_E_INVALID;
+    if (n == 0) return LARA2DGS_OK;
+    if (!x || !gamma || !stats || !d_xn || !d_x || !partials) return LARA2DGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        L2D_PROF("fine_ln_bwd", s);
+        hipLaunchKernelGGL(fine_ln_bwd_kernel, dim3((unsigned)lara_fine_ln_blocks(n)), dim3(256), 0, s, n, x, gamma,
+                           (const float2 *)stats, d_xn, d_x, partials);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

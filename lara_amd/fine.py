@@ -41,6 +41,12 @@ def _lib():
         lib.lara_fine_decoder_forward.argtypes = [i32] + [vp] * 9
         lib.lara_fine_decoder_backward.restype = ctypes.c_int
         lib.lara_fine_decoder_backward.argtypes = [i32] + [vp] * 15
+        lib.lara_fine_ln_blocks.restype = i32
+        lib.lara_fine_ln_blocks.argtypes = [i32]
+        lib.lara_fine_ln_forward.restype = ctypes.c_int
+        lib.lara_fine_ln_forward.argtypes = [i32, vp, vp, vp, ctypes.c_float, vp, vp, vp]
+        lib.lara_fine_ln_backward.restype = ctypes.c_int
+        lib.lara_fine_ln_backward.argtypes = [i32] + [vp] * 7
         _configured = True
     return lib
 
@@ -193,6 +199,42 @@ def _tn_over_points(a, b, chunk=1024):
     return out
 
 
+class _FineLayerNorm(torch.autograd.Function):
+    """LayerNorm over rows of 80 features, one thread per row (include/lara_finedec.h): x [n,80], gamma, beta, eps."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        if not x.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        x, gamma, beta = x.detach().float().contiguous(), gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        n = x.shape[0]
+        xn = torch.empty_like(x)
+        stats = torch.empty(n, 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _check(_lib().lara_fine_ln_forward(n, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), xn.data_ptr(),
+                                               stats.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                   "lara_fine_ln_forward")
+        ctx.save_for_backward(x, gamma, stats)
+        return xn
+
+    @staticmethod
+    def backward(ctx, d_xn):
+        x, gamma, stats = ctx.saved_tensors
+        n = x.shape[0]
+        d_xn = d_xn.float().contiguous()
+        d_x = torch.empty_like(x)
+        lib = _lib()
+        parts = torch.empty(max(lib.lara_fine_ln_blocks(n), 1), 2 * _FD, dtype=torch.float32, device=x.device)
+        if n == 0:
+            parts.zero_()
+        with torch.cuda.device(x.device):
+            _check(lib.lara_fine_ln_backward(n, x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), d_xn.data_ptr(), d_x.data_ptr(),
+                                             parts.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                   "lara_fine_ln_backward")
+        tot = parts.sum(0)
+        return d_x, tot[:_FD], tot[_FD:], None
+
+
 def _fold_fine_weights(decoder):
     """The folded matrices of include/lara_finedec.h, formed WITH autograd from the reference Decoder's parameters
     (network.py:234-240), in fp32."""
@@ -219,8 +261,7 @@ def forward_fine(decoder, volume_feat, point_feats):
     its storage is used as it is) -> sh [n,1,12] fp32."""
     if point_feats.dim() != 3 or point_feats.shape[1:] != (_NV, _CD) or volume_feat.shape[-1] != _FD:
         raise RuntimeError("expected volume_feat [n,80] and point_feats [n,4,8]")
-    xn = torch.nn.functional.layer_norm(volume_feat.float(), (_FD,), decoder.norm.weight.float(), decoder.norm.bias.float(),
-                                        decoder.norm.eps)
+    xn = _FineLayerNorm.apply(volume_feat.float(), decoder.norm.weight, decoder.norm.bias, decoder.norm.eps)
     pf = point_feats.float().permute(1, 2, 0)      # [4,8,n]; contiguous() is a no-op on the sampler's own layout
     sh = _FineDecoder.apply(xn, pf, *_fold_fine_weights(decoder))
     return sh.unsqueeze(1)
