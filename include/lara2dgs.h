@@ -80,8 +80,9 @@ typedef struct lara2dgs_state_layout {
     int64_t tile_order;  /* uint32[tiles]: tile ids sorted by list length, longest first: the composite
                           * kernels' workgroup -> tile map (load balance across the 256 CUs) */
     int64_t pair_base;   /* uint32[P+1]: first (tile, surfel) pair of each surfel, surfel-major order */
-    int64_t pair_pos;    /* uint32[capacity]: surfel-major pair index -> position in point_list; lets the
-                          * backward gather per-surfel gradients deterministically, without atomics */
+    int64_t pair_pos;    /* uint32[capacity]: position in point_list -> the (tile, surfel) pair's index in surfel-major
+                          * numbering (pair_base[id] + tile offset); the backward writes its per-pair gradient rows
+                          * there, so that a surfel's rows are contiguous and summed without atomics */
     int64_t final_T;     /* float[10][H][W]: end-of-walk T, M1, M2, colour(3), depth, normal(3) sums */
     int64_t n_contrib;   /* uint32[2][H][W]: last contributor, median contributor */
     int64_t seg_base;    /* uint32[tiles+1]: exclusive scan of floor((len-1)/512) = interior boundaries when a

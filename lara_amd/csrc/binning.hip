@@ -401,7 +401,8 @@ __device__ __forceinline__ void block_sort(uint64_t (&x)[E], uint64_t *lds) {
     }
 }
 
-// where (surfel id, this tile) sits in the surfel-major pair numbering
+// where (surfel id, this tile) sits in the surfel-major pair numbering: recorded per list position, so that the
+// backward can write its gradient rows surfel-major (a surfel's rows contiguous: preprocess_bwd streams them)
 struct PairMap {
     const uint4 *rect;
     const uint32_t *pair_base;
@@ -411,7 +412,7 @@ struct PairMap {
     __device__ __forceinline__ void put(const uint32_t id, const uint32_t i) const {
         const uint4 r = rect[id];
         const int rx0 = r.x & 0xffff, ry0 = r.x >> 16, rx1 = r.y & 0xffff;
-        pair_pos[pair_base[id] + (uint32_t)((ty - ry0) * (rx1 - rx0) + (tx - rx0))] = first + i;
+        pair_pos[first + i] = pair_base[id] + (uint32_t)((ty - ry0) * (rx1 - rx0) + (tx - rx0));
     }
 };
 

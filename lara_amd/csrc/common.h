@@ -36,7 +36,7 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     uint2 *ranges;        // [tiles]
     uint32_t *tile_order; // [tiles] tile ids, longest list first (work-balanced launch order)
     uint32_t *pair_base;  // [P+1] first pair index of each surfel (exclusive scan of tiles touched)
-    uint32_t *pair_pos;   // [cap] pair index (surfel-major) -> position in the sorted list
+    uint32_t *pair_pos;   // [cap] position in the sorted list -> pair index in surfel-major numbering
     float *final_T;       // [L2D_CKPT_F][HW] end-of-walk T, M1, M2, C(3), D, N(3)
     uint32_t *n_contrib;  // [2][HW]
     uint32_t *seg_base;   // [tiles+1] exclusive scan of interior segment boundaries per tile
@@ -56,8 +56,8 @@ struct ScratchView {
     uint4 *rect;           // [P] tile rectangle (4 x u16 in .x,.y) + depth bits (.z)
     uint64_t *keys;        // [cap]  (depth bits << 32) | surfel id, grouped per tile, unsorted
     uint32_t *block_tot;   // [ceil(P/256)] pairs per surfel block, then (in place) their exclusive scan
-    float4 *pair_grad;     // [cap][5] backward: per (tile, surfel) gradient rows (aliases the forward region)
-    uint32_t *pair_valid;  // [cap/32] backward: bit p set <=> row p was written
+    float4 *pair_grad;     // [cap][5] backward: per (tile, surfel) gradient rows, surfel-major (aliases the forward region)
+    uint32_t *pair_valid;  // [cap] bytes, backward: byte q != 0 <=> gradient row q (surfel-major) was written
 };
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -106,7 +106,7 @@ static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayou
     const int64_t fwd_end = o;
     L->pair_grad = fwd0;  // backward reuses the forward-only region
     L->pair_valid = align_up(fwd0 + cap * GRAD_F * 4, 256);
-    const int64_t bwd_end = align_up(L->pair_valid + (cap / 32 + 2) * 4, 256);
+    const int64_t bwd_end = align_up(L->pair_valid + cap + 256, 256);
     L->total = fwd_end > bwd_end ? fwd_end : bwd_end;
 }
 

@@ -497,7 +497,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint2 *__restrict__ bwd_items, const float *__restrict__ ckpt,
                      const uint2 *__restrict__ pair_mask,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
-                     float4 *__restrict__ pair_grad, uint32_t *__restrict__ pair_valid) {
+                     const uint32_t *__restrict__ pair_pos,
+                     float4 *__restrict__ pair_grad, uint8_t *__restrict__ pair_valid) {
     constexpr int WIN = SLAB_WIN;
     __shared__ float4 rec[REC4 * WIN];
     __shared__ __attribute__((aligned(16))) float pool[SLAB_POOL * SLAB_F];
@@ -839,30 +840,17 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     for (int i = 0; i < 3; i++) dl0[i] = t1[i] + t2[i];
                     cross3(l0, b, t1); cross3(cc, k0, t2);
                     for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + g[9 + i];
-                    // one 80-byte gradient row per touched (tile, surfel) pair, written exactly once; a
-                    // bitmap marks the rows that exist; preprocess_bwd sums each surfel's rows
-                    float4 *row = pair_grad + (size_t)p * (GRAD_F / 4);
+                    // one 80-byte gradient row per touched (tile, surfel) pair, written exactly once, at the pair's
+                    // SURFEL-MAJOR index (pair_pos[p], recorded by the sort): a surfel's rows are contiguous and
+                    // preprocess_bwd streams them; a byte per pair marks the rows that exist
+                    const uint32_t q = pair_pos[p];
+                    float4 *row = pair_grad + (size_t)q * (GRAD_F / 4);
                     row[0] = make_float4(-dk0[0], -dk0[1], -dk0[2], -dl0[0]);
                     row[1] = make_float4(-dl0[1], -dl0[2], dTw[0], dTw[1]);
                     row[2] = make_float4(dTw[2], g[12], g[13], g[14]);
                     row[3] = make_float4(g[15], g[16], g[17], g[18]);
                     row[4] = make_float4(g[19], g[20], 0.f, 0.f);
-                }
-                // publish the wave's 32 validity bits (consecutive list positions) with <= 2 atomic ORs
-                {
-                    const unsigned long long bal = __ballot(touched);
-                    const uint32_t m32 = (uint32_t)__ballot(lane < 32 && ((bal >> (2 * (lane & 31))) & 1ull));
-                    if (m32) {
-                        // entry k of the wave sits at list position p0 - k: bit-reverse so that bits ascend with p
-                        const long long p_lo = (long long)range.x + (whi - 1 - s0 - 32 * wave) - 31;
-                        unsigned long long bits = (unsigned long long)__builtin_bitreverse32(m32);
-                        long long pb = p_lo;
-                        if (pb < 0) { bits >>= (unsigned)(-pb); pb = 0; }
-                        bits <<= (unsigned)(pb & 31);
-                        const uint32_t w0 = (uint32_t)(pb >> 5);
-                        if (lane == 0 && (uint32_t)bits) atomicOr(&pair_valid[w0], (uint32_t)bits);
-                        if (lane == 1 && (uint32_t)(bits >> 32)) atomicOr(&pair_valid[w0 + 1], (uint32_t)(bits >> 32));
-                    }
+                    pair_valid[q] = 1;
                 }
             }
             s0 += nfit;
@@ -922,7 +910,8 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
                            (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.bwd_order,
-                           st.bwd_items, st.ckpt, st.pair_mask, dL_dcolor, dL_dallmap, sc.pair_grad, sc.pair_valid);
+                           st.bwd_items, st.ckpt, st.pair_mask, dL_dcolor, dL_dallmap, st.pair_pos, sc.pair_grad,
+                           (uint8_t *)sc.pair_valid);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

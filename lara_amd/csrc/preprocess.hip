@@ -331,8 +331,8 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
                       const float *__restrict__ colors_precomp, const float2 *__restrict__ scales,
                       const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
                       const int32_t *__restrict__ radii, const float4 *__restrict__ geom,
-                      const uint32_t *__restrict__ pair_base, const uint32_t *__restrict__ pair_pos,
-                      const float4 *__restrict__ pair_grad, const uint32_t *__restrict__ pair_valid,
+                      const uint32_t *__restrict__ pair_base,
+                      const float4 *__restrict__ pair_grad, const uint8_t *__restrict__ pair_valid,
                       float *__restrict__ dL_dmeans3D,
                       float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
                       float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
@@ -348,10 +348,9 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     for (int k = 0; k < GRAD_F; k++) gacc[k] = 0.f;
     if (visible) {
         const uint32_t q0 = pair_base[idx], q1 = pair_base[idx + 1];
-        for (uint32_t q = q0; q < q1; q++) {
-            const uint32_t pp = pair_pos[q];
-            if (!((pair_valid[pp >> 5] >> (pp & 31u)) & 1u)) continue;  // no pixel used this pair
-            const float4 *row = pair_grad + (size_t)pp * (GRAD_F / 4);
+        for (uint32_t q = q0; q < q1; q++) {     // the surfel's rows are contiguous (written surfel-major by composite_bwd)
+            if (!pair_valid[q]) continue;        // no pixel used this pair
+            const float4 *row = pair_grad + (size_t)q * (GRAD_F / 4);
 #pragma unroll
             for (int k = 0; k < GRAD_F / 4; k++) {
                 const float4 w4 = row[k];
@@ -565,7 +564,7 @@ int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *s
     hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, v, means3D, shs,           \
                        colors_precomp, (const float2 *)scales, (const float4 *)rotations,        \
                        transmat_precomp, radii, (const float4 *)st.geom, st.pair_base,           \
-                       st.pair_pos, (const float4 *)sc.pair_grad, sc.pair_valid,                 \
+                       (const float4 *)sc.pair_grad, (const uint8_t *)sc.pair_valid,                 \
                        dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities,             \
                        (float2 *)dL_dscales, (float4 *)dL_drotations, dL_dtransmat)
     {
