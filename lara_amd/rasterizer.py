@@ -612,6 +612,7 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
         seg_cnt=sec(L.seg_cnt, tiles * 4, torch.int32, (tiles,)),
         bwd_order=sec(L.bwd_order, tiles * 4, torch.int32, (tiles,)),
         bwd_items=sec(L.bwd_items, (cap // 512 + 1) * 8, torch.int32, (cap // 512 + 1, 2)),
+        pair_mask=sec(L.pair_mask, cap * 8, torch.int64, (cap,)),
     )
 
 
