@@ -10,10 +10,11 @@ stated fp tolerance.  Tolerances used here and why:
     of 1/255, or a pixel whose T sits within an ulp of 1e-4, may be taken on one side and skipped on
     the other; such a flip moves a pixel by <= 1/255 * T.  So: max |diff| <= 5e-3 everywhere,
     99.9 % of pixels within 2e-5, PSNR >= 70 dB; n_contrib equal on >= 99.9 % of pixels.
-  * gradients: fp32 sums (fixed order) vs double accumulation in the oracle ->
-    max |diff| <= 2e-3 * max |ref| per tensor at training-size images (measured 1e-6 .. 3e-4 for
-    opacity / SH, 2e-4 .. 4e-4 for means / scales / rotations at 128 px; the maxima come from a few
-    steeply inclined splats whose alpha is ill-conditioned in fp32 -- see the 1024 px test).
+  * gradients: fp32 sums (fixed order) vs double accumulation in the oracle -> ONE bar for every test
+    (`_within_gradient_bar`): relative to max |ref| of the tensor, every entry within 1e-2, all but max(2, 1e-4 of
+    the entries) within 2e-3, relative L2 <= 2e-3 (measured maxima 1e-6 .. 3e-4 for opacity / SH, 2e-4 .. 4.5e-3 for
+    means / scales / rotations; the maxima come from a few steeply inclined splats whose alpha is ill-conditioned in
+    fp32 -- see the 1024 px test).  The full-size scene has its own yardstick, the oracle's one-ulp conditioning.
 """
 import numpy as np
 import pytest
@@ -149,7 +150,23 @@ def test_forward_sh_degrees(hip_lib, deg):
     _check_forward(r, ref, 96, 96)
 
 
-def _grad_check(act, cam, bg, sh_degree=1, seed=11, tol=2e-3):
+def _within_gradient_bar(got, want, name):
+    """THE gradient bar, the same in every test of this file: relative to max|ref| of the tensor,
+    every entry within 1e-2, all but max(2, 1e-4 of the entries) within 2e-3, and the tensor's relative L2 error
+    <= 2e-3.  (The allowance is for the handful of large, steeply inclined surfels whose alpha is ill-conditioned in
+    fp32 -- see test_forward_backward_1024_eval_resolution; measured maxima 1e-6 .. 4.5e-3.)"""
+    ref_max = np.abs(want).max() + 1e-20
+    err = np.abs(got - want) / ref_max
+    worst = float(err.max())
+    assert worst <= 1e-2, f"grad {name}: rel-to-max err {worst:.3e}"
+    over = int((err > 2e-3).sum())
+    assert over <= max(2, int(1e-4 * err.size)), f"grad {name}: {over} of {err.size} entries beyond 2e-3 of max (worst {worst:.3e})"
+    l2 = float(np.linalg.norm((got - want).ravel()) / (np.linalg.norm(want.ravel()) + 1e-20))
+    assert l2 <= 2e-3, f"grad {name}: relative L2 {l2:.3e}"
+    return worst
+
+
+def _grad_check(act, cam, bg, sh_degree=1, seed=11):
     from lara_amd import GaussianRasterizer
     rs = raster_settings(cam, bg, sh_degree=sh_degree, device=DEV)
     inp = {k: v.to(DEV).requires_grad_(True) for k, v in act.items()}
@@ -168,12 +185,8 @@ def _grad_check(act, cam, bg, sh_degree=1, seed=11, tol=2e-3):
     for name in ("means3D", "opacities", "scales", "rotations", "shs"):
         got = inp[name].grad.cpu().numpy().reshape(gref[name].shape)
         assert np.isfinite(got).all()
-        err = np.abs(got - gref[name]).max() / (np.abs(gref[name]).max() + 1e-20)
-        out[name] = err
-        assert err <= tol, f"grad {name}: rel-to-max err {err:.3e}"
-    got2d = means2D.grad.cpu().numpy()
-    err = np.abs(got2d - gref["means2D"]).max() / (np.abs(gref["means2D"]).max() + 1e-20)
-    assert err <= tol, f"grad means2D: {err:.3e}"
+        out[name] = _within_gradient_bar(got, gref[name], name)
+    _within_gradient_bar(means2D.grad.cpu().numpy(), gref["means2D"], "means2D")
     return out
 
 
@@ -195,9 +208,9 @@ def test_backward_big_splats_low_pass_and_sh3(hip_lib):
 def test_backward_sh_degrees(hip_lib, deg):
     act, cams = small_scene(grid=10, size=96, seed=20 + deg, sh_coeffs=16)
     cam, bg = cams[3], (0.0, 0.0, 0.0)
-    # 4e-3: this scene contains steeply inclined splats (see test_forward_backward_1024_eval_resolution for
-    # the fp32 conditioning of their alpha); scales land at 2.1e-3 of max|grad| for one seed
-    _grad_check(act, cam, bg, sh_degree=deg, tol=4e-3)
+    # (this scene contains steeply inclined splats -- see test_forward_backward_1024_eval_resolution for the fp32
+    # conditioning of their alpha: one entry of `scales` lands at 2.1e-3 of max|grad| for one seed)
+    _grad_check(act, cam, bg, sh_degree=deg)
 
 
 def test_backward_is_bit_reproducible(hip_lib):
@@ -238,7 +251,7 @@ def test_forward_backward_1024_eval_resolution(hip_lib):
     # 4e-4 at 128 px, 2e-3 at 512 px, 4.5e-3 at 1024 px for this scene (the footprints grow with the
     # image); the median surfel is at 1e-8.  Culling, segmentation and the slab parameters were varied
     # and leave these numbers unchanged to the digit.
-    _grad_check(act, cam, bg, tol=1e-2)
+    _grad_check(act, cam, bg)
 
 
 def test_backward_ragged_image(hip_lib):
