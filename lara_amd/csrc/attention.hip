@@ -37,6 +37,31 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
     if (!x || !cond_bf16 || !ln_weight || !ln_bias || !wq || !wkv || !wo || !y || !workspace)
         return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    {
+        // Experiment knob (default off): LayerNorm + Q projection + attention + output projection + residual as ONE
+        // wave-private kernel (group_attn_fused_kernel).  Same results; measured 237 us against the 190 us of the four
+        // launches it replaces at 4 scenes -- a wave's serial chain (LayerNorm, 16 L2 round trips for the weight
+        // tiles, attention, epilogue) at 1.5 waves per SIMD is latency-bound.  DESIGN.md section 3.3.
+        static const bool fused = getenv("LARA_GA_FUSED") && atoi(getenv("LARA_GA_FUSED")) != 0;
+        if (fused) {
+            unsigned short *kvf = (unsigned short *)workspace + (size_t)G * 8 * 256 * 2;
+            {
+                L2D_PROF("ga_gemm_kv", s);
+                GemmP p{};
+                p.A = cond_bf16; p.W = wkv; p.C = kvf; p.M = G * 4; p.N = 512; p.K = cond_dim;
+                if (launch_gemm_ring<0, 0>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+            }
+            L2D_CHECK_LAUNCH();
+            {
+                L2D_PROF("ga_fused", s);
+                const int units = (G + 3) / 4;
+                hipLaunchKernelGGL(group_attn_fused_kernel, dim3((units + 1) / 2), dim3(128), 0, s, x, ln_weight, ln_bias, eps,
+                                   wq, kvf, wo, y, G);
+            }
+            L2D_CHECK_LAUNCH();
+            return LARA2DGS_OK;
+        }
+    }
     unsigned short *xn = (unsigned short *)workspace;
     unsigned short *q = xn + (size_t)G * 8 * 256;
     unsigned short *kv = q + (size_t)G * 8 * 256;
