@@ -89,3 +89,27 @@ def test_ragged_group_count_and_larger_batch(hip_lib):
             ref = restated(norm1, mha, x, cond)
         d = (y - ref).abs()
         assert float(d.max()) <= 4e-2 and float(d.mean()) <= 4e-3, (G, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
+def test_fused_wave_private_kernel_is_parity_green(hip_lib):
+    """The experiment knob LARA_GA_FUSED=1 (one wave-private kernel for LayerNorm, Q projection, attention, output
+    projection + residual) is read once per process: run the same checks in a child."""
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_groupatt import build_modules, restated\n"
+        "from lara_amd.attention import GroupCrossAttention\n"
+        "norm1, mha = build_modules(7); g = torch.Generator().manual_seed(8)\n"
+        "for G in (1, 7, 130, 4096):\n"
+        "    x = torch.randn(G, 8, 256, generator=g); cond = torch.randn(G, 4, 800, generator=g)\n"
+        "    mod = GroupCrossAttention.from_modules(norm1, mha).to('cuda:0')\n"
+        "    with torch.no_grad():\n"
+        "        y = mod(x.cuda(), cond.cuda()).cpu(); ref = restated(norm1, mha, x, cond)\n"
+        "    d = (y - ref).abs()\n"
+        "    assert float(d.max()) <= 4e-2 and float(d.mean()) <= 4e-3, (G, float(d.max()), float(d.mean()))\n"
+        "print('fused ok')\n" % (HERE, os.path.dirname(HERE)))
+    env = dict(os.environ, LARA_GA_FUSED="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fused ok" in out.stdout, out.stdout + out.stderr
