@@ -67,8 +67,8 @@ class TSDFVolume:
         the camera's field of view, depth zeroed where acc_map < alpha_thres, colour quantised to 8 bits."""
         H, W = int(cam.image_height), int(cam.image_width)
         K = torch.tensor([[W / (2 * math.tan(cam.FoVx / 2.0)), H / (2 * math.tan(cam.FoVy / 2.0)), W / 2, H / 2]])
-        depth = render_pkg["depth"].detach().reshape(1, H, W).clone()
-        depth[render_pkg["acc_map"].detach().reshape(1, H, W) < alpha_thres] = 0
+        depth = render_pkg["depth"].detach().reshape(1, H, W)
+        depth = torch.where(render_pkg["acc_map"].detach().reshape(1, H, W) < alpha_thres, torch.zeros_like(depth), depth)
         color = (render_pkg["image"].detach().reshape(1, H, W, 3) * 255).to(torch.uint8).float()
         self.integrate(depth, color, K, cam.world_view_transform.T.reshape(1, 4, 4), depth_trunc)
 
