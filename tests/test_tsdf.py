@@ -83,3 +83,33 @@ def test_hip_tsdf_argument_errors():
     vol = TSDFVolume((0, 0, 0), 0.1, 0.2, 8)
     with pytest.raises(RuntimeError, match="expected depth"):
         vol.integrate(torch.zeros(2, 4, 4), torch.zeros(2, 4, 4, 3), torch.zeros(1, 4), torch.zeros(2, 4, 4), 10.0)
+
+
+@pytest.mark.gpu
+def test_integrate_render_prepares_a_view_as_the_mesh_extractor_does():
+    """`integrate_render` = tools/meshExtractor.py:76-108 for one rendered view: pinhole intrinsics from the camera's
+    field of view, depth zeroed where acc_map < alpha_thres, colour quantised to 8 bits, extrinsic = world_view^T."""
+    from lara_amd import cameras
+    from lara_amd.tsdf import TSDFVolume
+    H = W = 64
+    cam = cameras.make_cameras(cameras.turntable_c2w(4)[1:2], W, H, 0.75, 0.75, 0.5, 2.5, device="cuda")[0]
+    g = torch.Generator().manual_seed(3)
+    depth = 1.2 + 0.8 * torch.rand(H, W, 1, generator=g)
+    acc = torch.rand(H, W, generator=g)
+    img = torch.rand(H, W, 3, generator=g)
+    pkg = {"depth": depth.cuda(), "acc_map": acc.cuda(), "image": img.cuda()}
+    res, vl = 32, 1.0 / 32
+    vol = TSDFVolume((-0.5, -0.5, -0.5), vl, 3 * vl, res)
+    vol.integrate_render(cam, pkg, alpha_thres=0.3, depth_trunc=10.0)
+    torch.cuda.synchronize()
+    f = W / (2 * math.tan(0.75 / 2))
+    K = np.array([[f, f, W / 2, H / 2]], np.float32)
+    E = cam.world_view_transform.T.cpu().numpy().reshape(1, 4, 4)
+    d = depth.numpy().reshape(1, H, W).copy()
+    d[acc.numpy().reshape(1, H, W) < 0.3] = 0
+    c = np.floor(img.numpy().reshape(1, H, W, 3) * 255).astype(np.uint8).astype(np.float32)
+    rt, rw, rc = tsdf_ref.integrate(res, (-0.5, -0.5, -0.5), vl, 3 * vl, d, c, K, E, np.array([10.0], np.float32))
+    np.testing.assert_array_equal(vol.weight.cpu().numpy(), rw)
+    assert np.abs(vol.tsdf.cpu().numpy() - rt).max() <= 1e-6
+    assert np.abs(vol.rgb.cpu().numpy() - rc).max() <= 1e-3
+    assert (rw > 0).sum() > 50
