@@ -30,7 +30,7 @@ composite kernels end in a tail of a few heavy tiles; a second stream fills thos
 Extra objects on the JSON line (rank 0, N = 1): "roofline" (dominant kernel, HIP-event timed, algorithmic bytes of
 SURVEY.md section 8d; `bound` says what binds it), "cpu_baseline" (the CPU oracle of the raster AND the fixture-pinned
 fp32 restatement of the reference's encoder, both on this box's host cores), "raster_only", "single_stream",
-"forward_only", "attention", "encoder", "encoder_train", "rays", "render_img", "point_feats".
+"forward_only", "attention", "encoder", "encoder_train", "rays", "render_img", "point_feats", "fine_decoder", "fine_stage".
 """
 import argparse
 import contextlib
@@ -627,6 +627,123 @@ def fine_decoder_leg(device):
             "fwd_kernel_TFLOPs_f32": round(flop / (k.get("fine_decoder_fwd", 1e9) * 1e-6) / 1e12, 1) if "fine_decoder_fwd" in k else None}
 
 
+def fine_stage_leg(device, args):
+    """One scene through LaRa's whole render section after `start_fine` (network.py:486-527): 8 coarse views ->
+    `get_point_feats` on the 4 input views -> `Decoder.forward_fine` -> 8 fine views over the opacity > 0.005 subset,
+    forward + backward with gradients on image / depth / normal maps of all 16 frames:
+      (a) reference style -- the reference's sequence of torch operators around the drop-in rasteriser (one call per
+          view, torch post-processing, torch sampler, torch modules of the fine decoder, boolean-mask gathers per view);
+      (b) every opt-in of this repository -- `Renderer.render_views`, `fine.sample_point_feats`, `fine.forward_fine`,
+          `fine.take_rows`.
+    What a LaRa training step spends per scene on rows R0-R11 + section 8f-2/8f-4, as frames/s (16 frames per scene)."""
+    import torch.nn.functional as F
+    from torch import nn
+    from lara_amd import batch, cameras, synthetic
+    from lara_amd.fine import forward_fine, sample_point_feats, take_rows
+    from lara_amd.renderer import Renderer
+
+    class Dec(nn.Module):       # the reference's declarations, network.py:234-240
+        def __init__(self):
+            super().__init__()
+            self.norm = nn.LayerNorm(80)
+            self.cross_att = nn.MultiheadAttention(embed_dim=80, num_heads=8, kdim=8, vdim=8, dropout=0.0, bias=False, batch_first=True)
+            self.mlp_fine = nn.Sequential(nn.Linear(80, 64), nn.ReLU(), nn.Linear(64, 12))
+
+        def forward_fine(self, volume_feat, point_feats):
+            volume_feat = self.norm(volume_feat.unsqueeze(1))
+            x = self.cross_att(volume_feat, point_feats, point_feats, need_weights=False)[0]
+            return self.mlp_fine(x).float()
+
+    torch.manual_seed(1)
+    dec = Dec().to(device)
+    V, res, nsel = args.views, args.res, 4
+    sc = synthetic.make_scene(grid=args.grid, K=2, regime=args.regime, seed=321, device=device)
+    P = sc["centers"].shape[0]
+    c2w = cameras.turntable_c2w(V).to(device)
+    cams = cameras.make_cameras(c2w, res, res, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8, device=device)
+    ixt = batch.fov_to_ixt(torch.tensor([0.75, 0.75], device=device), (res, res)).reshape(1, 3, 3).expand(V, 3, 3).contiguous()
+    rays = batch.build_rays(c2w, ixt, res, res)
+    w2c = torch.linalg.inv(c2w.double()).float()
+    img_ref = torch.rand(nsel, 3, res, res, device=device)
+    vol_feat0 = torch.randn(P, 80, device=device) * 0.5
+    keys = ("image", "depth", "rend_normal")
+    r = Renderer(sh_degree=1, white_background=True)
+    mask = torch.sigmoid(sc["opacity"].detach()).squeeze(-1) > FINE_OPACITY
+    idx = mask.nonzero().squeeze(-1)
+
+    def ref_view(cam, ray, centers, shs, opacity, scales, rotations):     # renderer_2dgs.py:181-268 as torch operators
+        rast = r.set_rasterizer(cam, device=device)
+        sp = torch.zeros_like(centers, requires_grad=True) + 0
+        col, _, allmap = rast(means3D=centers, means2D=sp, shs=shs, opacities=torch.sigmoid(opacity), scales=torch.exp(scales),
+                              rotations=F.normalize(rotations), cov3D_precomp=None)
+        image = col.clamp(0, 1)
+        alpha = allmap[1:2]
+        normal = (allmap[2:5].permute(1, 2, 0) @ (cam.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+        expected = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
+        return {"image": image.permute(1, 2, 0), "depth": expected.permute(1, 2, 0), "acc_map": alpha.squeeze(0),
+                "rend_normal": normal.permute(1, 2, 0)}
+
+    def ref_sampler(points, image, acc, depth):                            # network.py:390-411
+        pc = points.reshape(1, -1, 3) @ w2c[:nsel, :3, :3].permute(0, 2, 1) + w2c[:nsel, :3, 3][:, None]
+        q = pc @ ixt[:nsel].permute(0, 2, 1)
+        xy, z = q[..., :2] / q[..., -1:], q[..., -1:]
+        grid = (xy + 0.5) / torch.tensor([res, res], device=device) * 2 - 1.0
+        stack = torch.cat((img_ref, torch.einsum('bhwc->bchw', torch.cat((image, acc.unsqueeze(-1), depth), dim=-1))), dim=1)
+        n = points.shape[0]
+        feats = F.grid_sample(stack, grid.unsqueeze(1), align_corners=False).view(nsel, -1, n)
+        return torch.cat((feats[:, :-1], (feats[:, -1:] - z.view(nsel, -1, n)).abs()), dim=1)
+
+    def one(opt_in):
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in sc.items()}
+        vol_feat = vol_feat0.clone().requires_grad_(True)
+        loss = 0
+        if opt_in:
+            coarse = r.render_views(cams, rays, p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], device)
+        else:
+            coarse = [ref_view(cam, ray, p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"]) for cam, ray in zip(cams, rays)]
+        for o in coarse:
+            for k in keys:
+                loss = loss + o[k].sum() * 1e-6
+        ren = {k: torch.stack([o[k] for o in coarse[:nsel]]) for k in ("image", "acc_map", "depth")}
+        if opt_in:
+            centers_f = take_rows(p["centers"], idx)
+            pf = sample_point_feats(centers_f, w2c[:nsel], ixt[:nsel], img_ref, ren["image"], ren["acc_map"], ren["depth"])
+            sh_res = forward_fine(dec, take_rows(vol_feat, idx), torch.einsum('lcb->blc', pf))
+            shs_f = sh_res.view(-1, 4, 3) + take_rows(p["shs"], idx)
+            fine = r.render_views(cams, rays, centers_f, shs_f, take_rows(p["opacity"], idx), take_rows(p["scales"], idx),
+                                  take_rows(p["rotations"], idx), device)
+        else:
+            centers_f = p["centers"][mask]
+            pf = torch.einsum('lcb->blc', ref_sampler(centers_f, ren["image"], ren["acc_map"], ren["depth"]))
+            vf = vol_feat[mask]
+            with torch.autocast("cuda", dtype=torch.bfloat16):     # the reference trains under bf16-mixed
+                sh_res = torch.cat([dec.forward_fine(a, b) for a, b in zip(vf.split(32768), pf.split(32768))])
+            shs_f = sh_res.view(-1, 4, 3) + p["shs"][mask]
+            fine = [ref_view(cam, ray, centers_f, shs_f, p["opacity"][mask], p["scales"][mask], p["rotations"][mask])
+                    for cam, ray in zip(cams, rays)]
+        for o in fine:
+            for k in keys:
+                loss = loss + o[k].sum() * 1e-6
+        loss.backward()
+        for q in dec.parameters():
+            q.grad = None
+
+    res_ = {}
+    for opt_in in (False, True):
+        one(opt_in)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            one(opt_in)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        res_[opt_in] = (round(2 * V / dt, 1), round(1e3 * dt, 2))
+    return {"workload": f"one scene through the render section after start_fine: {V} coarse views, point sampler on {nsel} views, "
+                        f"forward_fine on {int(idx.numel())} points, {V} fine views, forward + backward; one stream",
+            "unit": "frames/s", "reference_style_torch_operators": res_[False][0], "ms_per_scene_reference_style": res_[False][1],
+            "all_opt_ins": res_[True][0], "ms_per_scene_all_opt_ins": res_[True][1]}
+
+
 def rays_leg(device, scenes, views, res):
     """Device-side generation of the step's tar_rays + tar_rays_down (dataLoader/utils.py:21-34):
     a pure store stream, priced against the HBM peak."""
@@ -985,6 +1102,7 @@ def main():
         out["render_img"] = render_img_leg(device, args)
         out["point_feats"] = point_feats_leg(device, args)
         out["fine_decoder"] = fine_decoder_leg(device)
+        out["fine_stage"] = fine_stage_leg(device, args)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
         out["cpu_baseline"]["encoder"] = cpu_encoder_baseline()
