@@ -147,8 +147,10 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
  * sum, so the library deals them round-robin to LARA2DGS_VIEW_STREAMS lanes (default 2: more streams than the
  * device's 4 hardware queues alias and serialise again): lane 0 is `stream` itself, the others are side streams the
  * library keeps per caller stream, forked from and joined back into `stream` with events, no host synchronisation.
- * The composite kernels end in a tail of a few heavy tiles that the other lane's kernels fill.  `scratch` holds n_scratch transient buffers of
- * scratch_stride bytes each (>= lara2dgs_scratch_bytes); n_scratch bounds the number of views in flight. */
+ * The composite kernels end in a tail of a few heavy tiles that the other lane's kernels fill.  `scratch` holds
+ * n_scratch transient buffers of scratch_stride bytes each (>= lara2dgs_scratch_bytes); n_scratch bounds the number of views in flight.  With
+ * n_scratch >= n_views the per-surfel preprocess of ALL cameras is ONE launch (camera = fast index of the workgroup id:
+ * the surfels' inputs are read from HBM once), and the lanes run binning + composite only. */
 int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                            const float *shs, const float *colors_precomp, const float *opacities,
                            const float *scales, const float *rotations, const float *transmat_precomp,

@@ -367,15 +367,50 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
     if (lanes > n_scratch) lanes = n_scratch;
     auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
     const int64_t HW = (int64_t)v0.image_height * v0.image_width;
-    if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
-    for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
     int rc = LARA2DGS_OK;
-    for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
-        const int k = i % lanes;  // views on one lane are serialised: they share that lane's scratch
-        rc = lara2dgs_forward(&views[i], means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp,
-                              out_color + i * 3 * HW, out_allmap + i * 7 * HW,
-                              out_radii ? out_radii + (int64_t)i * v0.P : nullptr,
-                              (char *)state + i * state_stride, (char *)scratch + k * scratch_stride, lane_stream(k));
+    // With a scratch buffer per view the preprocess of ALL cameras is one launch on the caller's stream (the surfels'
+    // inputs are read from HBM once for the n cameras); the lanes then only run binning + composite of their views.
+    const bool batched = n_scratch >= n_views && v0.P > 0;
+    if (batched) {
+        if (!out_color || !out_allmap || !means3D || !opacities || !out_radii) return LARA2DGS_E_INVALID;
+        if ((shs == nullptr) == (colors_precomp == nullptr)) return LARA2DGS_E_INVALID;
+        if ((scales && rotations) == (transmat_precomp != nullptr)) return LARA2DGS_E_INVALID;
+        std::vector<ViewDev> vd(n_views);
+        std::vector<StateView> st(n_views);
+        std::vector<ScratchView> sc(n_views);
+        std::vector<int32_t *> rad(n_views);
+        for (int i = 0; i < n_views; i++) {
+            if (!make_view(&views[i], vd[i])) return LARA2DGS_E_INVALID;
+            if (shs && vd[i].M < (vd[i].deg + 1) * (vd[i].deg + 1)) return LARA2DGS_E_INVALID;
+            st[i] = carve_state(vd[i], (char *)state + i * state_stride);
+            ScratchLayout SL;
+            sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL);
+            rad[i] = out_radii + (int64_t)i * v0.P;
+            HIP_TRY(hipMemsetAsync(sc[i].tile_count, 0, (size_t)(SL.sub_start - SL.tile_count), caller));
+        }
+        for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
+            const int nb = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
+            rc = launch_preprocess_fwd_views(vd[i0], nb, &vd[i0], means3D, shs, colors_precomp, opacities, scales, rotations,
+                                             transmat_precomp, &st[i0], &sc[i0], &rad[i0], caller);
+        }
+        if (rc != LARA2DGS_OK) return rc;
+        if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
+        for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
+        for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
+            hipStream_t s = lane_stream(i % lanes);
+            rc = launch_binning(vd[i], st[i], sc[i], s);
+            if (rc == LARA2DGS_OK) rc = launch_composite_fwd(vd[i], st[i], out_color + i * 3 * HW, out_allmap + i * 7 * HW, s);
+        }
+    } else {
+        if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
+        for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
+        for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
+            const int k = i % lanes;  // views on one lane are serialised: they share that lane's scratch
+            rc = lara2dgs_forward(&views[i], means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp,
+                                  out_color + i * 3 * HW, out_allmap + i * 7 * HW,
+                                  out_radii ? out_radii + (int64_t)i * v0.P : nullptr,
+                                  (char *)state + i * state_stride, (char *)scratch + k * scratch_stride, lane_stream(k));
+        }
     }
     // always join, also after a failure: the caller's stream must not run ahead of what was enqueued
     for (int k = 1; k < lanes; k++) {

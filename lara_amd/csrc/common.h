@@ -17,6 +17,7 @@
 #define GRAD_F 20          // floats per surfel in the backward accumulator (18 used)
 #define L2D_SEG 512       // backward work unit: a tile's list is cut into segments of this many entries
 #define L2D_CKPT_F 10      // floats per pixel in a segment-boundary checkpoint / in the per-pixel finals
+#define L2D_MAX_VIEWS 8    // cameras of one batched preprocess launch (a multi-view call with more views issues several)
 
 // Everything a kernel needs to know about the view, passed by value (lands in SGPRs / kernarg).
 struct ViewDev {
@@ -115,6 +116,10 @@ int launch_preprocess_fwd(const ViewDev &v, const float *means3D, const float *s
                           const float *colors_precomp, const float *opacities, const float *scales,
                           const float *rotations, const float *transmat_precomp, StateView st,
                           ScratchView sc, int32_t *radii, hipStream_t s);
+int launch_preprocess_fwd_views(const ViewDev &v, int n, const ViewDev *views, const float *means3D, const float *shs,
+                                const float *colors_precomp, const float *opacities, const float *scales,
+                                const float *rotations, const float *transmat_precomp, const StateView *st,
+                                const ScratchView *sc, int32_t *const *radii, hipStream_t s);
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s);
 int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float *out_allmap,
                          hipStream_t s);

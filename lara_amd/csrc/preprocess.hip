@@ -252,18 +252,16 @@ surfel_forward(const ViewDev &v, const int idx, const float *__restrict__ means3
 // only a few dozen distinct tiles: counts are aggregated in an LDS histogram and flushed with one
 // device-scope atomic per touched tile instead of one per (surfel, tile) pair.
 template <int DEG>
-__global__ void __launch_bounds__(256)
-preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
-                      const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
-                      const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
-                      const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
-                      float4 *__restrict__ cullbox, uint4 *__restrict__ rect_out,
-                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ block_tot,
-                      int32_t *__restrict__ radii, const int use_lds) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    __shared__ uint32_t wsum[4];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slice = blockIdx.x % L2D_SLICES;
+__device__ __forceinline__ void
+preprocess_fwd_block(const ViewDev &v, const int block, const float *__restrict__ means3D, const float *__restrict__ shs,
+                     const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
+                     const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
+                     const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
+                     float4 *__restrict__ cullbox, uint4 *__restrict__ rect_out,
+                     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ block_tot,
+                     int32_t *__restrict__ radii, const int use_lds, uint32_t *hist, uint32_t *wsum) {
+    const int idx = block * blockDim.x + threadIdx.x;
+    const int slice = block % L2D_SLICES;
     if (use_lds) {
         for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) hist[t] = 0;
         __syncthreads();
@@ -288,7 +286,7 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
     __syncthreads();
     uint32_t woff = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += wsum[w];
-    if (threadIdx.x == 255) block_tot[blockIdx.x] = woff + incl;
+    if (threadIdx.x == 255) block_tot[block] = woff + incl;
     if (idx < v.P) {
         // tile rectangle + depth key bits + local pair offset, 16 B per surfel, for the scatter pass
         const float depth = tt ? geom[(size_t)idx * 5 + 3].w : 0.f;
@@ -307,6 +305,48 @@ preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
             if (c) __hip_atomic_fetch_add(&tile_count[t * L2D_SLICES + slice], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
+                      const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
+                      const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
+                      const float *__restrict__ transmat_precomp, float4 *__restrict__ geom,
+                      float4 *__restrict__ cullbox, uint4 *__restrict__ rect_out,
+                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ block_tot,
+                      int32_t *__restrict__ radii, const int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    __shared__ uint32_t wsum[4];
+    preprocess_fwd_block<DEG>(v, (int)blockIdx.x, means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp,
+                              geom, cullbox, rect_out, tile_count, block_tot, radii, use_lds, hist, wsum);
+}
+
+// ONE launch for the n cameras of a multi-view call ("shared preprocess inputs, per-camera T").
+// The camera is the FAST index of the workgroup id: the n workgroups that process the same 256 surfels run next to
+// each other, so the surfels' 88 input bytes come from HBM once and from L2 n - 1 times.
+struct PreViews {
+    int n;
+    const float *bg[L2D_MAX_VIEWS], *viewmatrix[L2D_MAX_VIEWS], *projmatrix[L2D_MAX_VIEWS], *campos[L2D_MAX_VIEWS];
+    float4 *geom[L2D_MAX_VIEWS], *cullbox[L2D_MAX_VIEWS];
+    uint4 *rect[L2D_MAX_VIEWS];
+    uint32_t *tile_count[L2D_MAX_VIEWS], *block_tot[L2D_MAX_VIEWS];
+    int32_t *radii[L2D_MAX_VIEWS];
+};
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_fwd_views_kernel(ViewDev v, PreViews pv, const float *__restrict__ means3D, const float *__restrict__ shs,
+                            const float *__restrict__ colors_precomp, const float *__restrict__ opacities,
+                            const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
+                            const float *__restrict__ transmat_precomp, const int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    __shared__ uint32_t wsum[4];
+    const int view = (int)(blockIdx.x % (unsigned)pv.n), block = (int)(blockIdx.x / (unsigned)pv.n);
+    v.bg = pv.bg[view]; v.viewmatrix = pv.viewmatrix[view]; v.projmatrix = pv.projmatrix[view]; v.campos = pv.campos[view];
+    preprocess_fwd_block<DEG>(v, block, means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp,
+                              pv.geom[view], pv.cullbox[view], pv.rect[view], pv.tile_count[view], pv.block_tot[view],
+                              pv.radii[view], use_lds, hist, wsum);
 }
 
 __global__ void __launch_bounds__(256)
@@ -548,6 +588,41 @@ int launch_preprocess_fwd(const ViewDev &v, const float *means3D, const float *s
         }
     }
 #undef L2D_PRE
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int launch_preprocess_fwd_views(const ViewDev &v, int n, const ViewDev *views, const float *means3D, const float *shs,
+                                const float *colors_precomp, const float *opacities, const float *scales,
+                                const float *rotations, const float *transmat_precomp, const StateView *st,
+                                const ScratchView *sc, int32_t *const *radii, hipStream_t s) {
+    if (v.P == 0 || n <= 0) return LARA2DGS_OK;
+    if (n > L2D_MAX_VIEWS) return LARA2DGS_E_INVALID;
+    PreViews pv{};
+    pv.n = n;
+    for (int i = 0; i < n; i++) {
+        pv.bg[i] = views[i].bg; pv.viewmatrix[i] = views[i].viewmatrix; pv.projmatrix[i] = views[i].projmatrix;
+        pv.campos[i] = views[i].campos;
+        pv.geom[i] = st[i].geom; pv.cullbox[i] = st[i].cullbox; pv.rect[i] = sc[i].rect;
+        pv.tile_count[i] = sc[i].tile_count; pv.block_tot[i] = sc[i].block_tot; pv.radii[i] = radii[i];
+    }
+    const dim3 grid((unsigned)((v.P + 255) / 256) * (unsigned)n), block(256);
+    const int use_lds = v.tiles <= L2D_LDS_HIST_TILES;
+    const size_t lds_bytes = use_lds ? (size_t)v.tiles * 4 : 0;
+#define L2D_PREV(DEG)                                                                                    \
+    hipLaunchKernelGGL(preprocess_fwd_views_kernel<DEG>, grid, block, lds_bytes, s, v, pv, means3D, shs, \
+                       colors_precomp, opacities, (const float2 *)scales, (const float4 *)rotations,     \
+                       transmat_precomp, use_lds)
+    {
+        L2D_PROF("preprocess_fwd_views", s);
+        switch (colors_precomp ? 0 : v.deg) {
+        case 0: L2D_PREV(0); break;
+        case 1: L2D_PREV(1); break;
+        case 2: L2D_PREV(2); break;
+        default: L2D_PREV(3); break;
+        }
+    }
+#undef L2D_PREV
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }

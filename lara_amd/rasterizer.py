@@ -435,10 +435,14 @@ class _RasterizeViews(torch.autograd.Function):
             sb = (lib.lara2dgs_state_bytes(P, H, W, cap) + 255) // 256 * 256
             qb = (lib.lara2dgs_scratch_bytes(P, H, W, cap) + 255) // 256 * 256
             state = torch.empty((n * sb,), dtype=torch.uint8, device=device)
-            scratch = _get_scratch(device, lanes * qb)
+            # a scratch buffer per VIEW: the library then preprocesses all cameras in one launch (the surfels' inputs are
+            # read once); with fewer it falls back to one preprocess launch per view on the lanes
+            # (LARA2DGS_VIEWS_BATCH_PREPROCESS=0 keeps one scratch per lane: the memory-lean path)
+            n_scr = n if os.environ.get("LARA2DGS_VIEWS_BATCH_PREPROCESS", "1") != "0" else lanes
+            scratch = _get_scratch(device, n_scr * qb)
             rc = lib.lara2dgs_forward_views(n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c),
                                             _ptr(sc_c), _ptr(rot_c), _ptr(tm_c), color.data_ptr(), allmap.data_ptr(),
-                                            radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb, lanes, stream)
+                                            radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb, n_scr, stream)
             _check(rc, "lara2dgs_forward_views")
             ev, hdrs = _watch_overflow(state.view(n, sb)[:, :64].contiguous().view(torch.int32), cap,
                                        any(rs.debug for rs in settings))

@@ -76,9 +76,13 @@ def test_views_repeatable_and_independent_of_stream_count(monkeypatch):
     c1, g1 = run()
     monkeypatch.setenv("LARA2DGS_VIEW_STREAMS", "1")   # read by the Python side per call (scratch lanes)
     c2, g2 = run()
-    assert torch.equal(c0, c1) and torch.equal(c0, c2)
+    monkeypatch.setenv("LARA2DGS_VIEWS_BATCH_PREPROCESS", "0")   # one preprocess launch per view on the lanes
+    c3, g3 = run()
+    monkeypatch.delenv("LARA2DGS_VIEW_STREAMS")
+    c4, g4 = run()
+    assert torch.equal(c0, c1) and torch.equal(c0, c2) and torch.equal(c0, c3) and torch.equal(c0, c4)
     for k in g0:
-        assert torch.equal(g0[k], g1[k]) and torch.equal(g0[k], g2[k]), k
+        assert torch.equal(g0[k], g1[k]) and torch.equal(g0[k], g2[k]) and torch.equal(g0[k], g3[k]) and torch.equal(g0[k], g4[k]), k
 
 
 def test_views_argument_errors():
