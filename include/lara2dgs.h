@@ -165,10 +165,13 @@ typedef struct lara2dgs_grad_layout {
 int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int32_t has_colors,
                              int32_t has_scale_rot, int32_t has_transmat, lara2dgs_grad_layout *out);
 
-/* Backward of lara2dgs_forward_views: dL_dcolor [n,3,H,W], dL_dallmap [n,7,H,W], radii [n,P].  Every view writes
- * its gradients into its own slice of grad_tmp ([n_views][layout.total] floats); one kernel then adds the slices
- * into grad_out ([layout.total] floats, fully overwritten) in a fixed order -- the sum over a scene's views that
- * autograd otherwise forms with n-1 accumulation kernels per input, and bit-reproducible. */
+/* Backward of lara2dgs_forward_views: dL_dcolor [n,3,H,W], dL_dallmap [n,7,H,W], radii [n,P].  grad_out
+ * ([layout.total] floats; every gradient array in it is fully overwritten) receives the gradients summed over the
+ * views in view order -- the sum over a scene's views that autograd otherwise forms with n-1 accumulation kernels per
+ * input, and bit-reproducible.  With n_scratch >= n_views the lanes run composite_bwd only and ONE per-surfel launch
+ * folds the n views' contributions in registers (grad_tmp is not used and may be NULL).  With fewer scratch buffers
+ * every view writes its gradients into its own slice of grad_tmp ([n_views][layout.total] floats, required) and one
+ * kernel adds the slices in the same order: same bits either way. */
 int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                             const float *shs, const float *colors_precomp, const float *scales,
                             const float *rotations, const float *transmat_precomp, const int32_t *radii,

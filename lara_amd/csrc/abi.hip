@@ -426,7 +426,7 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
                             const float *dL_dcolor, const float *dL_dallmap, const void *state,
                             int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
                             float *grad_tmp, float *grad_out, void *stream) {
-    if (n_views <= 0 || !views || n_scratch <= 0 || !state || !scratch || !grad_tmp || !grad_out) return LARA2DGS_E_INVALID;
+    if (n_views <= 0 || !views || n_scratch <= 0 || !state || !scratch || !grad_out) return LARA2DGS_E_INVALID;
     if (!views_agree(n_views, views)) return LARA2DGS_E_INVALID;
     const lara2dgs_view &v0 = views[0];
     if (state_stride % 256 || scratch_stride % 256 ||
@@ -447,10 +447,51 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
     if (lanes > n_scratch) lanes = n_scratch;
     auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
     const int64_t HW = (int64_t)v0.image_height * v0.image_width;
+    auto at = [&](float *base, int64_t off) { return off < 0 ? (float *)nullptr : base + off; };
+    int rc = LARA2DGS_OK;
+    // With a scratch buffer per view the lanes only run composite_bwd (each view's gradient rows stay in its own
+    // scratch); after the join ONE preprocess_bwd launch walks every surfel through the n views and writes the summed
+    // gradients -- no per-view gradient tensors (grad_tmp is not touched), no summation pass.
+    const bool batched = n_scratch >= n_views;
+    if (batched) {
+        if (!means3D || !radii) return LARA2DGS_E_INVALID;
+        if (has_sh == has_col || has_sr == has_tm) return LARA2DGS_E_INVALID;
+        std::vector<ViewDev> vd(n_views);
+        std::vector<StateView> st(n_views);
+        std::vector<ScratchView> sc(n_views);
+        std::vector<const int32_t *> rad(n_views);
+        std::vector<ScratchLayout> SL(n_views);
+        for (int i = 0; i < n_views; i++) {
+            if (!make_view(&views[i], vd[i])) return LARA2DGS_E_INVALID;
+            st[i] = carve_state(vd[i], (char *)const_cast<void *>(state) + i * state_stride);
+            sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL[i]);
+            rad[i] = radii + (int64_t)i * v0.P;
+        }
+        if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
+        for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
+        for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
+            hipStream_t s = lane_stream(i % lanes);
+            const hipError_t e = hipMemsetAsync(sc[i].pair_valid, 0, (size_t)(SL[i].total - SL[i].pair_valid), s);
+            if (e != hipSuccess) { l2d_set_hip_error(e); rc = LARA2DGS_E_LAUNCH; break; }
+            rc = launch_composite_bwd(vd[i], st[i], sc[i], dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW, s);
+        }
+        for (int k = 1; k < lanes; k++) {
+            HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
+            HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
+        }
+        for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
+            const int nb = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
+            rc = launch_preprocess_bwd_views(vd[i0], nb, &vd[i0], i0 > 0, means3D, shs, colors_precomp, scales, rotations,
+                                             transmat_precomp, &rad[i0], &st[i0], &sc[i0], at(grad_out, G.means3D),
+                                             at(grad_out, G.means2D), at(grad_out, G.shs), at(grad_out, G.colors),
+                                             at(grad_out, G.opacities), at(grad_out, G.scales), at(grad_out, G.rotations),
+                                             at(grad_out, G.transmat), caller);
+        }
+        return rc;
+    }
+    if (!grad_tmp) return LARA2DGS_E_INVALID;
     if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
     for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
-    int rc = LARA2DGS_OK;
-    auto at = [&](float *base, int64_t off) { return off < 0 ? (float *)nullptr : base + off; };
     for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
         const int k = i % lanes;
         float *g = grad_tmp + (int64_t)i * G.total;

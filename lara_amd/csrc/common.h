@@ -131,6 +131,12 @@ int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *s
                           ScratchView sc, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
                           float *dL_dcolors, float *dL_dopacities, float *dL_dscales,
                           float *dL_drotations, float *dL_dtransmat, hipStream_t s);
+int launch_preprocess_bwd_views(const ViewDev &v, int n, const ViewDev *views, int accumulate, const float *means3D,
+                                const float *shs, const float *colors_precomp, const float *scales, const float *rotations,
+                                const float *transmat_precomp, const int32_t *const *radii, const StateView *st,
+                                const ScratchView *sc, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
+                                float *dL_dcolors, float *dL_dopacities, float *dL_dscales, float *dL_drotations,
+                                float *dL_dtransmat, hipStream_t s);
 int launch_selftest_butterfly(const float *in, float *out, hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present,
                         hipStream_t s);

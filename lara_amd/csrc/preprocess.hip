@@ -365,21 +365,44 @@ mark_visible_kernel(int P, const float *__restrict__ means3D, const float *__res
 //   grad[idx][0..8]  dL/dT (Tu,Tv,Tw)   [9..10] dL/dmean2D   [11..13] dL/dnormal
 //   grad[idx][14]    dL/dopacity        [15..17] dL/drgb
 // ------------------------------------------------------------------------------------------------
+// everything one view contributes to a surfel's gradients
 template <int DEG>
-__global__ void __launch_bounds__(256)
-preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
-                      const float *__restrict__ colors_precomp, const float2 *__restrict__ scales,
-                      const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
-                      const int32_t *__restrict__ radii, const float4 *__restrict__ geom,
-                      const uint32_t *__restrict__ pair_base,
-                      const float4 *__restrict__ pair_grad, const uint8_t *__restrict__ pair_valid,
-                      float *__restrict__ dL_dmeans3D,
-                      float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
-                      float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
-                      float2 *__restrict__ dL_dscales, float4 *__restrict__ dL_drots,
-                      float *__restrict__ dL_dtransmat) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= v.P) return;
+struct SurfelGrad {
+    static constexpr int NSH = (DEG + 1) * (DEG + 1) * 3;
+    float dmean[3], m2out[2], dopac, dscale[2], drot[4], dT[9], dcol[3], dsh[NSH];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { dmean[k] = 0.f; dcol[k] = 0.f; }
+        m2out[0] = m2out[1] = dopac = dscale[0] = dscale[1] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) drot[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dT[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSH; k++) dsh[k] = 0.f;
+    }
+    __device__ __forceinline__ void add(const SurfelGrad &o) {   // (no FMA contraction in this file: plain adds)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { dmean[k] += o.dmean[k]; dcol[k] += o.dcol[k]; }
+        m2out[0] += o.m2out[0]; m2out[1] += o.m2out[1]; dopac += o.dopac; dscale[0] += o.dscale[0]; dscale[1] += o.dscale[1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) drot[k] += o.drot[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) dT[k] += o.dT[k];
+#pragma unroll
+        for (int k = 0; k < NSH; k++) dsh[k] += o.dsh[k];
+    }
+};
+
+template <int DEG>
+__device__ __forceinline__ void
+surfel_backward(const ViewDev &v, const int idx, const float *__restrict__ means3D, const float *__restrict__ shs,
+                const float *__restrict__ colors_precomp, const float2 *__restrict__ scales,
+                const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
+                const int32_t *__restrict__ radii, const float4 *__restrict__ geom,
+                const uint32_t *__restrict__ pair_base, const float4 *__restrict__ pair_grad,
+                const uint8_t *__restrict__ pair_valid, SurfelGrad<DEG> &G) {
+    G.zero();
     const bool visible = radii[idx] > 0;
 
     // sum the surfel's per-tile gradient rows in tile order (deterministic; no atomics anywhere)
@@ -398,7 +421,7 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
             }
         }
     }
-    dL_dopacities[idx] = gacc[14];
+    G.dopac = gacc[14];
 
     float dmean[3] = {0.f, 0.f, 0.f};
     float2 dscale = make_float2(0.f, 0.f);
@@ -471,7 +494,7 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
 
         if (colors_precomp == nullptr) {
             const float *sh = shs + (size_t)idx * v.M * 3;
-            float *dsh = dL_dshs + (size_t)idx * v.M * 3;
+            float *dsh = G.dsh;
             const float dir_o[3] = {p[0] - v.campos[0], p[1] - v.campos[1], p[2] - v.campos[2]};
             const float len = sqrtf(dir_o[0] * dir_o[0] + dir_o[1] * dir_o[1] + dir_o[2] * dir_o[2]);
             const float x = dir_o[0] / len, y = dir_o[1] / len, z = dir_o[2] / len;
@@ -525,8 +548,6 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
                         }
                     }
                 }
-                // coefficients above the active degree get zero gradient
-                for (int k = (DEG + 1) * (DEG + 1); k < v.M; k++) dsh[k * 3 + ch] = 0.f;
                 ddir[0] += dx * gg; ddir[1] += dy * gg; ddir[2] += dz * gg;
             }
             const float sum2 = dir_o[0] * dir_o[0] + dir_o[1] * dir_o[1] + dir_o[2] * dir_o[2];
@@ -539,28 +560,121 @@ preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float 
         const float depth = g2.x;
         m2out[0] = gacc[2] * depth * 0.5f * (float)v.W;
         m2out[1] = gacc[5] * depth * 0.5f * (float)v.H;
-    } else if (colors_precomp == nullptr) {
-        float *dsh = dL_dshs + (size_t)idx * v.M * 3;
-        for (int k = 0; k < v.M * 3; k++) dsh[k] = 0.f;
     }
 
-    dL_dmeans3D[3 * idx + 0] = dmean[0];
-    dL_dmeans3D[3 * idx + 1] = dmean[1];
-    dL_dmeans3D[3 * idx + 2] = dmean[2];
-    dL_dmeans2D[3 * idx + 0] = m2out[0];
-    dL_dmeans2D[3 * idx + 1] = m2out[1];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { G.dmean[k] = dmean[k]; G.dcol[k] = gacc[15 + k]; }
+    G.m2out[0] = m2out[0]; G.m2out[1] = m2out[1];
+    G.dscale[0] = dscale.x; G.dscale[1] = dscale.y;
+    G.drot[0] = drot.x; G.drot[1] = drot.y; G.drot[2] = drot.z; G.drot[3] = drot.w;
+#pragma unroll
+    for (int k = 0; k < 9; k++) G.dT[k] = visible ? dT[k] : 0.f;
+}
+
+template <int DEG>
+__device__ __forceinline__ void
+write_surfel_grad(const ViewDev &v, const int idx, const SurfelGrad<DEG> &G, const bool has_sh, const bool has_col,
+                  const bool has_tm, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+                  float *__restrict__ dL_dshs, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
+                  float2 *__restrict__ dL_dscales, float4 *__restrict__ dL_drots, float *__restrict__ dL_dtransmat) {
+    dL_dopacities[idx] = G.dopac;
+    dL_dmeans3D[3 * idx + 0] = G.dmean[0];
+    dL_dmeans3D[3 * idx + 1] = G.dmean[1];
+    dL_dmeans3D[3 * idx + 2] = G.dmean[2];
+    dL_dmeans2D[3 * idx + 0] = G.m2out[0];
+    dL_dmeans2D[3 * idx + 1] = G.m2out[1];
     dL_dmeans2D[3 * idx + 2] = 0.f;
-    if (transmat_precomp == nullptr) {
-        dL_dscales[idx] = dscale;
-        dL_drots[idx] = drot;
+    if (!has_tm) {
+        dL_dscales[idx] = make_float2(G.dscale[0], G.dscale[1]);
+        dL_drots[idx] = make_float4(G.drot[0], G.drot[1], G.drot[2], G.drot[3]);
     } else {
 #pragma unroll
-        for (int k = 0; k < 9; k++) dL_dtransmat[9 * (size_t)idx + k] = visible ? dT[k] : 0.f;
+        for (int k = 0; k < 9; k++) dL_dtransmat[9 * (size_t)idx + k] = G.dT[k];
     }
-    if (colors_precomp != nullptr) {
+    if (has_sh) {
+        float *dsh = dL_dshs + (size_t)idx * v.M * 3;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * (size_t)idx + ch] = gacc[15 + ch];
+        for (int k = 0; k < SurfelGrad<DEG>::NSH; k++) dsh[k] = G.dsh[k];
+        for (int k = SurfelGrad<DEG>::NSH; k < v.M * 3; k++) dsh[k] = 0.f;   // coefficients above the active degree
     }
+    if (has_col) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * (size_t)idx + ch] = G.dcol[ch];
+    }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(ViewDev v, const float *__restrict__ means3D, const float *__restrict__ shs,
+                      const float *__restrict__ colors_precomp, const float2 *__restrict__ scales,
+                      const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
+                      const int32_t *__restrict__ radii, const float4 *__restrict__ geom,
+                      const uint32_t *__restrict__ pair_base,
+                      const float4 *__restrict__ pair_grad, const uint8_t *__restrict__ pair_valid,
+                      float *__restrict__ dL_dmeans3D,
+                      float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
+                      float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacities,
+                      float2 *__restrict__ dL_dscales, float4 *__restrict__ dL_drots,
+                      float *__restrict__ dL_dtransmat) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= v.P) return;
+    SurfelGrad<DEG> G;
+    surfel_backward<DEG>(v, idx, means3D, shs, colors_precomp, scales, rotations, transmat_precomp, radii, geom, pair_base,
+                         pair_grad, pair_valid, G);
+    write_surfel_grad<DEG>(v, idx, G, colors_precomp == nullptr, colors_precomp != nullptr, transmat_precomp != nullptr,
+                           dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drots, dL_dtransmat);
+}
+
+// ONE launch for the n views of a multi-view call: a thread walks its surfel through the views in order, adds each
+// view's contribution in registers (view 0, then + view 1, ...: the order and the roundings of adding the per-view
+// gradient tensors one after the other) and writes the summed gradient once -- the surfel's inputs are read once, no
+// per-view gradient tensors, no summation pass.
+struct BwdViews {
+    int n;
+    const float *viewmatrix[L2D_MAX_VIEWS], *projmatrix[L2D_MAX_VIEWS], *campos[L2D_MAX_VIEWS];
+    const int32_t *radii[L2D_MAX_VIEWS];
+    const float4 *geom[L2D_MAX_VIEWS], *pair_grad[L2D_MAX_VIEWS];
+    const uint32_t *pair_base[L2D_MAX_VIEWS];
+    const uint8_t *pair_valid[L2D_MAX_VIEWS];
+};
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+preprocess_bwd_views_kernel(ViewDev v, BwdViews bv, const int accumulate, const float *__restrict__ means3D,
+                            const float *__restrict__ shs, const float *__restrict__ colors_precomp,
+                            const float2 *__restrict__ scales, const float4 *__restrict__ rotations,
+                            const float *__restrict__ transmat_precomp, float *dL_dmeans3D, float *dL_dmeans2D,
+                            float *dL_dshs, float *dL_dcolors, float *dL_dopacities, float2 *dL_dscales, float4 *dL_drots,
+                            float *dL_dtransmat) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= v.P) return;
+    const bool has_sh = colors_precomp == nullptr, has_col = !has_sh, has_tm = transmat_precomp != nullptr;
+    SurfelGrad<DEG> A;
+    if (accumulate) {   // (a call with more than L2D_MAX_VIEWS views: continue the running sums of the launch before)
+        A.zero();
+        A.dopac = dL_dopacities[idx];
+        for (int k = 0; k < 3; k++) A.dmean[k] = dL_dmeans3D[3 * idx + k];
+        A.m2out[0] = dL_dmeans2D[3 * idx]; A.m2out[1] = dL_dmeans2D[3 * idx + 1];
+        if (!has_tm) {
+            const float2 a = dL_dscales[idx]; const float4 b = dL_drots[idx];
+            A.dscale[0] = a.x; A.dscale[1] = a.y; A.drot[0] = b.x; A.drot[1] = b.y; A.drot[2] = b.z; A.drot[3] = b.w;
+        } else {
+            for (int k = 0; k < 9; k++) A.dT[k] = dL_dtransmat[9 * (size_t)idx + k];
+        }
+        if (has_sh) for (int k = 0; k < SurfelGrad<DEG>::NSH; k++) A.dsh[k] = dL_dshs[(size_t)idx * v.M * 3 + k];
+        if (has_col) for (int k = 0; k < 3; k++) A.dcol[k] = dL_dcolors[3 * (size_t)idx + k];
+    }
+#pragma unroll 1
+    for (int view = 0; view < bv.n; view++) {
+        v.viewmatrix = bv.viewmatrix[view]; v.projmatrix = bv.projmatrix[view]; v.campos = bv.campos[view];
+        SurfelGrad<DEG> G;
+        surfel_backward<DEG>(v, idx, means3D, shs, colors_precomp, scales, rotations, transmat_precomp, bv.radii[view],
+                             bv.geom[view], bv.pair_base[view], bv.pair_grad[view], bv.pair_valid[view], G);
+        if (view == 0 && !accumulate) A = G;
+        else A.add(G);
+    }
+    write_surfel_grad<DEG>(v, idx, A, has_sh, has_col, has_tm, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities,
+                           dL_dscales, dL_drots, dL_dtransmat);
 }
 
 }  // namespace
@@ -661,6 +775,41 @@ int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, ui
     if (P == 0) return LARA2DGS_OK;
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D,
                        viewmatrix, present);
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int launch_preprocess_bwd_views(const ViewDev &v, int n, const ViewDev *views, int accumulate, const float *means3D,
+                                const float *shs, const float *colors_precomp, const float *scales, const float *rotations,
+                                const float *transmat_precomp, const int32_t *const *radii, const StateView *st,
+                                const ScratchView *sc, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
+                                float *dL_dcolors, float *dL_dopacities, float *dL_dscales, float *dL_drotations,
+                                float *dL_dtransmat, hipStream_t s) {
+    if (v.P == 0 || n <= 0) return LARA2DGS_OK;
+    if (n > L2D_MAX_VIEWS) return LARA2DGS_E_INVALID;
+    BwdViews bv{};
+    bv.n = n;
+    for (int i = 0; i < n; i++) {
+        bv.viewmatrix[i] = views[i].viewmatrix; bv.projmatrix[i] = views[i].projmatrix; bv.campos[i] = views[i].campos;
+        bv.radii[i] = radii[i]; bv.geom[i] = st[i].geom; bv.pair_base[i] = st[i].pair_base;
+        bv.pair_grad[i] = (const float4 *)sc[i].pair_grad; bv.pair_valid[i] = (const uint8_t *)sc[i].pair_valid;
+    }
+    const dim3 grid((v.P + 255) / 256), block(256);
+#define L2D_PREBV(DEG)                                                                                         \
+    hipLaunchKernelGGL(preprocess_bwd_views_kernel<DEG>, grid, block, 0, s, v, bv, accumulate, means3D, shs,   \
+                       colors_precomp, (const float2 *)scales, (const float4 *)rotations, transmat_precomp,   \
+                       dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, (float2 *)dL_dscales,      \
+                       (float4 *)dL_drotations, dL_dtransmat)
+    {
+        L2D_PROF("preprocess_bwd_views", s);
+        switch (colors_precomp ? 0 : v.deg) {
+        case 0: L2D_PREBV(0); break;
+        case 1: L2D_PREBV(1); break;
+        case 2: L2D_PREBV(2); break;
+        default: L2D_PREBV(3); break;
+        }
+    }
+#undef L2D_PREBV
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }

@@ -494,14 +494,19 @@ class _RasterizeViews(torch.autograd.Function):
                                  bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
             lanes = min(n, _view_lanes())
             out = torch.empty((max(G.total, 4),), dtype=torch.float32, device=device)
-            tmp = torch.empty((n * max(G.total, 4),), dtype=torch.float32, device=device)
-            scratch = _get_scratch(device, lanes * ctx.qb)
+            # a scratch buffer per VIEW: each view's gradient rows stay put until ONE preprocess_bwd launch folds the n
+            # views into the summed gradient (no per-view gradient tensors); with one per lane the library writes a
+            # gradient slice per view into `tmp` and sums the slices
+            batched = os.environ.get("LARA2DGS_VIEWS_BATCH_PREPROCESS", "1") != "0"
+            n_scr = n if batched else lanes
+            tmp = None if batched else torch.empty((n * max(G.total, 4),), dtype=torch.float32, device=device)
+            scratch = _get_scratch(device, n_scr * ctx.qb)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = lib.lara2dgs_backward_views(
                 n, views, _ptr(means3D), _ptr(sh if has_sh else None), _ptr(col if has_col else None),
                 _ptr(sc if has_sr else None), _ptr(rot if has_sr else None), _ptr(tm if has_tm else None),
                 radii.data_ptr(), grad_color.data_ptr(), grad_allmap.data_ptr(), state.data_ptr(), ctx.sb,
-                scratch.data_ptr(), ctx.qb, lanes, tmp.data_ptr(), out.data_ptr(), stream)
+                scratch.data_ptr(), ctx.qb, n_scr, _ptr(tmp), out.data_ptr(), stream)
             _check(rc, "lara2dgs_backward_views")
 
         def sec(off, k, shape):

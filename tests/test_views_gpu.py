@@ -15,7 +15,7 @@ def _inputs(act):
     return {k: v.to(DEV).clone().requires_grad_(True) for k, v in act.items()}
 
 
-@pytest.mark.parametrize("n_views,size", [(4, 128), (8, 96), (1, 64), (5, 80)])
+@pytest.mark.parametrize("n_views,size", [(4, 128), (8, 96), (1, 64), (5, 80), (11, 64)])
 def test_views_match_the_per_view_loop(n_views, size):
     from lara_amd import GaussianRasterizer, rasterize_gaussians_views
     act, cams = small_scene(grid=12, size=size, n_views=n_views, seed=3)
