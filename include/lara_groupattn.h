@@ -87,6 +87,13 @@ int lara_tokens_from_volume(int32_t scenes, int32_t R, int32_t C, const float *v
 int lara_volume_from_tokens(int32_t scenes, int32_t R, int32_t C, const float *tokens, float *volume,
                             void *stream);
 
+/* dst[b][c][r] = src[b][r][c] for `batch` row-major fp32 [rows, cols] matrices; dst is fp32, or bf16 (round to
+ * nearest even) when dst_bf16 != 0.  VolTransformer.forward's `b v c d h w -> (b d h w) v c` rearrangement of the
+ * image features fused with their bf16 cast (network.py:145-150: rows = v * c, cols = d * h * w) and, with rows and
+ * cols swapped, its backward -- one pass each instead of a strided torch copy plus a cast. */
+int lara_batched_transpose(int32_t batch, int32_t rows, int32_t cols, const float *src, void *dst, int32_t dst_bf16,
+                           void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training.  In the reference the backward is torch autograd through the modules above under bf16-mixed
  * autocast.  Here
@@ -129,7 +136,11 @@ int lara_groupblock_forward_train(int32_t scenes, int32_t R, int32_t cond_dim, c
 int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
                              const uint16_t *cond_bf16, const lara_groupblock_weights *w,
                              const lara_groupblock_weights_t *wt, const void *saved, float *g, float *dcond,
-                             const lara_groupblock_grads *dw, void *workspace, void *stream);
+                             const lara_groupblock_grads *dw, int32_t chained, void *workspace, void *stream);
+/* chained != 0: this call continues a backward sweep -- `workspace` was last used by a lara_groupblock_backward call
+ * with the same (scenes, R) whose output g is this call's input g, and nothing touched either since.  The call then
+ * reuses what that call left in the workspace (the bf16 copy of g its last LayerNorm backward wrote, the convolution's
+ * neighbour table) instead of rebuilding them.  chained == 0 (the first block of a sweep) builds both. */
 
 /* Backward of lara_voltrans_head_forward.  x: the rows that entered the head; dout: fp32
  * [scenes, 2R, 2R, 2R, Cout]; wdeconv_t: wdeconv transposed, [256, 8 * Cout] bf16.  Writes g = dL/dx

@@ -31,9 +31,46 @@ tokens_volume_kernel(const int R, const int C, const float *__restrict__ src, fl
     else dst[v] = src[i];
 }
 
+// dst[b][c][r] = src[b][r][c]: 64 x 64 tiles through LDS, both sides in 256-byte (fp32) / 128-byte (bf16) runs
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+batched_transpose_kernel(const float *__restrict__ src, void *__restrict__ dst, const int rows, const int cols) {
+    __shared__ float t[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        const int r = r0 + ty * 16 + k, c = c0 + tx;
+        t[ty * 16 + k][tx] = (r < rows && c < cols) ? src[base + (size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        const int c = c0 + ty * 16 + k, r = r0 + tx;
+        if (c < cols && r < rows) {
+            const float v = t[tx][ty * 16 + k];
+            if (BF16) ((unsigned short *)dst)[base + (size_t)c * rows + r] = f2bf(v);
+            else ((float *)dst)[base + (size_t)c * rows + r] = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int lara_batched_transpose(int32_t batch, int32_t rows, int32_t cols, const float *src, void *dst, int32_t dst_bf16,
+                           void *stream) {
+    if (batch < 0 || rows < 0 || cols < 0 || batch > 65535 || (rows + 63) / 64 > 65535) return LARA2DGS_E_INVALID;
+    if (batch == 0 || rows == 0 || cols == 0) return LARA2DGS_OK;
+    if (!src || !dst) return LARA2DGS_E_INVALID;
+    const dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
+    if (dst_bf16) hipLaunchKernelGGL(batched_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+    else hipLaunchKernelGGL(batched_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
 
 int64_t lara_groupblock_workspace_bytes(int32_t scenes, int32_t R) {
     if (scenes < 0 || R <= 0 || (R & 1)) return LARA2DGS_E_INVALID;

@@ -778,7 +778,7 @@ int lara_groupblock_forward_train(int32_t scenes, int32_t R, int32_t cond_dim, c
 int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
                              const uint16_t *cond_bf16, const lara_groupblock_weights *w,
                              const lara_groupblock_weights_t *wt, const void *saved, float *g, float *dcond,
-                             const lara_groupblock_grads *dw, void *workspace, void *stream) {
+                             const lara_groupblock_grads *dw, int32_t chained, void *workspace, void *stream) {
     if (scenes < 0 || R < 4 || (R & 1) || cond_dim <= 0 || (cond_dim % 32) != 0 || !block_weights_ok(w) || !wt || !dw)
         return LARA2DGS_E_INVALID;
     if (scenes == 0) return LARA2DGS_OK;
@@ -812,11 +812,13 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     float *tmpf = (float *)(ws + L.tmpf);
     float *lnpart = (float *)(ws + L.lnpart), *tnpart = (float *)(ws + L.tnpart);
     int *nbr = (int *)(ws + L.nbr);
-    if (hipMemsetAsync(gb + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
-    hipLaunchKernelGGL(neighbour_table_kernel, dim3((M + 255) / 256), dim3(256), 0, s, nbr, M, R, M, 512);
-    L2D_CHECK_LAUNCH();
+    if (!chained) {  // (a chained call finds the zero row, the neighbour table and bf16(g) where the call before left them)
+        if (hipMemsetAsync(gb + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        hipLaunchKernelGGL(neighbour_table_kernel, dim3((M + 255) / 256), dim3(256), 0, s, nbr, M, R, M, 512);
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, g, gb, (size_t)M * 64);
+        L2D_CHECK_LAUNCH();
+    }
     // ---- x_out = pn + cnn(pn), pn = norm3(x2)  (network.py:94-100) ----
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, g, gb, (size_t)M * 64);
     {
         L2D_PROF("gbb_dw_conv", s);
         if ((rc = gemm_tn(gb, 256, 256, xn3, 256, 256, 27, nbr, M, dw->wconv, tnpart, s))) return rc;
@@ -866,7 +868,7 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(tmpf, x_in, w->ln1_w, w->eps, g, g, nullptr, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(tmpf, x_in, w->ln1_w, w->eps, g, g, gb, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

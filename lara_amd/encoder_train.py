@@ -16,6 +16,7 @@ There is no CPU path and no torch fallback: tensors must live on the GPU and the
 from __future__ import annotations
 
 import ctypes
+import math
 
 import torch
 from torch import nn
@@ -46,7 +47,9 @@ def _lib():
         lib.lara_groupblock_backward_workspace_bytes.argtypes = [i32, i32]
         lib.lara_groupblock_backward.restype = ctypes.c_int
         lib.lara_groupblock_backward.argtypes = [i32, i32, i32, vp, vp, ctypes.POINTER(_BlockWeights),
-                                                 ctypes.POINTER(_BlockWeightsT), vp, vp, vp, ctypes.POINTER(_BlockGrads), vp, vp]
+                                                 ctypes.POINTER(_BlockWeightsT), vp, vp, vp, ctypes.POINTER(_BlockGrads), i32, vp, vp]
+        lib.lara_batched_transpose.restype = ctypes.c_int
+        lib.lara_batched_transpose.argtypes = [i32, i32, i32, vp, vp, i32, vp]
         lib.lara_groupblock_save_bytes.restype = i64
         lib.lara_groupblock_save_bytes.argtypes = [i32, i32]
         lib.lara_groupblock_forward_train.restype = ctypes.c_int
@@ -135,6 +138,14 @@ def invalidate_weight_cache():
 
 
 def _layer_bf16_t(f):
+    """The transposed operands of the backward's dX GEMMs; kept with the entry of `_layer_bf16` they derive from."""
+    t = f.get("_t")
+    if t is None:
+        t = f["_t"] = _transposed(f)
+    return t
+
+
+def _transposed(f):
     return {"wq_t": f["wq"].t().contiguous(), "wkv_t": f["wkv"].t().contiguous(), "wo_t": f["wo"].t().contiguous(),
             "w1_t": f["w1"].t().contiguous(), "w2_t": f["w2"].t().contiguous(),
             # [in][mirrored tap][out]: wconv_t[ci][t][co] = wconv[co][26 - t][ci] = cnn.weight[co, ci, 26 - t]
@@ -148,21 +159,26 @@ def _fill(struct, tensors, names):
 
 
 class _VolTransFn(torch.autograd.Function):
-    """(cond fp32 [B*G^3, 4, C], eps_block, eps_final, R, out_dim, pos_embed, norm.w, norm.b, deconv.w, deconv.b,
-    15 tensors per layer ...) -> [B, 2R, 2R, 2R, out_dim]"""
+    """(image_feats [B, V = 4, C, D, H, W], eps_block, eps_final, R, out_dim, pos_embed, norm.w, norm.b, deconv.w,
+    deconv.b, 15 tensors per layer ...) -> [B, 2R, 2R, 2R, out_dim]"""
 
     @staticmethod
-    def forward(ctx, cond, eps_block, eps_final, R, out_dim, pos_embed, norm_w, norm_b, deconv_w, deconv_b, *layer_params):
-        if not cond.is_cuda:
+    def forward(ctx, image_feats, eps_block, eps_final, R, out_dim, pos_embed, norm_w, norm_b, deconv_w, deconv_b, *layer_params):
+        if not image_feats.is_cuda:
             raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
         lib = _lib()
-        dev = cond.device
+        dev = image_feats.device
         n_layers = len(layer_params) // _NLP
-        G3 = (R // 2) ** 3
-        B = cond.shape[0] // G3
+        B, V, cond_dim = image_feats.shape[:3]
+        S = image_feats.shape[3] * image_feats.shape[4] * image_feats.shape[5]
         M = B * R ** 3
-        cond_dim = cond.shape[2]
-        cond_bf = cond.detach().to(torch.bfloat16).contiguous()
+        # `b v c d h w -> (b d h w) v c` (network.py:145-150) and the bf16 cast in one pass: per scene, the
+        # [v c, d h w] matrix transposed
+        feats = image_feats.detach().float().contiguous()
+        cond_bf = torch.empty(B * S, V, cond_dim, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            _check(lib.lara_batched_transpose(B, V * cond_dim, S, feats.data_ptr(), cond_bf.data_ptr(), 1, _stream(dev)),
+                   "lara_batched_transpose")
         x = volume_to_tokens(pos_embed.detach().float()).repeat(B, 1)       # network.py:152
         track = any(ctx.needs_input_grad)          # False under torch.no_grad(): plain in-place forward
         keep = track and _keep_activations()
@@ -202,6 +218,7 @@ class _VolTransFn(torch.autograd.Function):
             return out
         ctx.save_for_backward(cond_bf, x, pos_embed, norm_w, norm_b, deconv_w, *saved_x, *layer_params)
         ctx.meta = (float(eps_block), float(eps_final), R, out_dim, B, n_layers, cond_dim)
+        ctx.feat_shape, ctx.feat_dtype = tuple(image_feats.shape), image_feats.dtype
         ctx.saved_act, ctx.saved_w = saved_act, saved_w   # raw scratch / bf16 weight copies, not graph tensors
         return out
 
@@ -222,6 +239,17 @@ class _VolTransFn(torch.autograd.Function):
         d_wd, d_b8 = torch.zeros(8 * out_dim, 256, **f32), torch.zeros(8 * out_dim, **f32)
         dcond = torch.zeros(cond_bf.shape, **f32)
         grads = [None] * (n_layers * _NLP)
+        # every layer's 14 gradient accumulators carved from ONE zero-filled buffer (one fill, not 14 per layer)
+        shapes = {n: tuple(ctx.saved_w[0][n].shape) if ctx.saved_w else None for n in _GRAD_FIELDS}
+        if not ctx.saved_w:
+            f0 = _layer_bf16([t.detach() for t in layer_params[:_NLP]])
+            shapes = {n: tuple(f0[n].shape) for n in _GRAD_FIELDS}
+        offs, o = {}, 0
+        for n in _GRAD_FIELDS:
+            offs[n] = o
+            o += (math.prod(shapes[n]) + 63) // 64 * 64
+        per_layer = o
+        flat = torch.zeros(n_layers * per_layer, **f32)
         with torch.cuda.device(dev):
             wd_t = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).t().contiguous()
             nw, nb = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous()
@@ -238,21 +266,31 @@ class _VolTransFn(torch.autograd.Function):
                 w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
                 w.eps = eps_block
                 wt = _fill(_BlockWeightsT(), ft, ("wq_t", "wkv_t", "wo_t", "w1_t", "w2_t", "wconv_t"))
-                gd = {n: torch.zeros(f[n].shape, **f32) for n in _GRAD_FIELDS}
+                gd = {n: flat[l * per_layer + offs[n]:l * per_layer + offs[n] + math.prod(shapes[n])].view(shapes[n])
+                      for n in _GRAD_FIELDS}
                 dw = _fill(_BlockGrads(), gd, _GRAD_FIELDS)
                 act = ctx.saved_act[l].data_ptr() if ctx.saved_act else None
                 _check(lib.lara_groupblock_backward(B, R, cond_dim, saved_x[l].data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
                                                     ctypes.byref(wt), act, g.data_ptr(), dcond.data_ptr(), ctypes.byref(dw),
-                                                    ws.data_ptr(), _stream(dev)), "lara_groupblock_backward")
+                                                    int(l != n_layers - 1), ws.data_ptr(), _stream(dev)),
+                       "lara_groupblock_backward")
                 grads[l * _NLP:(l + 1) * _NLP] = [
                     gd["ln1_w"], gd["ln1_b"], gd["wq"], gd["wkv"][:256], gd["wkv"][256:], gd["wo"], gd["ln2_w"], gd["ln2_b"],
                     gd["w1"], gd["b1"], gd["w2"], gd["b2"], gd["ln3_w"], gd["ln3_b"],
                     gd["wconv"].view(256, 3, 3, 3, 256).permute(0, 4, 1, 2, 3)]
             # the same positional rows enter every scene (network.py:152)
             d_pos = tokens_to_volume(g.view(B, R ** 3, 256).sum(0), 1, R)
+            # dL/d(image_feats): the rearrangement's backward, [d h w, v c] -> [v c, d h w] per scene
+            Bf, V, C = ctx.feat_shape[:3]
+            S = dcond.shape[0] // Bf
+            d_feats = torch.empty(ctx.feat_shape, **f32)
+            _check(lib.lara_batched_transpose(Bf, S, V * C, dcond.data_ptr(), d_feats.data_ptr(), 0, _stream(dev)),
+                   "lara_batched_transpose")
+            if ctx.feat_dtype != torch.float32:
+                d_feats = d_feats.to(ctx.feat_dtype)
         d_deconv_w = d_wd.view(2, 2, 2, out_dim, 256).permute(4, 3, 0, 1, 2)
         d_deconv_b = d_b8.view(8, out_dim).sum(0)
-        return (dcond, None, None, None, None, d_pos, d_nw, d_nb, d_deconv_w, d_deconv_b, *grads)
+        return (d_feats, None, None, None, None, d_pos, d_nw, d_nb, d_deconv_w, d_deconv_b, *grads)
 
 
 class GroupAttBlock(nn.Module):
@@ -307,7 +345,6 @@ class VolTransformer(nn.Module):
         B, V, C, D = image_feats.shape[:4]
         if D != self.n_groups[0] or V != 4:
             raise RuntimeError("kernels are specialised for one image-feature voxel per group and 4 input views")
-        cond = image_feats.float().permute(0, 3, 4, 5, 1, 2).reshape(B * D ** 3, V, C)   # network.py:145-150
         flat = [p for layer in self.layers for p in layer.flat_params()]
-        return _VolTransFn.apply(cond, float(self.layers[0].norm1.eps), float(self.norm.eps), self.vol_low_res, self.out_dim,
+        return _VolTransFn.apply(image_feats, float(self.layers[0].norm1.eps), float(self.norm.eps), self.vol_low_res, self.out_dim,
                                  self.pos_embed, self.norm.weight, self.norm.bias, self.deconv.weight, self.deconv.bias, *flat)
