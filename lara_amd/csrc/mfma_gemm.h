@@ -340,16 +340,51 @@ gemm_bf16_nt_kernel(const GemmP p) {
 //   * K tiles (32 channels of one tap: A 256 rows x 64 B, W 256 rows x 64 B = 32 KB) travel global ->
 //     LDS with global_load_lds_dwordx4: no staging registers, no ds_write; every wave issues 4 of the 32
 //     one-KB pieces of a tile;
-//   * a ring of four tile buffers keeps three tiles in flight: iteration kt waits for its own four
-//     pieces of tile kt with a COUNTED vmcnt (8 younger pieces stay in flight), one barrier makes
-//     everybody's pieces visible and retires the reads of tile kt-1, whose buffer is then refilled
-//     with tile kt+3;
+//   * a ring of four tile buffers keeps three tiles in flight behind the one being multiplied: the
+//     barrier that publishes tile kt+1 sits between the two K steps of tile kt (two-phase schedule,
+//     see the main loop), each wave waits for its own four pieces with a COUNTED vmcnt (8 younger
+//     pieces stay in flight), and tile kt's buffer is refilled with tile kt+4 right after it;
 //   * LDS rows are 64 B, unpadded (the DMA writes lane-linear); the 16-byte chunk index is XORed with
 //     (row >> 2) & 3 on the SOURCE address and on the fragment reads, which spreads the rows a
 //     ds_read_b128 lane group touches over all four chunk slots.
 constexpr int RT = 256;             // tile rows (M) and columns (N)
 constexpr int RING = 4;             // tile buffers
 constexpr int RTILE = 2 * RT * 64;  // bytes per K tile: A panel + W panel
+
+// Epilogue of the 256 x 256 ring kernels, through LDS (32 x 64 per wave per trip): the same fused variants as
+// gemm_bf16_nt_kernel.  Wave tile: rows wr * 128 .., columns wc * 64 ..; the caller has synchronised the workgroup
+// after its last fragment read (the ring is reused as the bounce buffer).
+template <int EPI>
+__device__ __forceinline__ void ring_epilogue(const GemmP &p, f32x16 (&acc)[4][2], unsigned char *ring, const int wave,
+                                              const int lane, const int bm0, const int bn0, const int wr, const int wc) {
+    const int M = p.M, N = p.N;
+    const int r = lane & 31, kh = lane >> 5;
+    float *ep = (float *)ring + wave * (32 * 68);
+    unsigned long long *rowbase = (unsigned long long *)((float *)ring + 8 * (32 * 68)) + wave * 32;  // EPI 5
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][j][e];
+        if (EPI == 5 && lane < 32) {
+            int b, d, h, w;
+            token_to_voxel(min(bm0 + wr * 128 + i * 32 + lane, M - 1), p.R, b, d, h, w);
+            const size_t R2 = 2 * (size_t)p.R;
+            rowbase[lane] = (((size_t)b * R2 + 2 * d) * R2 + 2 * h) * R2 + 2 * w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
+            const int row = bm0 + wr * 128 + i * 32 + lr, col = bn0 + wc * 64 + c4;
+            if (row < M && col < N)
+                gemm_epilogue<EPI>(p, *(const float4 *)(ep + lr * 68 + c4), row, col, N, EPI == 5 ? rowbase[lr] : 0ull);
+        }
+    }
+}
 
 template <int AMODE, int EPI>
 __global__ void __launch_bounds__(512)
@@ -386,7 +421,7 @@ gemm_ring_kernel(const GemmP p) {
     const int ktiles = K / 32, kpt = AMODE ? Cin / 32 : 1;
     int cur_tap = -1;
     auto issue = [&](const int kt) {  // this wave's four pieces of K tile kt
-        const int tap = AMODE ? kt / kpt : 0, kc = AMODE ? kt - tap * kpt : kt;
+        const int tap = AMODE ? kt / kpt : 0, kc = AMODE ? kt - tap * kpt : kt, ksrc = kt;
         if (AMODE == 1 && tap != cur_tap) {
             cur_tap = tap;
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
@@ -403,7 +438,7 @@ gemm_ring_kernel(const GemmP p) {
         for (int q = 0; q < 2; q++) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ab + (noff[q] + (uint32_t)kc * 64)),
                                              (__attribute__((address_space(3))) void *)(buf + (2 * wave + q) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Wb + (woff[q] + (uint32_t)kt * 64)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Wb + (woff[q] + (uint32_t)ksrc * 64)),
                                              (__attribute__((address_space(3))) void *)(buf + RT * 64 + (2 * wave + q) * 1024), 16, 0, 0);
         }
     };
@@ -432,64 +467,68 @@ gemm_ring_kernel(const GemmP p) {
         }
     }
 
+    // Two-phase schedule.  A K tile is two K steps of eight MFMAs; the fragments of a step are fetched from LDS while
+    // the eight MFMAs of the step before run (256 matrix-core cycles of cover), and the barrier that publishes tile
+    // kt+1 sits BETWEEN the two steps of tile kt: by then every fragment of tile kt is in registers (lgkmcnt(0) is free,
+    // its reads were issued a step ago), so tile kt's buffer is refilled with tile kt+4 right after the barrier --
+    // three tiles stay in flight -- and the matrix cores always have a step's worth of issued work behind them.
+    bf16x8 fa[2][4], fb[2][2];
+    auto fetch = [&](const int set, const int kt, const int step) {
+        const unsigned char *buf = ring + (kt % RING) * RTILE;
+#pragma unroll
+        for (int i = 0; i < 4; i++) fa[set][i] = *(const bf16x8 *)(buf + aoff[i][step]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) fb[set][j] = *(const bf16x8 *)(buf + boff[j][step]);
+    };
+    auto mac = [&](const int set, const int i0, const int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    auto wait_tile = [&](const int younger) {   // my pieces of a tile have landed once only `younger` newer tiles are in flight
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     issue(0);
     if (1 < ktiles) issue(1);
     if (2 < ktiles) issue(2);
+    if (3 < ktiles) issue(3);
+    wait_tile(min(ktiles - 1, 3));
+    __builtin_amdgcn_s_barrier();
+    fetch(0, 0, 0);
+    // (The fetches are issued after the first two MFMAs of a step, not before them: the compiler's waitcnt pass puts
+    // lgkmcnt(0) in front of the step's first MFMA at this loop's joins, which would otherwise wait for the fetch
+    // just issued instead of the one a step old.)
     for (int kt = 0; kt < ktiles; kt++) {
-        // my four pieces of tile kt have landed once at most the pieces of the tiles issued after it
-        // (two tiles = 8 pieces, fewer at the tail) are still in flight
-        const int younger = min(ktiles - 1 - kt, 2);
-        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // all pieces of tile kt visible; all reads of tile kt-1 retired
-        if (kt + 3 < ktiles) issue(kt + 3);
-        const unsigned char *buf = ring + (kt % RING) * RTILE;
-        bf16x8 a[2][4], b[2][2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[s2][i] = *(const bf16x8 *)(buf + aoff[i][s2]);
-#pragma unroll
-            for (int j = 0; j < 2; j++) b[s2][j] = *(const bf16x8 *)(buf + boff[j][s2]);
+        mac(0, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1, kt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mac(0, 1, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all of tile kt is in registers
+        if (kt + 1 < ktiles) {
+            wait_tile(min(ktiles - 2 - kt, 2));
+            __builtin_amdgcn_s_barrier();   // tile kt+1 visible to everybody; nobody reads tile kt's buffer any more
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2][i], b[s2][j], acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads done before the next barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mac(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < ktiles) {
+            if (kt + 4 < ktiles) issue(kt + 4);
+            fetch(0, kt + 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mac(1, 1, 4);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
 
-    // epilogue through LDS (32 x 64 per wave per trip), the same fused variants as gemm_bf16_nt_kernel
-    float *ep = (float *)ring + wave * (32 * 68);
-    unsigned long long *rowbase = (unsigned long long *)((float *)ring + 8 * (32 * 68)) + wave * 32;  // EPI 5
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = acc[i][j][e];
-        if (EPI == 5 && lane < 32) {
-            int b, d, h, w;
-            token_to_voxel(min(bm0 + wr * 128 + i * 32 + lane, M - 1), p.R, b, d, h, w);
-            const size_t R2 = 2 * (size_t)p.R;
-            rowbase[lane] = (((size_t)b * R2 + 2 * d) * R2 + 2 * h) * R2 + 2 * w;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
-            const int row = bm0 + wr * 128 + i * 32 + lr, col = bn0 + wc * 64 + c4;
-            if (row < M && col < N)
-                gemm_epilogue<EPI>(p, *(const float4 *)(ep + lr * 68 + c4), row, col, N, EPI == 5 ? rowbase[lr] : 0ull);
-        }
-    }
+    ring_epilogue<EPI>(p, acc, ring, wave, lane, bm0, bn0, wr, wc);
 }
 
 // host-side launch of the ring kernel (dynamic LDS above the 64 KB default needs the attribute once)
