@@ -87,6 +87,11 @@ int lara_tokens_from_volume(int32_t scenes, int32_t R, int32_t C, const float *v
 int lara_volume_from_tokens(int32_t scenes, int32_t R, int32_t C, const float *tokens, float *volume,
                             void *stream);
 
+/* C[M, N] = A[M, K] . W[N, K]^T, bf16 operands, fp32 accumulate, on the 256 x 256 LDS-DMA ring kernel; C is bf16, or
+ * fp32 when c_fp32 != 0.  K % 32 == 0; operands below 4 GB.  (The all-layers dcond product of the training path.) */
+int lara_gemm_nt_bf16(int32_t M, int32_t N, int32_t K, const uint16_t *A, const uint16_t *W, void *C, int32_t c_fp32,
+                      void *stream);
+
 /* dst[b][c][r] = src[b][r][c] for `batch` row-major fp32 [rows, cols] matrices; dst is fp32, or bf16 (round to
  * nearest even) when dst_bf16 != 0.  VolTransformer.forward's `b v c d h w -> (b d h w) v c` rearrangement of the
  * image features fused with their bf16 cast (network.py:145-150: rows = v * c, cols = d * h * w) and, with rows and
@@ -136,7 +141,12 @@ int lara_groupblock_forward_train(int32_t scenes, int32_t R, int32_t cond_dim, c
 int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
                              const uint16_t *cond_bf16, const lara_groupblock_weights *w,
                              const lara_groupblock_weights_t *wt, const void *saved, float *g, float *dcond,
-                             const lara_groupblock_grads *dw, int32_t chained, void *workspace, void *stream);
+                             const lara_groupblock_grads *dw, int32_t chained, uint16_t *dkv, int32_t lddkv,
+                             void *workspace, void *stream);
+/* dkv != NULL: leave dL/d(K|V) of this block there (rows of 512 bf16, `lddkv` elements apart; lddkv >= 512,
+ * lddkv % 8 == 0) and do NOT touch dcond (which may then be NULL).  The same cond feeds every layer
+ * (network.py:152-155): the caller forms dcond = [dkv of all layers] . [wkv of all layers] in ONE product after the
+ * sweep (lara_gemm_nt_bf16, K = layers * 512) instead of one read-modify-write of the fp32 dcond tensor per layer. */
 /* chained != 0: this call continues a backward sweep -- `workspace` was last used by a lara_groupblock_backward call
  * with the same (scenes, R) whose output g is this call's input g, and nothing touched either since.  The call then
  * reuses what that call left in the workspace (the bf16 copy of g its last LayerNorm backward wrote, the convolution's

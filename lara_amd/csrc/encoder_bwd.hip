@@ -504,7 +504,7 @@ deconv_grad_gather_kernel(const float *__restrict__ dout, unsigned short *__rest
 __global__ void __launch_bounds__(256)
 group_attn_bwd_kernel(const unsigned short *__restrict__ Q, const unsigned short *__restrict__ KV,
                       const unsigned short *__restrict__ dO, unsigned short *__restrict__ dQ,
-                      unsigned short *__restrict__ dKV, const int G) {
+                      unsigned short *__restrict__ dKV, const int G, const int lddkv /* elements between dK|dV rows (>= 512) */) {
     __shared__ __attribute__((aligned(16))) unsigned short s_q[2][8 * 256], s_do[2][8 * 256], s_kv[2][4 * 512], s_dq[2][8 * 256];
     __shared__ float s_p[2][16 * 8 * 4], s_ds[2][16 * 8 * 4];
     const int gl = threadIdx.x >> 7, t = threadIdx.x & 127;
@@ -583,9 +583,11 @@ group_attn_bwd_kernel(const unsigned short *__restrict__ Q, const unsigned short
     }
     __syncthreads();
     if (active) {
-        uint4 *oq = (uint4 *)(dQ + (size_t)g * 8 * 256), *ok = (uint4 *)(dKV + (size_t)g * 4 * 512);
+        uint4 *oq = (uint4 *)(dQ + (size_t)g * 8 * 256);
+        // (dK|dV rows: 64 uint4 each, `lddkv` elements apart; t and t + 128 are rows t >> 6 and 2 + (t >> 6))
+        unsigned short *ok = dKV + ((size_t)g * 4 + (t >> 6)) * lddkv + (t & 63) * 8;
         oq[t] = ((const uint4 *)s_dq[gl])[t]; oq[t + 128] = ((const uint4 *)s_dq[gl])[t + 128];
-        ok[t] = ((const uint4 *)s_kv[gl])[t]; ok[t + 128] = ((const uint4 *)s_kv[gl])[t + 128];
+        *(uint4 *)ok = ((const uint4 *)s_kv[gl])[t]; *(uint4 *)(ok + 2 * (size_t)lddkv) = ((const uint4 *)s_kv[gl])[t + 128];
     }
 }
 
@@ -778,11 +780,13 @@ int lara_groupblock_forward_train(int32_t scenes, int32_t R, int32_t cond_dim, c
 int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const float *x_in,
                              const uint16_t *cond_bf16, const lara_groupblock_weights *w,
                              const lara_groupblock_weights_t *wt, const void *saved, float *g, float *dcond,
-                             const lara_groupblock_grads *dw, int32_t chained, void *workspace, void *stream) {
+                             const lara_groupblock_grads *dw, int32_t chained, uint16_t *dkv_ext, int32_t lddkv,
+                             void *workspace, void *stream) {
     if (scenes < 0 || R < 4 || (R & 1) || cond_dim <= 0 || (cond_dim % 32) != 0 || !block_weights_ok(w) || !wt || !dw)
         return LARA2DGS_E_INVALID;
     if (scenes == 0) return LARA2DGS_OK;
-    if (!x_in || !cond_bf16 || !g || !dcond || !workspace) return LARA2DGS_E_INVALID;
+    if (!x_in || !cond_bf16 || !g || (!dcond && !dkv_ext) || !workspace) return LARA2DGS_E_INVALID;
+    if (dkv_ext && (lddkv < 512 || (lddkv & 7))) return LARA2DGS_E_INVALID;
     if (!wt->wq_t || !wt->wkv_t || !wt->wo_t || !wt->w1_t || !wt->w2_t ||
         !wt->wconv_t || !dw->ln1_w || !dw->ln1_b || !dw->wq || !dw->wkv || !dw->wo || !dw->ln2_w || !dw->ln2_b ||
         !dw->w1 || !dw->b1 || !dw->w2 || !dw->b2 || !dw->ln3_w || !dw->ln3_b || !dw->wconv)
@@ -807,7 +811,10 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     unsigned short *z = (unsigned short *)(sv + S.z);  // (read only; the GEMM parameter block is not const-correct)
     const float *x1 = (const float *)(sv + S.x1), *x2 = (const float *)(sv + S.x2);
     unsigned short *gb = (unsigned short *)(ws + L.gb);
-    unsigned short *dzb = (unsigned short *)(ws + L.dzb), *dq = (unsigned short *)(ws + L.dq), *dkv = (unsigned short *)(ws + L.dkv);
+    unsigned short *dzb = (unsigned short *)(ws + L.dzb), *dq = (unsigned short *)(ws + L.dq);
+    // dK|dV: into the caller's all-layers buffer (its dcond product runs once, after the sweep) or into the workspace
+    unsigned short *dkv = dkv_ext ? dkv_ext : (unsigned short *)(ws + L.dkv);
+    const int ld_dkv = dkv_ext ? lddkv : 512;
     unsigned short *dob = (unsigned short *)(ws + L.dob);
     float *tmpf = (float *)(ws + L.tmpf);
     float *lnpart = (float *)(ws + L.lnpart), *tnpart = (float *)(ws + L.tnpart);
@@ -856,15 +863,15 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     {
         L2D_PROF("gbb_dx_attn", s);
         gemm_nt<0>(gb, wt->wo_t, dob, M, 256, 256, nullptr, nullptr, s);
-        hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, s, q, kv, dob, dq, dkv, G);
-        gemm_nt<1>(dkv, wt->wkv_t, dcond, Mkv, cond_dim, 512, dcond, nullptr, s);
+        hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, s, q, kv, dob, dq, dkv, G, ld_dkv);
+        if (!dkv_ext) gemm_nt<1>(dkv, wt->wkv_t, dcond, Mkv, cond_dim, 512, dcond, nullptr, s);
         gemm_nt<8>(dq, wt->wq_t, tmpf, M, 256, 256, nullptr, nullptr, s);
     }
     {
         L2D_PROF("gbb_dw_attn", s);
         if ((rc = gemm_tn(gb, 256, 256, o, 256, 256, 1, nullptr, M, dw->wo, tnpart, s))) return rc;
         if ((rc = gemm_tn(dq, 256, 256, xn1, 256, 256, 1, nullptr, M, dw->wq, tnpart, s))) return rc;
-        if ((rc = gemm_tn(dkv, 512, 512, cond_bf16, cond_dim, cond_dim, 1, nullptr, Mkv, dw->wkv, tnpart, s))) return rc;
+        if ((rc = gemm_tn(dkv, ld_dkv, 512, cond_bf16, cond_dim, cond_dim, 1, nullptr, Mkv, dw->wkv, tnpart, s))) return rc;
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
@@ -915,6 +922,20 @@ int lara_voltrans_head_backward(int32_t scenes, int32_t R, const float *x, const
 
 /* ---- unit entry points (parity tests of the individual kernels) ---- */
 
+int lara_gemm_nt_bf16(int32_t M, int32_t N, int32_t K, const uint16_t *A, const uint16_t *W, void *C, int32_t c_fp32,
+                      void *stream) {
+    if (M < 0 || N < 0 || K <= 0 || (K & 31)) return LARA2DGS_E_INVALID;
+    if (M == 0 || N == 0) return LARA2DGS_OK;
+    if (!A || !W || !C) return LARA2DGS_E_INVALID;
+    if ((size_t)M * K * 2 >= (1ull << 32) || (size_t)N * K * 2 >= (1ull << 32)) return LARA2DGS_E_INVALID;  // 32-bit operand offsets
+    GemmP p{};
+    p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K;
+    const hipError_t e = c_fp32 ? launch_gemm_ring<0, 8>(p, (hipStream_t)stream) : launch_gemm_ring<0, 0>(p, (hipStream_t)stream);
+    if (e != hipSuccess) { l2d_set_hip_error(e); return LARA2DGS_E_LAUNCH; }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
 int lara_gemm_tn_bf16(int32_t M, int32_t N, int32_t Kc, const uint16_t *A, const uint16_t *B, float *dst,
                       void *workspace, void *stream) {
     if (M <= 0 || N <= 0 || Kc <= 0 || !A || !B || !dst || !workspace) return LARA2DGS_E_INVALID;
@@ -935,7 +956,7 @@ int lara_groupattn_core_backward(int32_t G, const uint16_t *q, const uint16_t *k
     if (G < 0) return LARA2DGS_E_INVALID;
     if (G == 0) return LARA2DGS_OK;
     if (!q || !kv || !d_o || !dq || !dkv) return LARA2DGS_E_INVALID;
-    hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, (hipStream_t)stream, q, kv, d_o, dq, dkv, G);
+    hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, (hipStream_t)stream, q, kv, d_o, dq, dkv, G, 512);
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }

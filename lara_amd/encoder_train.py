@@ -47,7 +47,10 @@ def _lib():
         lib.lara_groupblock_backward_workspace_bytes.argtypes = [i32, i32]
         lib.lara_groupblock_backward.restype = ctypes.c_int
         lib.lara_groupblock_backward.argtypes = [i32, i32, i32, vp, vp, ctypes.POINTER(_BlockWeights),
-                                                 ctypes.POINTER(_BlockWeightsT), vp, vp, vp, ctypes.POINTER(_BlockGrads), i32, vp, vp]
+                                                 ctypes.POINTER(_BlockWeightsT), vp, vp, vp, ctypes.POINTER(_BlockGrads), i32,
+                                                 vp, i32, vp, vp]
+        lib.lara_gemm_nt_bf16.restype = ctypes.c_int
+        lib.lara_gemm_nt_bf16.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp]
         lib.lara_batched_transpose.restype = ctypes.c_int
         lib.lara_batched_transpose.argtypes = [i32, i32, i32, vp, vp, i32, vp]
         lib.lara_groupblock_save_bytes.restype = i64
@@ -188,8 +191,9 @@ class _VolTransFn(torch.autograd.Function):
             _check(int(nsave), "lara_groupblock_save_bytes")
         ws = None if keep else _workspace(dev, "fwd", lib.lara_groupblock_workspace_bytes(B, R))
         with torch.cuda.device(dev):
+            fs = [_layer_bf16([t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]]) for l in range(n_layers)]
             for l in range(n_layers):
-                f = _layer_bf16([t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]])
+                f = fs[l]
                 w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
                 w.eps = eps_block
                 if keep:   # out of place; the block's intermediates stay in HBM for the backward
@@ -237,7 +241,11 @@ class _VolTransFn(torch.autograd.Function):
         g = torch.empty(M, 256, **f32)
         d_nw, d_nb = torch.zeros(256, **f32), torch.zeros(256, **f32)
         d_wd, d_b8 = torch.zeros(8 * out_dim, 256, **f32), torch.zeros(8 * out_dim, **f32)
-        dcond = torch.zeros(cond_bf.shape, **f32)
+        # every block leaves its dK|dV in its 512 columns of ONE buffer; dcond is one product after the sweep
+        # (the same cond feeds every layer) instead of a read-modify-write of the fp32 dcond per layer
+        lddkv = n_layers * 512
+        dkv_all = torch.empty(cond_bf.shape[0] * cond_bf.shape[1], lddkv, dtype=torch.bfloat16, device=dev)
+        dcond = torch.empty(cond_bf.shape, **f32)
         grads = [None] * (n_layers * _NLP)
         # every layer's 14 gradient accumulators carved from ONE zero-filled buffer (one fill, not 14 per layer)
         shapes = {n: tuple(ctx.saved_w[0][n].shape) if ctx.saved_w else None for n in _GRAD_FIELDS}
@@ -272,12 +280,17 @@ class _VolTransFn(torch.autograd.Function):
                 act = ctx.saved_act[l].data_ptr() if ctx.saved_act else None
                 _check(lib.lara_groupblock_backward(B, R, cond_dim, saved_x[l].data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
                                                     ctypes.byref(wt), act, g.data_ptr(), dcond.data_ptr(), ctypes.byref(dw),
-                                                    int(l != n_layers - 1), ws.data_ptr(), _stream(dev)),
-                       "lara_groupblock_backward")
+                                                    int(l != n_layers - 1), dkv_all.data_ptr() + l * 1024, lddkv,
+                                                    ws.data_ptr(), _stream(dev)), "lara_groupblock_backward")
                 grads[l * _NLP:(l + 1) * _NLP] = [
                     gd["ln1_w"], gd["ln1_b"], gd["wq"], gd["wkv"][:256], gd["wkv"][256:], gd["wo"], gd["ln2_w"], gd["ln2_b"],
                     gd["w1"], gd["b1"], gd["w2"], gd["b2"], gd["ln3_w"], gd["ln3_b"],
                     gd["wconv"].view(256, 3, 3, 3, 256).permute(0, 4, 1, 2, 3)]
+            # dcond [rows, C] = dkv_all [rows, L * 512] . wkv_all [L * 512, C]
+            wkv_all_t = torch.cat([(ctx.saved_w[l] if ctx.saved_w else _layer_bf16(
+                [t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]]))["wkv"] for l in range(n_layers)], 0).t().contiguous()
+            _check(lib.lara_gemm_nt_bf16(dkv_all.shape[0], cond_dim, lddkv, dkv_all.data_ptr(), wkv_all_t.data_ptr(),
+                                         dcond.data_ptr(), 1, _stream(dev)), "lara_gemm_nt_bf16")
             # the same positional rows enter every scene (network.py:152)
             d_pos = tokens_to_volume(g.view(B, R ** 3, 256).sum(0), 1, R)
             # dL/d(image_feats): the rearrangement's backward, [d h w, v c] -> [v c, d h w] per scene
