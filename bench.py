@@ -131,6 +131,13 @@ def fine_subsets(scenes):
         return [(torch.sigmoid(sc["opacity"].detach()).squeeze(-1) > FINE_OPACITY).nonzero().squeeze(-1) for sc in scenes]
 
 
+def view_lanes_for(n_streams):
+    """Lanes of the library's multi-view calls: its second lane fills the device when ONE stream feeds it (1341 vs the
+    loop's 1012 frames/s); with two scene streams the application fills it already and the second lane only costs
+    (raster alone 1383 -> 1421, training step 762 -> 786 frames/s; profiles/README.md)."""
+    return 1 if n_streams >= 2 else 2
+
+
 def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="loop"):
     """All forwards of the batch, then one backward through every view (as loss.backward() does).
     Per scene: the coarse views (network.py:487-497) and, with `fine_idx`, the fine views over the masked subset with
@@ -142,6 +149,9 @@ def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="
     api = "views": the views of a scene and pass go through ONE multi-view call (one autograd node; activations and
     subset gathers once per scene, as `lara_amd.renderer.Renderer.render_views` does) instead of one call per view."""
     from lara_amd import GaussianRasterizer, rasterize_gaussians_views
+    from lara_amd import rasterizer as _rz
+    if api == "views" and "LARA2DGS_VIEW_STREAMS" not in os.environ:
+        _rz.set_view_lanes(view_lanes_for(n_streams))
     outs, grads = [], []
     cur = torch.cuda.current_stream()
     while len(_streams) < n_streams and n_streams > 1:
@@ -1039,8 +1049,10 @@ def main():
             "frames_per_step": frames_per_step,
             "parallelism": f"dp{joined} (per-scene; raster not sharded)",
             "hip_streams": args.streams,
-            "raster_api": ("views: one multi-view rasteriser call per scene and pass (opt-in lara_amd API; the library runs the "
-                           "views on its own side streams)" if args.raster_api == "views" else
+            "view_lanes": (int(os.environ["LARA2DGS_VIEW_STREAMS"]) if "LARA2DGS_VIEW_STREAMS" in os.environ
+                           else view_lanes_for(args.streams)) if args.raster_api == "views" else None,
+            "raster_api": ("views: one multi-view rasteriser call per scene and pass (opt-in lara_amd API; `view_lanes` "
+                           "streams per call)" if args.raster_api == "views" else
                            "loop: one GaussianRasterizer call per view (the reference's loop)"),
             "grad_allreduce": info["grad_allreduce"],
         },

@@ -151,6 +151,11 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
  * n_scratch transient buffers of scratch_stride bytes each (>= lara2dgs_scratch_bytes); n_scratch bounds the number of views in flight.  With
  * n_scratch >= n_views the per-surfel preprocess of ALL cameras is ONE launch (camera = fast index of the workgroup id:
  * the surfels' inputs are read from HBM once), and the lanes run binning + composite only. */
+/* Lanes of the multi-view calls from now on (1..8; the only process-wide setting of the library, initialised from
+ * LARA2DGS_VIEW_STREAMS, default 2).  Two lanes pay when ONE stream feeds the device; an application that already
+ * issues from two streams (one per scene) is better off with 1 (measured: training step 762 -> 786 frames/s).
+ * Returns the previous value. */
+int lara2dgs_set_view_lanes(int32_t lanes);
 int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                            const float *shs, const float *colors_precomp, const float *opacities,
                            const float *scales, const float *rotations, const float *transmat_precomp,

@@ -264,38 +264,35 @@ constexpr int MAX_SIDE = 8;
 // stream (process-wide map: PyTorch replays the backward on its autograd thread, on the forward's stream -- both
 // directions share the lanes, and two caller streams never funnel into the same side stream).
 struct SidePool {
-    int n = 0;   // side streams (= lanes - 1)
+    int n = 0;   // side streams created so far
     hipStream_t s[MAX_SIDE];
-    hipEvent_t fork, join[MAX_SIDE];
+    hipEvent_t fork = nullptr, join[MAX_SIDE];
 };
 std::mutex g_side_mu;
 std::map<std::pair<int, hipStream_t>, SidePool> g_side;
 
-int lane_count() {
-    static const int n = [] {
-        const char *e = getenv("LARA2DGS_VIEW_STREAMS");
-        int k = e ? atoi(e) : 2;
-        return k < 1 ? 1 : (k > MAX_SIDE ? MAX_SIDE : k);
-    }();
-    return n;
-}
+// lanes of a multi-view call (>= 1): LARA2DGS_VIEW_STREAMS at load (default 2), lara2dgs_set_view_lanes at run time
+std::atomic<int> g_lanes{[] {
+    const char *e = getenv("LARA2DGS_VIEW_STREAMS");
+    const int k = e ? atoi(e) : 2;
+    return k < 1 ? 1 : (k > MAX_SIDE ? MAX_SIDE : k);
+}()};
 
-// the side streams of `caller` on the current device (created on first use, kept for the life of the process)
-SidePool *side_pool(hipStream_t caller) {
+// the side streams of `caller` on the current device (created on first use, grown on demand, kept for the life of
+// the process); the returned copy holds at least lanes - 1 of them
+bool side_pool(hipStream_t caller, int lanes, SidePool *out) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lk(g_side_mu);
-    auto it = g_side.find({dev, caller});
-    if (it != g_side.end()) return &it->second;
-    SidePool p;
-    const int n = lane_count() - 1;
-    if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    for (int i = 0; i < n; i++) {
-        if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    SidePool &p = g_side[{dev, caller}];
+    if (!p.fork && hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return false;
+    while (p.n < lanes - 1) {
+        if (hipStreamCreateWithFlags(&p.s[p.n], hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&p.join[p.n], hipEventDisableTiming) != hipSuccess) return false;
+        p.n++;
     }
-    p.n = n;
-    return &(g_side[{dev, caller}] = p);
+    *out = p;
+    return true;
 }
 
 #define HIP_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { l2d_set_hip_error(e__); return LARA2DGS_E_LAUNCH; } } while (0)
@@ -339,6 +336,11 @@ __global__ void __launch_bounds__(256) sum_slices_kernel(const float4 *__restric
 
 extern "C" {
 
+int lara2dgs_set_view_lanes(int32_t lanes) {
+    const int k = lanes < 1 ? 1 : (lanes > MAX_SIDE ? MAX_SIDE : lanes);
+    return g_lanes.exchange(k);
+}
+
 int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int32_t has_colors,
                              int32_t has_scale_rot, int32_t has_transmat, lara2dgs_grad_layout *out) {
     if (!out || P < 0 || sh_coeffs < 0) return LARA2DGS_E_INVALID;
@@ -360,11 +362,11 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
         scratch_stride < lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity))
         return LARA2DGS_E_INVALID;
     hipStream_t caller = (hipStream_t)stream;
-    SidePool *pool = side_pool(caller);
-    if (!pool) return LARA2DGS_E_LAUNCH;
-    int lanes = pool->n + 1;
+    int lanes = g_lanes.load();
     if (lanes > n_views) lanes = n_views;
     if (lanes > n_scratch) lanes = n_scratch;
+    SidePool pool_, *pool = &pool_;
+    if (!side_pool(caller, lanes, pool)) return LARA2DGS_E_LAUNCH;
     auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
     const int64_t HW = (int64_t)v0.image_height * v0.image_width;
     int rc = LARA2DGS_OK;
@@ -440,11 +442,11 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
     grad_layout(v0.P, v0.sh_coeffs, has_sh, has_col, has_sr, has_tm, &G);
     hipStream_t caller = (hipStream_t)stream;
     if (v0.P == 0 || G.total == 0) return LARA2DGS_OK;
-    SidePool *pool = side_pool(caller);
-    if (!pool) return LARA2DGS_E_LAUNCH;
-    int lanes = pool->n + 1;
+    int lanes = g_lanes.load();
     if (lanes > n_views) lanes = n_views;
     if (lanes > n_scratch) lanes = n_scratch;
+    SidePool pool_, *pool = &pool_;
+    if (!side_pool(caller, lanes, pool)) return LARA2DGS_E_LAUNCH;
     auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
     const int64_t HW = (int64_t)v0.image_height * v0.image_width;
     auto at = [&](float *base, int64_t off) { return off < 0 ? (float *)nullptr : base + off; };

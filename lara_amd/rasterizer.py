@@ -88,6 +88,8 @@ def load_library():
     lib.lara2dgs_forward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 11 + [i64, vp, i64, i32, vp]
     lib.lara2dgs_backward_views.restype = ctypes.c_int
     lib.lara2dgs_backward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 10 + [i64, vp, i64, i32, vp, vp, vp]
+    lib.lara2dgs_set_view_lanes.restype = ctypes.c_int
+    lib.lara2dgs_set_view_lanes.argtypes = [i32]
     lib.lara2dgs_get_grad_layout.restype = ctypes.c_int
     lib.lara2dgs_get_grad_layout.argtypes = [i32, i32, i32, i32, i32, i32, ctypes.POINTER(GradLayout)]
     lib.lara2dgs_mark_visible.restype = ctypes.c_int
@@ -389,8 +391,21 @@ class _RasterizeGaussians(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # opt-in: all views of a scene in one call
 # ---------------------------------------------------------------------------------------------
+_lanes = None   # lanes of the multi-view calls; None = LARA2DGS_VIEW_STREAMS (default 2), read per call
+
+
+def set_view_lanes(n):
+    """Lanes (streams) a multi-view call spreads its views over: 2 pays when one stream feeds the device, 1 when the
+    application already issues from two streams (one per scene).  None returns to LARA2DGS_VIEW_STREAMS."""
+    global _lanes
+    _lanes = None if n is None else max(1, min(8, int(n)))
+
+
 def _view_lanes() -> int:
-    return max(1, min(8, int(os.environ.get("LARA2DGS_VIEW_STREAMS", "2"))))
+    n = _lanes if _lanes is not None else max(1, min(8, int(os.environ.get("LARA2DGS_VIEW_STREAMS", "2"))))
+    lib = load_library()
+    lib.lara2dgs_set_view_lanes(n)
+    return n
 
 
 def _views_array(settings, P, M, cap, device, prefiltered_bits=None):

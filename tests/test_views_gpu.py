@@ -80,9 +80,15 @@ def test_views_repeatable_and_independent_of_stream_count(monkeypatch):
     c3, g3 = run()
     monkeypatch.delenv("LARA2DGS_VIEW_STREAMS")
     c4, g4 = run()
-    assert torch.equal(c0, c1) and torch.equal(c0, c2) and torch.equal(c0, c3) and torch.equal(c0, c4)
+    monkeypatch.setenv("LARA2DGS_VIEW_STREAMS", "4")   # four lanes, per-lane scratch
+    c5, g5 = run()
+    monkeypatch.delenv("LARA2DGS_VIEWS_BATCH_PREPROCESS")
+    c6, g6 = run()                                      # four lanes, batched preprocess
+    for c in (c1, c2, c3, c4, c5, c6):
+        assert torch.equal(c0, c)
     for k in g0:
-        assert torch.equal(g0[k], g1[k]) and torch.equal(g0[k], g2[k]) and torch.equal(g0[k], g3[k]) and torch.equal(g0[k], g4[k]), k
+        for g in (g1, g2, g3, g4, g5, g6):
+            assert torch.equal(g0[k], g[k]), k
 
 
 def test_views_argument_errors():
