@@ -17,7 +17,9 @@ A *frame* is one rasteriser forward + backward.  `value` 
 max-over-ranks wall time of the timed steps, with scenes, cameras, image features and incoming gradients already
 resident in HBM.  Data is synthetic (no dataset / checkpoint in this environment): SURVEY.md section 8d,
 lara_amd/synthetic.py; the encoder and the raster run on independent synthetic tensors of the right shapes (the
-decoder MLP between them is outside section 8a).  `--step raster` times the raster alone (round 1's definition);
+decoder MLP between them is outside section 8a), but in LaRa's ORDER: the raster's forward is enqueued behind the
+encoder's forward and the encoder's backward behind the raster's backward (stream waits), so the two never overlap on
+the device, as the data dependence through the decoder forbids.  `--step raster` times the raster alone (round 1's definition);
 the default line carries it as `raster_only`.
 
 `python bench.py --gpus N` with N > 1 launches its own N ranks (torch.distributed.run, one per GPU, backend nccl =
@@ -145,7 +147,8 @@ def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="
     subset's coefficients are offset by a constant).  Activations and subset gathers are applied per view, as the
     reference's `render_img` / loop do.  Scenes are independent (the unit the north star data-parallelises over), so
     scene i is enqueued on HIP stream i % n_streams; autograd replays each view's backward on its forward's stream.
-    `after(outs, grads)` appends further roots to the one backward call (the encoder's output and its gradient).
+    `after(outs, grads)` names the roots of a second backward call that runs after the raster's (the encoder's output
+    and its gradient).
     api = "views": the views of a scene and pass go through ONE multi-view call (one autograd node; activations and
     subset gathers once per scene, as `lara_amd.renderer.Renderer.render_views` does) instead of one call per view."""
     from lara_amd import GaussianRasterizer, rasterize_gaussians_views
@@ -200,11 +203,15 @@ def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="
                         render(rs, centers_f, shs_f, sc["opacity"][idx], sc["scales"][idx], sc["rotations"][idx])
     for side in _streams[:n_streams if n_streams > 1 else 0]:
         cur.wait_stream(side)
-    if after is not None:
-        after(outs, grads)
     torch.autograd.backward(outs, grads)
     for side in _streams[:n_streams if n_streams > 1 else 0]:
         cur.wait_stream(side)
+    if after is not None:
+        # the encoder's backward consumes what the raster's backward produces (through the decoder, in LaRa): it is
+        # a second backward call, enqueued behind the scene streams' work, so that the two do not overlap on the device
+        more_outs, more_grads = [], []
+        after(more_outs, more_grads)
+        torch.autograd.backward(more_outs, more_grads)
     for sc in scenes:
         for v in sc.values():
             v.grad = None
@@ -940,7 +947,7 @@ def make_training_step(args, device, rank, world, plumbing):
             raster(None)
             return
         info["_out"] = model(feats)             # 1. encoder forward (DDP: also arms the reducer's hooks)
-        raster(_enc_roots)                      # 2. raster forwards; 3. ONE backward: raster, then encoder (+ all-reduce)
+        raster(_enc_roots)                      # 2. raster forwards; 3. raster backward; 4. encoder backward (+ all-reduce)
         for p in enc.parameters():
             p.grad = None
         info["_out"] = None
