@@ -32,7 +32,8 @@ composite kernels end in a tail of a few heavy tiles; a second stream fills thos
 Extra objects on the JSON line (rank 0, N = 1): "roofline" (dominant kernel, HIP-event timed, algorithmic bytes of
 SURVEY.md section 8d; `bound` says what binds it), "cpu_baseline" (the CPU oracle of the raster AND the fixture-pinned
 fp32 restatement of the reference's encoder, both on this box's host cores), "raster_only", "single_stream",
-"forward_only", "attention", "encoder", "encoder_train", "rays", "render_img", "point_feats", "fine_decoder", "fine_stage".
+"forward_only", "mesh_eval" (configs[4]: 48 views @1024x1024 + TSDF fusion), "attention", "encoder", "encoder_train", "rays",
+"render_img", "point_feats", "fine_decoder", "fine_stage".
 """
 import argparse
 import contextlib
@@ -247,6 +248,59 @@ def forward_only_leg(scenes, settings, args):
     frames = len(scenes) * len(settings) * args.steps
     return {"value": round(frames / dt, 1), "unit": "frames/s",
             "workload": "forward renders only (configs[1]: inference), same scenes and views"}
+
+
+def mesh_eval_leg(args, device):
+    """BASELINE.json configs[4] (eval_all.py / tools/meshExtractor.py:50-110): the mesh path's 48 views of one object at
+    1024x1024, forward only, each batch of 8 fused into the TSDF volume on the device (the reference copies depth,
+    alpha and colour of every view to the host for Open3D).  Trained-like scene (an opaque shell: there is a surface)."""
+    from lara_amd import cameras, synthetic, GaussianRasterizationSettings, rasterize_gaussians_views
+    from lara_amd.tsdf import TSDFVolume
+    res, n_views, chunk, grid = 1024, 48, 8, 256
+    sc = synthetic.make_scene(grid=args.grid, K=2, regime="trained", seed=123, device=device)
+    cams = cameras.make_cameras(cameras.turntable_c2w(n_views), res, res, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8, device=device)
+    settings = [GaussianRasterizationSettings(
+        image_height=res, image_width=res, tanfovx=math.tan(c.FoVx * 0.5), tanfovy=math.tan(c.FoVy * 0.5),
+        bg=torch.ones(3, device=device), scale_modifier=1.0, viewmatrix=c.world_view_transform.contiguous(),
+        projmatrix=c.full_proj_transform.contiguous(), sh_degree=1, campos=c.camera_center.contiguous(), prefiltered=False,
+        debug=False) for c in cams]
+    K = torch.tensor([[res / (2 * math.tan(c.FoVx / 2.0)), res / (2 * math.tan(c.FoVy / 2.0)), res / 2, res / 2] for c in cams],
+                     device=device)
+    ext = torch.stack([c.world_view_transform.T for c in cams]).contiguous()
+    with torch.no_grad():
+        opac, scales = torch.sigmoid(sc["opacity"]), torch.exp(sc["scales"])
+        rots = torch.nn.functional.normalize(sc["rotations"])
+
+    def run(fuse):
+        vol = TSDFVolume((-1.0, -1.0, -1.0), 2.0 / grid, 0.08, grid, device=device) if fuse else None
+        with torch.no_grad():
+            for i in range(0, n_views, chunk):
+                color, _, allmap = rasterize_gaussians_views(settings[i:i + chunk], sc["centers"], None, opac, shs=sc["shs"],
+                                                             scales=scales, rotations=rots)
+                if fuse:   # expected depth = ch0 / ch1 where the ray hit something (renderer_2dgs.py:226-233), else 0
+                    acc = allmap[:, 1]
+                    depth = torch.where(acc < 0.08, torch.zeros_like(acc), allmap[:, 0] / acc.clamp_min(1e-8))
+                    rgb8 = (color.clamp(0, 1).permute(0, 2, 3, 1) * 255).to(torch.uint8).float()
+                    vol.integrate(depth, rgb8, K[i:i + chunk], ext[i:i + chunk], 10.0)
+        return vol
+
+    def timed(fuse):
+        run(fuse)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            vol = run(fuse)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 2, vol
+
+    t_r, _ = timed(False)
+    t_all, vol = timed(True)
+    occupied = int((vol.weight > 0).sum())
+    return {"workload": f"one object: {n_views} views @{res}x{res} forward (multi-view calls of {chunk}), each batch fused into a "
+                        f"{grid}^3 TSDF volume on the device (voxel 2/{grid}, trunc 0.08, alpha threshold 0.08)",
+            "render_frames_per_s": round(n_views / t_r, 1), "ms_per_object_render": round(1e3 * t_r, 2),
+            "ms_per_object_render_and_fuse": round(1e3 * t_all, 2), "tsdf_ms_per_object": round(1e3 * (t_all - t_r), 2),
+            "voxels_observed": occupied}
 
 
 def measure_roofline(scenes, settings, gc, ga, args):
@@ -1104,6 +1158,8 @@ def main():
         finally:
             rasterizer.set_cull_transparent(prev)
         out["forward_only"] = forward_only_leg(scenes, settings, args)
+        if not args.no_side_legs:
+            out["mesh_eval"] = mesh_eval_leg(args, device)
     if rank == 0 and not plumbing and not args.no_roofline:
         scenes, settings, gc, ga, fine_idx = info["raster_state"]
         roof, table, D = measure_roofline(scenes, settings, gc, ga, args)
