@@ -53,6 +53,16 @@ def test_invalid_arguments_return_error_codes_not_crashes(hip_lib):
     assert hip_lib.lara2dgs_mark_visible(4, None, None, None, None, None) == -1
 
 
+def test_view_lanes_setting_round_trips(hip_lib):
+    """The one process-wide setting of the library: lanes of the multi-view calls, clamped to 1..8; the setter returns
+    the previous value (host-side state only, no GPU needed)."""
+    prev = hip_lib.lara2dgs_set_view_lanes(3)
+    assert 1 <= prev <= 8
+    assert hip_lib.lara2dgs_set_view_lanes(100) == 3
+    assert hip_lib.lara2dgs_set_view_lanes(0) == 8
+    assert hip_lib.lara2dgs_set_view_lanes(prev) == 1
+
+
 def test_operator_refuses_cpu_tensors_and_has_no_fallback(hip_lib):
     import torch
     from tests.helpers import small_scene, raster_settings
