@@ -436,6 +436,13 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 // ------------------------------------------------------------------------------------------------
 // quad (4-lane) reduce-scatter of 22 per-lane values with DPP quad_perm
 // ------------------------------------------------------------------------------------------------
+// v_mul_legacy_f32: 0 * anything (inf, NaN) = 0; every other product as v_mul_f32
+__device__ __forceinline__ float mul_legacy(const float a, const float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_full(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
@@ -730,7 +737,12 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     // lanes keep their state and contribute exact zeros.
                     const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
                     const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
-                    const float alpha = h.alpha, c_d = h.depth;
+                    // An inactive lane runs the recurrences with alpha = 0, which leaves its state where the next active
+                    // entry would have put it anyway: T / (1 - 0) = T; the collapsed "what lies behind" recurrence
+                    // becomes (accum_new, *, 0) and the next step's 0 * last_g + 1 * accum_new reproduces accum_new
+                    // bit for bit; last_dL_dT likewise.  One select (alpha) instead of five state selects; the two
+                    // products whose other factor may be garbage on such a lane are legacy multiplies (0 * NaN = 0).
+                    const float alpha = active ? h.alpha : 0.f, c_d = h.depth;
                     const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float T_new = T * inv_1ma;
                     const float w = alpha * T_new;
@@ -741,7 +753,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2] +
                                        nrm[0] * dnrm[0] + nrm[1] * dnrm[1] + nrm[2] * dnrm[2] +
                                        c_d * dL_ddepth + dL_daccum;
-                    const float accum_new = last_alpha * last_g + (1.f - last_alpha) * accum_g;
+                    const float accum_new = mul_legacy(last_alpha, last_g) + (1.f - last_alpha) * accum_g;
                     float dL_dalpha = gval - accum_new;
                     float dL_dz = 0.0f;
                     const float inv_cd = __builtin_amdgcn_rcpf(c_d);
@@ -750,34 +762,40 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     if (contributor + 1 == median_contributor) dL_dz += dL_dmedian;
                     const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.f * m_d * final_D) * dL_dreg;
                     dL_dalpha += dL_dweight - last_dL_dT;
-                    const float dLdT_new = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                    const float dLdT_new = mul_legacy(alpha, dL_dweight) + (1.f - alpha) * last_dL_dT;
                     const float dL_dmd = 2.0f * (T_new * alpha) * (m_d * final_A - final_D) * dL_dreg;
                     dL_dz += dL_dmd * dmd_dd;
                     dL_dalpha *= T_new;
                     dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
                     dL_dz += w * dL_ddepth;
-                    T = active ? T_new : T;
-                    accum_g = active ? accum_new : accum_g;
-                    last_g = active ? gval : last_g;
-                    last_alpha = active ? alpha : last_alpha;
-                    last_dL_dT = active ? dLdT_new : last_dL_dT;
+                    T = T_new;
+                    accum_g = accum_new;
+                    last_g = gval;
+                    last_alpha = alpha;
+                    last_dL_dT = dLdT_new;
                     // this pixel's 22 coefficient-space partials (zeros when inactive) ...
-                    const float ww = active ? w : 0.f, da = active ? dL_dalpha : 0.f, dz = active ? dL_dz : 0.f;
-                    const float sx = active ? h.sx : 0.f, sy = active ? h.sy : 0.f, rz = active ? h.rz : 0.f;
+                    // An inactive lane's sx, sy, rz may be inf / NaN (pz = 0); every product they enter has a factor
+                    // that IS zero there (dz, qG, dpx, dpy, rz3), and v_mul_legacy_f32 (0 * anything = 0) keeps the
+                    // zero -- three selects fewer than zeroing sx, sy, rz themselves.  Active lanes: same products.
+                    const float ww = w, da = active ? dL_dalpha : 0.f, dz = active ? dL_dz : 0.f;   // (w = 0 when inactive)
+                    const float sx = h.sx, sy = h.sy;
+                    const float rz3 = (active && h.use3d) ? h.rz : 0.f;     // the 3-D branch's 1/pz, else 0
                     float g[22];
                     g[18] = ww * dpix[0]; g[19] = ww * dpix[1]; g[20] = ww * dpix[2];
                     g[14] = ww * dnrm[0]; g[15] = ww * dnrm[1]; g[16] = ww * dnrm[2];
                     // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
-                    g[9] = dz * sx; g[10] = dz * sy; g[11] = dz;
-                    const float qG = opa * da * h.G;  // dL/dG * G
-                    const float dL_dsx = dz * Tw[0] - qG * sx, dL_dsy = dz * Tw[1] - qG * sy;
-                    const float dpx = h.use3d ? dL_dsx * rz : 0.f, dpy = h.use3d ? dL_dsy * rz : 0.f;
-                    const float dpz = -(dpx * sx + dpy * sy);
+                    g[9] = mul_legacy(dz, sx); g[10] = mul_legacy(dz, sy); g[11] = dz;
+                    const float qG = opa * da * h.G;  // dL/dG * G  (G is finite on every lane)
+                    const float dL_dsx = dz * Tw[0] - mul_legacy(qG, sx);
+                    const float dL_dsy = dz * Tw[1] - mul_legacy(qG, sy);
+                    const float dpx = dL_dsx * rz3, dpy = dL_dsy * rz3;
+                    const float dpz = -(mul_legacy(dpx, sx) + mul_legacy(dpy, sy));
                     g[0] = dpx; g[1] = dpy; g[2] = dpz;
                     g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
                     g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
-                    g[12] = h.use3d ? 0.f : -qG * FILTER_INV_SQUARE * h.ddx;
-                    g[13] = h.use3d ? 0.f : -qG * FILTER_INV_SQUARE * h.ddy;
+                    const float qG2 = h.use3d ? 0.f : -FILTER_INV_SQUARE * qG;   // the low-pass branch's share
+                    g[12] = qG2 * h.ddx;
+                    g[13] = qG2 * h.ddy;
                     g[17] = h.G * da;
                     g[21] = ww;  // > 0 marks a block that contributed
                     // ... summed over the quad's 2x2 pixels with a DPP reduce-scatter (each lane ends up
