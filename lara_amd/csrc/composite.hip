@@ -803,6 +803,11 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     // writer per slot
                     float r[6];
                     quad_reduce_scatter(g, r, lane);
+                    // (pin the sums here: left alone, the compiler sinks the second step's adds into the `if (has)` below,
+                    // away from their DPP operand fetches, and pays a v_mov 0 + v_mov_dpp + v_add per value instead of one
+                    // v_add_f32_dpp)
+#pragma unroll
+                    for (int i = 0; i < 6; i++) asm volatile("" : "+v"(r[i]));
                     const unsigned long long lv = s_live[has ? j : 0];
                     const int rank = __builtin_popcount((uint32_t)lv & below_lo) + __builtin_popcount((uint32_t)(lv >> 32) & below_hi);
                     float *ps = pool + ((int)s_base[has ? j : 0] + rank) * SLAB_F + (lane & 3);
