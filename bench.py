@@ -1158,6 +1158,8 @@ def main():
         finally:
             rasterizer.set_cull_transparent(prev)
         out["forward_only"] = forward_only_leg(scenes, settings, args)
+        if "LARA2DGS_VIEW_STREAMS" not in os.environ:
+            rasterizer.set_view_lanes(None)     # the one-stream side legs below: the library's default (two lanes)
         if not args.no_side_legs:
             out["mesh_eval"] = mesh_eval_leg(args, device)
     if rank == 0 and not plumbing and not args.no_roofline:
