@@ -530,7 +530,7 @@ class _RasterizeViews(torch.autograd.Function):
         if g_sh is not None and ctx.shapes[0] is not None:
             g_sh = g_sh.view(ctx.shapes[0])
         g_opac = sec(G.opacities, 1, (P, 1)).view(ctx.shapes[1])
-        return (sec(G.means3D, 3, (P, 3)), sec(G.means2D, 3, (P, 3)), g_sh,
+        return (sec(G.means3D, 3, (P, 3)), sec(G.means2D, 3, (P, 3)) if ctx.needs_input_grad[1] else None, g_sh,
                 sec(G.colors, 3, (P, 3)) if has_col else None, g_opac,
                 sec(G.scales, 2, (P, 2)) if has_sr else None, sec(G.rotations, 4, (P, 4)) if has_sr else None,
                 sec(G.transmat, 9, (P, 9)) if has_tm else None, None)

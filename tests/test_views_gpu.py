@@ -57,6 +57,49 @@ def test_views_match_the_per_view_loop(n_views, size):
         assert torch.equal(got[k], want), f"grad {k}: max diff {(got[k] - want).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("batched", [True, False])
+def test_views_with_precomputed_colour_and_transmat(monkeypatch, batched):
+    """The other input combination of the operator (colors_precomp + cov3D_precomp = the 3x3 splat-to-pixel matrices)
+    through the multi-view call, both backward paths (one folded preprocess_bwd launch / per-view slices + summation):
+    outputs and gradients equal the per-view operator's.  The matrices are one camera's (from the oracle's preprocess),
+    used for every view: geometrically meaningless for the others, numerically as good a test as any."""
+    from lara_amd import GaussianRasterizer, rasterize_gaussians_views
+    from tests.helpers import oracle_view, run_oracle, to_numpy
+    if not batched:
+        monkeypatch.setenv("LARA2DGS_VIEWS_BATCH_PREPROCESS", "0")
+    act, cams = small_scene(grid=10, size=80, n_views=3, seed=9)
+    a = to_numpy(act)
+    tm = run_oracle(oracle_view(cams[0], (1.0, 1.0, 1.0)), a).transMats
+    cols = np.random.default_rng(0).uniform(0, 1, (a["means3D"].shape[0], 3)).astype(np.float32)
+    settings = [raster_settings(c, [1.0, 1.0, 1.0], device=DEV) for c in cams]
+    g = torch.Generator().manual_seed(6)
+    dcs = [torch.randn(3, 80, 80, generator=g).to(DEV) for _ in cams]
+    das = [(torch.randn(7, 80, 80, generator=g) * 0.1).to(DEV) for _ in cams]
+
+    def leaves():
+        return {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in
+                dict(means3D=a["means3D"], opac=a["opacities"], cols=cols, tm=tm).items()}
+
+    want, outs = None, []
+    for i, rs in enumerate(settings):
+        t = leaves()
+        c, r, al = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opac"],
+                                          colors_precomp=t["cols"], cov3D_precomp=t["tm"])
+        ((c * dcs[i]).sum() + (al * das[i]).sum()).backward()
+        outs.append((c.detach(), al.detach()))
+        gi = {k: v.grad.clone() for k, v in t.items()}
+        want = gi if want is None else {k: want[k] + gi[k] for k in gi}       # view order
+    t = leaves()
+    color, radii, allmap = rasterize_gaussians_views(settings, t["means3D"], None, t["opac"], colors_precomp=t["cols"],
+                                                     cov3D_precomp=t["tm"])
+    sum((color[i] * dcs[i]).sum() + (allmap[i] * das[i]).sum() for i in range(len(cams))).backward()
+    torch.cuda.synchronize()
+    for i in range(len(cams)):
+        assert torch.equal(color[i].detach(), outs[i][0]) and torch.equal(allmap[i].detach(), outs[i][1])
+    for k in want:
+        assert torch.equal(t[k].grad, want[k]), f"grad {k}: max diff {(t[k].grad - want[k]).abs().max().item():.3e}"
+
+
 def test_views_repeatable_and_independent_of_stream_count(monkeypatch):
     """Same bits run to run, and whether the library spreads the views over 1 or 4 side streams."""
     from lara_amd import rasterize_gaussians_views
