@@ -385,7 +385,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_sh = g_sh.view(ctx.shapes[0])
         g_opac = g_opac.view(ctx.shapes[1])
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
-        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_sc, g_rot, g_tm, None
+        return g_means3D, (g_means2D if ctx.needs_input_grad[1] else None), g_sh, g_col, g_opac, g_sc, g_rot, g_tm, None
 
 
 # ---------------------------------------------------------------------------------------------

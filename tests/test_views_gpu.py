@@ -57,6 +57,34 @@ def test_views_match_the_per_view_loop(n_views, size):
         assert torch.equal(got[k], want), f"grad {k}: max diff {(got[k] - want).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("deg", [0, 2, 3])
+def test_views_other_sh_degrees(deg):
+    """SH degrees 0, 2, 3 with 16 stored coefficients through the multi-view call (the folded backward preprocess is
+    one template instance per degree; coefficients above the active degree must come back with zero gradient)."""
+    from lara_amd import GaussianRasterizer, rasterize_gaussians_views
+    act, cams = small_scene(grid=10, size=80, n_views=3, seed=30 + deg, sh_coeffs=16)
+    settings = [raster_settings(c, [0.0, 0.5, 1.0], sh_degree=deg, device=DEV) for c in cams]
+    g = torch.Generator().manual_seed(deg)
+    dcs = [torch.randn(3, 80, 80, generator=g).to(DEV) for _ in cams]
+    want = None
+    for i, rs in enumerate(settings):
+        inp = _inputs(act)
+        c, r, a = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
+                                         scales=inp["scales"], rotations=inp["rotations"])
+        (c * dcs[i]).sum().backward()
+        gi = {k: v.grad.clone() for k, v in inp.items()}
+        want = gi if want is None else {k: want[k] + gi[k] for k in gi}
+    inp = _inputs(act)
+    color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+    sum((color[i] * dcs[i]).sum() for i in range(len(cams))).backward()
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(inp[k].grad, want[k]), f"deg {deg} grad {k}: max diff {(inp[k].grad - want[k]).abs().max().item():.3e}"
+    assert float(inp["shs"].grad[:, (deg + 1) ** 2:].abs().max() if deg < 3 else 0.0) == 0.0
+    assert float(inp["shs"].grad[:, :(deg + 1) ** 2].abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("batched", [True, False])
 def test_views_with_precomputed_colour_and_transmat(monkeypatch, batched):
     """The other input combination of the operator (colors_precomp + cov3D_precomp = the 3x3 splat-to-pixel matrices)
