@@ -162,6 +162,72 @@ def test_views_repeatable_and_independent_of_stream_count(monkeypatch):
             assert torch.equal(g0[k], g[k]), k
 
 
+@pytest.mark.parametrize("P", [0, 3, 257])
+def test_views_tiny_and_empty_inputs(P):
+    """P = 0 (background only, nothing to differentiate), a handful of surfels, one more than a workgroup's worth."""
+    from lara_amd import GaussianRasterizer, rasterize_gaussians_views
+    act, cams = small_scene(grid=8, size=64, n_views=3, seed=2)
+    act = {k: v[:P].contiguous() for k, v in act.items()}
+    settings = [raster_settings(c, [0.25, 0.5, 0.75], device=DEV) for c in cams]
+    inp = _inputs(act)
+    color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+    assert color.shape == (3, 3, 64, 64) and radii.shape == (3, P) and torch.isfinite(color).all()
+    if P == 0:
+        assert torch.equal(color, torch.tensor([0.25, 0.5, 0.75], device=DEV).view(1, 3, 1, 1).expand(3, 3, 64, 64))
+        assert float(allmap.detach().abs().max()) == 0.0
+    (color.sum() + allmap.sum()).backward()
+    torch.cuda.synchronize()
+    want = None
+    for rs in settings:
+        ref = _inputs(act)
+        c, r, a = GaussianRasterizer(rs)(means3D=ref["means3D"], means2D=None, shs=ref["shs"], opacities=ref["opacities"],
+                                         scales=ref["scales"], rotations=ref["rotations"])
+        (c.sum() + a.sum()).backward()
+        gi = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in ref.items()}
+        want = gi if want is None else {k: want[k] + gi[k] for k in gi}
+    for k in want:
+        got = inp[k].grad if inp[k].grad is not None else torch.zeros_like(inp[k])
+        assert torch.equal(got, want[k]), k
+
+
+def test_views_from_two_caller_streams_at_once():
+    """Two scenes issued from two HIP streams (what the bench's scene streams do): the library keeps a lane pool per
+    caller stream, the calls must not disturb each other -- same bits as issued one after the other."""
+    from lara_amd import rasterize_gaussians_views
+    scenes = [small_scene(grid=12, size=96, n_views=4, seed=s) for s in (5, 6)]
+    settings = [[raster_settings(c, [1.0, 1.0, 1.0], device=DEV) for c in cams] for _, cams in scenes]
+
+    def run(streams):
+        outs, leaves = [], []
+        cur = torch.cuda.current_stream()
+        for i, (act, _) in enumerate(scenes):
+            inp = _inputs(act)
+            leaves.append(inp)
+            st = streams[i] if streams else None
+            if st is not None:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st) if st is not None else torch.cuda.stream(cur):
+                c, r, a = rasterize_gaussians_views(settings[i], inp["means3D"], None, inp["opacities"], shs=inp["shs"],
+                                                    scales=inp["scales"], rotations=inp["rotations"])
+                outs.extend((c, a))
+        for st in streams or []:
+            cur.wait_stream(st)
+        torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+        for st in streams or []:
+            cur.wait_stream(st)
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], [{k: v.grad.clone() for k, v in l.items()} for l in leaves]
+
+    o1, g1 = run(None)
+    o2, g2 = run([torch.cuda.Stream(), torch.cuda.Stream()])
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    for ga, gb in zip(g1, g2):
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+
+
 def test_views_argument_errors():
     from lara_amd import rasterize_gaussians_views
     act, cams = small_scene(grid=8, size=64, n_views=2, seed=1)
