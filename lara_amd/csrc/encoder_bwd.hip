@@ -384,11 +384,23 @@ neighbour_table_kernel(int *__restrict__ nbr, const int M, const int R, const in
 // bf16; per-workgroup partial column sums of dy xhat (dgamma), dy (dbeta) and out (the bias gradient of
 // the linear layer that produced the LayerNorm's input) go to part[block][3][256].
 // dx_out may alias dy or skip (same element only): a row's loads are issued before the previous row's stores.
+// DY_BF16: dy is the bf16 output of the dX product in front (what the reference's LayerNorm backward receives under
+// autocast: the gradient of a bf16 matmul, up-cast) -- half the bytes of that product's store and of this load.
 constexpr int LNB_ROWS = 128;
+template <bool DY_BF16>
 __global__ void __launch_bounds__(256)
-ln_bwd_kernel(const float *dy, const float *__restrict__ x, const float *__restrict__ gamma, const float eps,
+ln_bwd_kernel(const void *dy_, const float *__restrict__ x, const float *__restrict__ gamma, const float eps,
               const float *skip, float *dx_out, unsigned short *__restrict__ dx_bf16, float *__restrict__ part,
               const int tokens) {
+    const float *dy = (const float *)dy_;
+    const unsigned short *dyh = (const unsigned short *)dy_;
+    auto load_dy = [&](const size_t tok, const int lane) {
+        if (DY_BF16) {
+            const ushort4 h = ((const ushort4 *)(dyh + tok * 256))[lane];
+            return make_float4(bf2f(h.x), bf2f(h.y), bf2f(h.z), bf2f(h.w));
+        }
+        return ((const float4 *)(dy + tok * 256))[lane];
+    };
     __shared__ float red[4][12][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float4 g = ((const float4 *)gamma)[lane];
@@ -399,7 +411,7 @@ ln_bwd_kernel(const float *dy, const float *__restrict__ x, const float *__restr
     float4 vn = z4, dn = z4, kn = z4;
     if (nrow > 0) {
         vn = ((const float4 *)(x + (size_t)tok0 * 256))[lane];
-        dn = ((const float4 *)(dy + (size_t)tok0 * 256))[lane];
+        dn = load_dy((size_t)tok0, lane);
         if (skip) kn = ((const float4 *)(skip + (size_t)tok0 * 256))[lane];
     }
     for (int i = 0; i < nrow; i++) {
@@ -407,7 +419,7 @@ ln_bwd_kernel(const float *dy, const float *__restrict__ x, const float *__restr
         const float4 v = vn, d = dn, k = kn;
         if (i + 1 < nrow) {
             vn = ((const float4 *)(x + (size_t)(tok + 1) * 256))[lane];
-            dn = ((const float4 *)(dy + (size_t)(tok + 1) * 256))[lane];
+            dn = load_dy((size_t)(tok + 1), lane);
             if (skip) kn = ((const float4 *)(skip + (size_t)(tok + 1) * 256))[lane];
         }
         float s = v.x + v.y + v.z + v.w;
@@ -634,10 +646,11 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
 }
 
 // LayerNorm backward + the reductions of its partial sums into dgamma, dbeta, dbias (any may be null)
-int ln_bwd(const float *dy, const float *x, const float *gamma, float eps, const float *skip, float *dx,
+int ln_bwd(const void *dy, bool dy_bf16, const float *x, const float *gamma, float eps, const float *skip, float *dx,
            unsigned short *dx_bf16, float *dgamma, float *dbeta, float *dbias, float *part, int M, hipStream_t s) {
     const int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, dy, x, gamma, eps, skip, dx, dx_bf16, part, M);
+    if (dy_bf16) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, eps, skip, dx, dx_bf16, part, M);
+    else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, eps, skip, dx, dx_bf16, part, M);
     hipLaunchKernelGGL(accum_ln_partials_kernel, dim3(4, 3), dim3(1024), 0, s, dgamma, dbeta, dbias, part, blocks);
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
 }
@@ -816,7 +829,7 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     unsigned short *dkv = dkv_ext ? dkv_ext : (unsigned short *)(ws + L.dkv);
     const int ld_dkv = dkv_ext ? lddkv : 512;
     unsigned short *dob = (unsigned short *)(ws + L.dob);
-    float *tmpf = (float *)(ws + L.tmpf);
+    unsigned short *tmpb = (unsigned short *)(ws + L.tmpf);   // dX of the MLP / of the Q projection, bf16 [M, 256]
     float *lnpart = (float *)(ws + L.lnpart), *tnpart = (float *)(ws + L.tnpart);
     int *nbr = (int *)(ws + L.nbr);
     if (!chained) {  // (a chained call finds the zero row, the neighbour table and bf16(g) where the call before left them)
@@ -839,14 +852,14 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(g, x2, w->ln3_w, w->eps, nullptr, g, gb, dw->ln3_w, dw->ln3_b, dw->b2, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(g, false, x2, w->ln3_w, w->eps, nullptr, g, gb, dw->ln3_w, dw->ln3_b, dw->b2, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x2 = x1 + mlp(norm2(x1)) ----
     {
         L2D_PROF("gbb_dx_mlp", s);
         gemm_nt<7>(gb, wt->w2_t, dzb, M, 512, 256, nullptr, z, s);  // dz = (g2 W2) * gelu'(z)
-        gemm_nt<8>(dzb, wt->w1_t, tmpf, M, 256, 512, nullptr, nullptr, s);
+        gemm_nt<0>(dzb, wt->w1_t, tmpb, M, 256, 512, nullptr, nullptr, s);   // bf16: see ln_bwd_kernel
     }
     {
         L2D_PROF("gbb_dw_mlp", s);
@@ -856,7 +869,7 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(tmpf, x1, w->ln2_w, w->eps, g, g, gb, dw->ln2_w, dw->ln2_b, nullptr, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(tmpb, true, x1, w->ln2_w, w->eps, g, g, gb, dw->ln2_w, dw->ln2_b, nullptr, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x1 = x0 + cross_attn(norm1(x0), cond, cond) ----
@@ -865,7 +878,7 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
         gemm_nt<0>(gb, wt->wo_t, dob, M, 256, 256, nullptr, nullptr, s);
         hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, s, q, kv, dob, dq, dkv, G, ld_dkv);
         if (!dkv_ext) gemm_nt<1>(dkv, wt->wkv_t, dcond, Mkv, cond_dim, 512, dcond, nullptr, s);
-        gemm_nt<8>(dq, wt->wq_t, tmpf, M, 256, 256, nullptr, nullptr, s);
+        gemm_nt<0>(dq, wt->wq_t, tmpb, M, 256, 256, nullptr, nullptr, s);
     }
     {
         L2D_PROF("gbb_dw_attn", s);
@@ -875,7 +888,7 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(tmpf, x_in, w->ln1_w, w->eps, g, g, gb, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(tmpb, true, x_in, w->ln1_w, w->eps, g, g, gb, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
@@ -914,8 +927,8 @@ int lara_voltrans_head_backward(int32_t scenes, int32_t R, const float *x, const
     }
     if ((rc = colsum_bf16(dog, M, N8, d_bias8, lnpart, s))) return rc;
     if ((rc = gemm_tn(dog, N8, N8, xn, 256, 256, 1, nullptr, M, d_wdeconv, tnpart, s))) return rc;
-    gemm_nt<8>(dog, wdeconv_t, tmpf, M, 256, N8, nullptr, nullptr, s);
-    if ((rc = ln_bwd(tmpf, x, ln_w, eps, nullptr, g, nullptr, d_ln_w, d_ln_b, nullptr, lnpart, M, s))) return rc;
+    gemm_nt<0>(dog, wdeconv_t, tmpf, M, 256, N8, nullptr, nullptr, s);   // (bf16 rows in the fp32-sized region)
+    if ((rc = ln_bwd(tmpf, true, x, ln_w, eps, nullptr, g, nullptr, d_ln_w, d_ln_b, nullptr, lnpart, M, s))) return rc;
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }
@@ -948,7 +961,7 @@ int lara_layernorm256_backward(int32_t rows, const float *dy, const float *x, co
                                const float *skip, float *dx, float *dgamma, float *dbeta, void *workspace,
                                void *stream) {
     if (rows <= 0 || !dy || !x || !gamma || !dx || !dgamma || !dbeta || !workspace) return LARA2DGS_E_INVALID;
-    return ln_bwd(dy, x, gamma, eps, skip, dx, nullptr, dgamma, dbeta, nullptr, (float *)workspace, rows, (hipStream_t)stream);
+    return ln_bwd(dy, false, x, gamma, eps, skip, dx, nullptr, dgamma, dbeta, nullptr, (float *)workspace, rows, (hipStream_t)stream);
 }
 
 int lara_groupattn_core_backward(int32_t G, const uint16_t *q, const uint16_t *kv, const uint16_t *d_o, uint16_t *dq,
