@@ -18,6 +18,10 @@
  * c2ws [n_views, 4, 4], ixts [n_views, 3, 3] (neither is modified: the reference scales `ixts` in
  * place and its callers pass copies), rays [n_views, Hs, Ws, 6]; fp32, row-major, device pointers.
  * Returns 0 or a negative LARA2DGS_E_* code; work is enqueued on `stream`, no host synchronisation.
+ *
+ * ABI note: until ABI version 4 this entry point was `lara_build_rays(n_views, H, W, scale, ...)` taking the INPUT
+ * size.  The output-size form has the same C signature, so it carries a new name: a caller built against the old
+ * header fails at link / symbol lookup instead of silently producing full-resolution maps with scaled intrinsics.
  */
 #ifndef LARA_RAYS_H
 #define LARA_RAYS_H
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-int lara_build_rays(int32_t n_views, int32_t Hs, int32_t Ws, float scale, const float *c2ws,
+int lara_build_rays_out(int32_t n_views, int32_t Hs, int32_t Ws, float scale, const float *c2ws,
                     const float *ixts, float *rays, void *stream);
 
 #ifdef __cplusplus

@@ -24,8 +24,8 @@ def _lib():
     lib = load_library()
     if not _configured:
         vp, i32 = ctypes.c_void_p, ctypes.c_int32
-        lib.lara_build_rays.restype = ctypes.c_int
-        lib.lara_build_rays.argtypes = [i32, i32, i32, ctypes.c_float, vp, vp, vp, vp]
+        lib.lara_build_rays_out.restype = ctypes.c_int
+        lib.lara_build_rays_out.argtypes = [i32, i32, i32, ctypes.c_float, vp, vp, vp, vp]
         _configured = True
     return lib
 
@@ -55,9 +55,9 @@ def build_rays(c2ws: torch.Tensor, ixts: torch.Tensor, H: int, W: int, scale: fl
     rays = torch.empty(V, Hs, Ws, 6, dtype=torch.float32, device=c.device)
     with torch.cuda.device(c.device):
         # the output size is computed once, here, as the reference does (double precision), and handed over
-        rc = _lib().lara_build_rays(V, Hs, Ws, float(scale), c.data_ptr(), k.data_ptr(), rays.data_ptr(),
+        rc = _lib().lara_build_rays_out(V, Hs, Ws, float(scale), c.data_ptr(), k.data_ptr(), rays.data_ptr(),
                                     torch.cuda.current_stream(c.device).cuda_stream)
-    _check(rc, "lara_build_rays")
+    _check(rc, "lara_build_rays_out")
     return rays
 
 

@@ -301,7 +301,8 @@ bool views_agree(int n, const lara2dgs_view *views) {
     for (int i = 1; i < n; i++) {
         const lara2dgs_view &a = views[0], &b = views[i];
         if (a.P != b.P || a.sh_degree != b.sh_degree || a.sh_coeffs != b.sh_coeffs || a.image_height != b.image_height ||
-            a.image_width != b.image_width || a.capacity != b.capacity || a.prefiltered != b.prefiltered) return false;
+            a.image_width != b.image_width || a.capacity != b.capacity || a.prefiltered != b.prefiltered ||
+            a.scale_modifier != b.scale_modifier || a.debug != b.debug) return false;   // (the batched preprocess runs all cameras with views[0]'s scalars)
     }
     return true;
 }

@@ -564,10 +564,10 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
                  const uint32_t *__restrict__ tile_order, uint64_t *__restrict__ keys,
                  uint32_t *__restrict__ point_list, const uint4 *__restrict__ rect,
                  const uint32_t *__restrict__ pair_base, uint32_t *__restrict__ pair_pos,
-                 const uint32_t *__restrict__ sort_parts, const uint2 *__restrict__ sort_items) {
+                 uint32_t *__restrict__ sort_parts, const uint2 *__restrict__ sort_items) {
     __shared__ uint64_t lds[L2D_SORT_LDS_KEYS];
     __shared__ uint32_t bkt[L2D_SORT_BUCKETS + 1], sh[16];
-    __shared__ uint32_t s_min, s_max, s_mine, s_hist[L2D_SORT_PARTS];
+    __shared__ uint32_t s_min, s_max, s_mine, s_ticket, s_hist[L2D_SORT_PARTS];
     // Grid: `tiles` extra work items first (tile_scan's list of (tile, part >= 1) for the long lists; the unused ones
     // exit on one load), then part 0 of every tile in longest-list-first order.  (A grid of parts x tiles workgroups
     // that find out for themselves that they are not needed costs 20 us in dependent loads before they exit.)
@@ -583,7 +583,7 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
     const uint32_t n = rg.y - rg.x;
     if (header[1]) return;  // capacity overflow: lists are incomplete, outputs get poisoned instead
     if (n == 0) return;
-    const int S = (int)sort_parts[tile];
+    const int S = (int)(sort_parts[tile] & 0xffffu);   // (bits 16+: the parts' arrival tickets, see the fallback below)
     uint64_t *seg = keys + rg.x;
     uint32_t *out = point_list + rg.x;
     const PairMap pm{rect, pair_base, pair_pos, tile % v.gx, tile / v.gx, rg.x};
@@ -634,8 +634,18 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
             off += b < part ? s_hist[b] : 0u;
             biggest = s_hist[b] > biggest ? s_hist[b] : biggest;
         }
-        if (biggest > L2D_SORT_LDS_KEYS) {       // a slice that does not fit the LDS (a wall of equal depths): part 0 sorts
-            if (part != 0) return;               // the whole list in place instead, every other part stands down
+        if (biggest > L2D_SORT_LDS_KEYS) {
+            // A slice that does not fit the LDS (a wall of equal depths): ONE workgroup sorts the whole list in place
+            // instead.  That mutates `seg`, which the tile's other parts read for the passes above, and the parts are
+            // unordered workgroups -- so the LAST part to arrive here does it: each takes a ticket once its own reads
+            // of `seg` are done (they fed the reductions above), nobody writes before all S tickets are taken, hence
+            // every part derived min / max / histogram from the untouched segment and took this same branch.
+            if (threadIdx.x == 0) {
+                __threadfence();
+                s_ticket = __hip_atomic_fetch_add(&sort_parts[tile], 0x10000u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) >> 16;
+            }
+            __syncthreads();
+            if (s_ticket != (uint32_t)S - 1u) return;
             whole_list_in_place = true;
         } else {
             const uint32_t m = s_hist[part];

@@ -46,7 +46,7 @@ build_rays_kernel(const int Hs, const int Ws, const float scale, const float *__
 
 }  // namespace
 
-extern "C" int lara_build_rays(int32_t n_views, int32_t Hs, int32_t Ws, float scale, const float *c2ws,
+extern "C" int lara_build_rays_out(int32_t n_views, int32_t Hs, int32_t Ws, float scale, const float *c2ws,
                                const float *ixts, float *rays, void *stream) {
     // Hs, Ws are the OUTPUT size, computed once by the caller (the reference's int(H*scale) is a
     // double-precision product; recomputing it here in fp32 could disagree by one row)

@@ -143,7 +143,7 @@ def get_point_feats(self, idx, img_ref, renderings, n_views_sel, batch, points, 
 # ---------------------------------------------------------------------------------------------
 # Decoder.forward_fine (network.py:280-284)
 # ---------------------------------------------------------------------------------------------
-_FD, _NH, _HD, _CD, _NV, _HID = 80, 8, 10, 8, 4, 64   # the only sizes the kernel is built for (configs/base.yaml)
+_FD, _NH, _HD, _CD, _NV, _HID, _SH = 80, 8, 10, 8, 4, 64, 12   # the only sizes the kernel is built for (configs/base.yaml)
 
 
 class _FineDecoder(torch.autograd.Function):
@@ -156,7 +156,11 @@ class _FineDecoder(torch.autograd.Function):
         f = lambda t: t.detach().float().contiguous()
         xn, pf, Wqk, W1ov, b1, W2, b2 = map(f, (xn, pf, Wqk, W1ov, b1, W2, b2))
         n = xn.shape[0]
-        sh = torch.empty(n, W2.shape[0], dtype=torch.float32, device=xn.device)
+        if (xn.shape != (n, _FD) or pf.shape != (_NV, _CD, n) or Wqk.shape != (_NH * _CD, _FD) or W1ov.shape != (_HID, _NH * _CD)
+                or b1.shape != (_HID,) or W2.shape != (_SH, _HID) or b2.shape != (_SH,)):
+            raise RuntimeError("lara_fine_decoder_forward: the kernel is built for xn [n,80], pf [4,8,n], Wqk [64,80], "
+                               "W1ov [64,64], b1 [64], W2 [12,64], b2 [12]")
+        sh = torch.empty(n, _SH, dtype=torch.float32, device=xn.device)
         with torch.cuda.device(xn.device):
             _check(_lib().lara_fine_decoder_forward(n, xn.data_ptr(), pf.data_ptr(), Wqk.data_ptr(), W1ov.data_ptr(),
                                                     b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), sh.data_ptr(),
@@ -241,9 +245,10 @@ def _fold_fine_weights(decoder):
     att = decoder.cross_att
     E = att.embed_dim
     if (E != _FD or att.num_heads != _NH or att.kdim != _CD or att.vdim != _CD or att.in_proj_bias is not None
-            or att.out_proj.bias is not None or decoder.mlp_fine[0].out_features != _HID):
+            or att.out_proj.bias is not None or decoder.mlp_fine[0].out_features != _HID
+            or decoder.mlp_fine[2].out_features != _SH):
         raise RuntimeError("lara_amd.fine.forward_fine is built for LaRa's sizes only: embed 80, 8 heads, kdim = vdim = 8, "
-                           "no biases in the attention, hidden 64")
+                           "no biases in the attention, hidden 64, 12 SH outputs (sh_degree 1)")
     Wq = att.q_proj_weight.float().view(_NH, _HD, E)            # [h, d, i]
     Wk = att.k_proj_weight.float().view(_NH, _HD, _CD)          # [h, d, c]
     Wv = att.v_proj_weight.float().view(_NH, _HD, _CD)

@@ -29,7 +29,7 @@ from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class _View(ctypes.Structure):
@@ -432,9 +432,10 @@ class _RasterizeViews(torch.autograd.Function):
         rs0 = settings[0]
         n = len(settings)
         for rs in settings[1:]:
-            if (rs.image_height, rs.image_width, rs.sh_degree, bool(rs.prefiltered)) != \
-                    (rs0.image_height, rs0.image_width, rs0.sh_degree, bool(rs0.prefiltered)):
-                raise RuntimeError("lara_amd: the views of one multi-view call must agree in image size, sh_degree and prefiltered")
+            if (rs.image_height, rs.image_width, rs.sh_degree, bool(rs.prefiltered), float(rs.scale_modifier), bool(rs.debug)) != \
+                    (rs0.image_height, rs0.image_width, rs0.sh_degree, bool(rs0.prefiltered), float(rs0.scale_modifier), bool(rs0.debug)):
+                raise RuntimeError("lara_amd: the views of one multi-view call must agree in image size, sh_degree, prefiltered, "
+                                   "scale_modifier and debug")
         device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c) = _validate(
             means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs0.sh_degree)
         H, W = int(rs0.image_height), int(rs0.image_width)

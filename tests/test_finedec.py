@@ -61,6 +61,9 @@ def test_fold_refuses_other_sizes():
     dec.cross_att = torch.nn.MultiheadAttention(80, 4, kdim=8, vdim=8, bias=False, batch_first=True)
     with pytest.raises(RuntimeError, match="LaRa's sizes"):
         _fold_fine_weights(dec)
+    # sh_degree != 1 (3 or 27 outputs): the kernel stores 12 floats per point, so the wrapper must refuse
+    with pytest.raises(RuntimeError, match="LaRa's sizes"):
+        _fold_fine_weights(FineDecoderRef(sh_dim=3))
 
 
 @pytest.mark.gpu

@@ -118,12 +118,14 @@ def test_forward_ragged_image_and_big_splats(hip_lib):
     assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 2048  # exercised the large-tile sort
 
 
-@pytest.mark.parametrize("n_wall,n_rest", [(5000, 1500), (2600, 3000), (9000, 200)])
+@pytest.mark.parametrize("n_wall,n_rest", [(5000, 1500), (2600, 3000), (9000, 200), (5000, 2)])
 def test_sort_parts_wall_of_equal_depths_and_tie_order(hip_lib, n_wall, n_rest):
     """The per-tile sort cuts long lists by depth range into parts sorted by different workgroups (binning.hip).  A wall
     of surfels with EXACTLY equal depth cannot be cut: more than 4096 of them in one slice must take the in-place
     fallback, fewer ride in one part; either way ties keep the reference's order (surfel id ascending), bit for bit.
-    9000 + 200 also exceeds the 8192-entry limit of the parts scheme."""
+    9000 + 200 also exceeds the 8192-entry limit of the parts scheme; 5000 + 2 is "a wall plus a far outlier": the
+    outlier alone decides the list's depth interval, so every part must derive it from the untouched segment (the parts
+    take arrival tickets and the last one sorts in place)."""
     g = torch.Generator().manual_seed(n_wall)
     from lara_amd import cameras
     cam = cameras.make_cameras(cameras.turntable_c2w(4)[:1], 64, 64, 0.75, 0.75, 0.5, 2.5)[0]

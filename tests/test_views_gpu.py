@@ -238,6 +238,10 @@ def test_views_argument_errors():
     with pytest.raises(RuntimeError, match="must agree"):
         rasterize_gaussians_views([s_ok, s_other], t["means3D"], m2, t["opacities"], shs=t["shs"], scales=t["scales"],
                                   rotations=t["rotations"])
+    s_scaled = raster_settings(cams[1], [1.0, 1.0, 1.0], device=DEV)._replace(scale_modifier=0.5)
+    with pytest.raises(RuntimeError, match="must agree"):   # the batched preprocess runs all cameras with one scale_modifier
+        rasterize_gaussians_views([s_ok, s_scaled], t["means3D"], m2, t["opacities"], shs=t["shs"], scales=t["scales"],
+                                  rotations=t["rotations"])
     with pytest.raises(Exception, match="excatly one"):
         rasterize_gaussians_views([s_ok], t["means3D"], m2, t["opacities"], scales=t["scales"], rotations=t["rotations"])
     with pytest.raises(RuntimeError, match="at least one view"):
