@@ -62,8 +62,14 @@ def parse():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--grid", type=int, default=64, help="surfels = grid^3 * 2 (64 -> 524288)")
     ap.add_argument("--regime", default="init", choices=["init", "trained"])
-    ap.add_argument("--step", default="train", choices=["train", "raster"],
-                    help="train: encoder fwd + raster fwd/bwd + encoder bwd (DDP all-reduce when N > 1); raster: the raster alone")
+    ap.add_argument("--step", default="pipeline", choices=["pipeline", "train", "raster"],
+                    help="pipeline: the whole data-dependent LaRa step (lara_amd.pipeline: encoder -> coarse decoder -> coarse views -> "
+                         "sampler -> forward_fine -> fine views -> loss -> one backward; DDP all-reduce when N > 1); train: round 2's "
+                         "definition (encoder and raster on independent tensors, no decoder / sampler / forward_fine); raster: the raster alone")
+    ap.add_argument("--fine-mask", default="reference", choices=["reference", "plain"],
+                    help="pipeline step: `reference` applies Network._check_mask as a training step does (a mask keeping > 50 %% of the "
+                         "Gaussians is thinned to about half at random, network.py:381-388); `plain` keeps every Gaussian above the "
+                         "opacity threshold (what an eval step renders)")
     ap.add_argument("--no-fine", action="store_true", help="coarse views only (LaRa before train.start_fine)")
     ap.add_argument("--encoder-layers", type=int, default=12, help="transformer depth (configs/base.yaml:16: 12)")
     ap.add_argument("--raster-api", default="views", choices=["views", "loop"],
@@ -957,6 +963,138 @@ def cpu_encoder_baseline(scenes=1):
                       f"MLP -> 524288 Gaussians), fp32 torch, {cores} threads; one pass, no warm-up"}
 
 
+def make_pipeline_step(args, device, rank, world, plumbing):
+    """The headline step: `lara_amd.pipeline.LaRaPipeline` (network.py:455-532) + `lara_loss` (loss.py minus MS-SSIM) +
+    one backward through everything, the encoder's backward last (autograd's order), DDP over ALL trainable
+    parameters (VolTransformer + decoder) when N > 1.  Inputs resident in HBM: the collated batch dictionary
+    (cameras, images, rays) and the image-feature volume the DINO encoder + `build_feat_vol` would hand over (both
+    outside SURVEY.md section 8)."""
+    from lara_amd import rasterizer
+    from lara_amd.batch import synthetic_batch
+    from lara_amd.encoder_train import VolTransformer
+    from lara_amd.pipeline import CoarseFineDecoder, LaRaPipeline, lara_loss
+    rasterizer.load_library()
+    info = {"grad_allreduce": None}
+    torch.manual_seed(0)          # identical initial parameters on every rank, as DDP expects
+    enc = VolTransformer(256, 800, [args.grid // 4], args.grid // 2, args.grid, 80, args.encoder_layers, 16)
+    pipe = LaRaPipeline(enc, CoarseFineDecoder(), grid_reso=args.grid // 2, n_streams=args.streams).to(device)
+    pipe.fine_mask = args.fine_mask
+    pipe.train()
+    if "LARA2DGS_VIEW_STREAMS" not in os.environ:
+        rasterizer.set_view_lanes(view_lanes_for(args.streams))
+    batch = synthetic_batch(batch_size=args.scenes, n_views=args.views, H=args.res, W=args.res, n_input=4, seed=7 + rank, device=device)
+    g = torch.Generator(device="cpu").manual_seed(11 + rank)
+    batch["tar_rgb"] = torch.rand(batch["tar_rgb"].shape, generator=g).to(device)
+    feat_vol = torch.randn(args.scenes, 4, 800, args.grid // 4, args.grid // 4, args.grid // 4, generator=g).to(device)
+    n_par = sum(p.numel() for p in pipe.parameters() if p.requires_grad)
+    info["encoder"] = {"parameters": sum(p.numel() for p in enc.parameters()), "layers": args.encoder_layers}
+    model = pipe
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from lara_amd import dp
+        model = DDP(pipe, device_ids=[device.index], find_unused_parameters=True, bucket_cap_mb=dp.DDP_BUCKET_MB)   # train_lightning.py:72
+        info["grad_allreduce"] = {"bytes_per_step": 4 * n_par, "bucket_cap_MB": dp.DDP_BUCKET_MB, "buckets": None,
+                                  "backend": os.environ.get("LARA_BENCH_BACKEND", "nccl"),
+                                  "what": "torch DistributedDataParallel over the VolTransformer + decoder parameters (fp32 master "
+                                          "gradients); the encoder's backward is one autograd node per block, so a bucket's all-reduce "
+                                          "starts while the earlier blocks' backward is still running"}
+    params = [p for p in pipe.parameters() if p.requires_grad]
+    with_fine = not args.no_fine
+
+    def full_step():
+        out = model(batch, feat_vol, with_fine=with_fine)
+        loss, _ = lara_loss(batch, out, 2000)       # past iteration 1000: distortion + normal terms are on (loss.py:48)
+        loss.backward()
+        pipe.join_streams()
+        for p in params:
+            p.grad = None
+
+    def after_first_step():
+        if info["grad_allreduce"] is not None:
+            try:
+                sizes = model._get_ddp_logging_data().get("bucket_sizes", "")
+                info["grad_allreduce"]["buckets"] = [int(x) for x in str(sizes).split(",") if x.strip()]
+            except Exception:
+                pass
+    info.update(after_first_step=after_first_step, frames_per_rank_step=args.scenes * args.views * (2 if with_fine else 1),
+                pipeline=(pipe, batch, feat_vol, full_step))
+    if rank == 0 and not args.no_roofline:
+        # the seeded synthetic scenes of SURVEY.md section 8d (what `roofline`, `kernels` and the raster side legs run on)
+        scenes, settings, gc, ga = build_batch(args, device, rank)
+        info["raster_state"] = (scenes, settings, gc, ga, None if args.no_fine else fine_subsets(scenes))
+    return full_step, info
+
+
+def pipeline_breakdown(info, args):
+    """Where the pipeline step's time goes: (a) forward stages on ONE stream (HIP events at the stage boundaries of
+    `LaRaPipeline.forward`) + the whole backward; (b) the library's kernels of one whole step grouped by stage (HIP events
+    around every launch, serialised); (c) the fine subset's size and D."""
+    from lara_amd import rasterizer
+    from lara_amd.pipeline import lara_loss
+    pipe, batch, feat_vol, full_step = info["pipeline"]
+    prev_streams = pipe.n_streams
+    pipe.n_streams = 1
+    if "LARA2DGS_VIEW_STREAMS" not in os.environ:
+        rasterizer.set_view_lanes(1)      # strictly serial: stage times add up
+    res = {}
+    try:
+        for _ in range(2):
+            full_step()
+        torch.cuda.synchronize()
+        pipe.stage_events = []
+        out = pipe(batch, feat_vol, with_fine=not args.no_fine)
+        loss, _ = lara_loss(batch, out, 2000)
+        e_l = torch.cuda.Event(enable_timing=True); e_l.record()
+        loss.backward()
+        pipe.join_streams()
+        e_b = torch.cuda.Event(enable_timing=True); e_b.record()
+        torch.cuda.synchronize()
+        ev, pipe.stage_events = pipe.stage_events, None
+        stages = {}
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1)
+        stages["loss"] = ev[-1][1].elapsed_time(e_l)
+        stages["backward (all of it)"] = e_l.elapsed_time(e_b)
+        res["one_stream_ms"] = {k: round(v, 2) for k, v in stages.items()}
+        res["one_stream_ms"]["sum"] = round(sum(stages.values()), 2)
+        for p in pipe.parameters():
+            p.grad = None
+        # (b) per-kernel HIP events of the library's launches over one step
+        rasterizer.profile_enable(True)
+        full_step()
+        torch.cuda.synchronize()
+        rec = rasterizer.profile_collect()
+        rasterizer.profile_enable(False)
+        groups = {"raster": ("preprocess", "tile_", "scatter", "composite", "sum_view_grads"), "encoder": ("ga_", "gb_", "gbb_", "gbt_", "vt_", "vtb_"),
+                  "surface maps": ("surface",), "point sampler": ("point_feats",), "forward_fine": ("fine_",)}
+        agg, other = {k: 0.0 for k in groups}, {}
+        for name, ms in rec:
+            for gname, pre in groups.items():
+                if name.startswith(pre):
+                    agg[gname] += ms
+                    break
+            else:
+                other[name] = other.get(name, 0.0) + ms
+        res["library_kernels_ms"] = {k: round(v, 2) for k, v in agg.items()}
+        if other:
+            res["library_kernels_ms"]["other"] = {k: round(v, 3) for k, v in sorted(other.items(), key=lambda kv: -kv[1])[:12]}
+        res["library_kernels_ms"]["sum"] = round(sum(ms for _, ms in rec), 2)
+        comp = {}
+        for name, ms in rec:
+            if name in ("composite_fwd", "composite_bwd", "preprocess_fwd", "preprocess_bwd", "preprocess_fwd_views", "preprocess_bwd_views", "tile_sort"):
+                c = comp.setdefault(name, [0, 0.0]); c[0] += 1; c[1] += ms
+        res["raster_kernels"] = {k: {"launches": n, "avg_us": round(1e3 * t / n, 1)} for k, (n, t) in comp.items()}
+        with torch.no_grad():
+            g = pipe.gaussians(feat_vol)
+            res["fine_subset_fraction_before_check_mask"] = round(float(g["masks"].float().mean()), 4)
+            res["opacity_mean"] = round(float(torch.sigmoid(g["opacity"]).mean()), 4)
+    finally:
+        pipe.n_streams = prev_streams
+        if "LARA2DGS_VIEW_STREAMS" not in os.environ:
+            rasterizer.set_view_lanes(view_lanes_for(args.streams))
+    return res
+
+
 class _PlumbingEncoder(torch.nn.Module):
     """LARA_BENCH_PLUMBING=1 (CPU tests of the launcher): a few linear layers stand in for the HIP encoder so that the
     spawn / process-group / DDP / barrier / max-over-ranks / JSON path can run without a GPU.  Nothing is measured."""
@@ -1071,7 +1209,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    full_step, info = make_training_step(args, device, rank, world, plumbing)
+    if args.step == "pipeline" and not plumbing:
+        full_step, info = make_pipeline_step(args, device, rank, world, plumbing)
+    else:
+        full_step, info = make_training_step(args, device, rank, world, plumbing)
     for i in range(max(args.warmup, 1) if info["grad_allreduce"] else args.warmup):
         full_step()
         if i == 0:
@@ -1113,27 +1254,56 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.step == "raster" else "f32 raster + bf16-MFMA/f32-accumulate encoder",
+        "dtype": "f32" if args.step == "raster" else "f32 raster + bf16-MFMA/f32-accumulate encoder"
+                 + (" (+ bf16-autocast coarse decoder MLP, as the reference's bf16-mixed)" if args.step == "pipeline" else ""),
         "data": "synthetic" if not plumbing else "PLUMBING SELF-TEST (no GPU work; not a measurement)",
         "config": {
-            "workload": (f"configs[2]: LaRa training step on the hot path, per GPU {args.scenes} scenes: "
-                         + (f"VolTransformer fwd+bwd ({enc['layers']} layers, {enc['parameters'] / 1e6:.2f} M parameters) + "
-                            if enc else "")
-                         + f"raster fwd+bwd of {args.views} coarse" + ("" if args.no_fine else f" + {args.views} fine")
-                         + f" views/scene @{args.res}x{args.res}, P={P} surfels/scene, SH degree 1, regime={args.regime}"),
+            "workload": (
+                (f"configs[2]: the whole data-dependent LaRa training step (lightning/network.py:455-532 + loss.py minus MS-SSIM), per GPU "
+                 f"{args.scenes} scenes: VolTransformer ({enc['layers']} layers, {enc['parameters'] / 1e6:.2f} M parameters) -> coarse decoder MLP "
+                 f"-> {args.views} coarse views/scene -> " + ("" if args.no_fine else f"_check_mask ({args.fine_mask}) -> point sampler on 4 input views -> "
+                 f"forward_fine -> {args.views} fine views/scene -> ") + f"loss -> ONE backward through all of it; @{args.res}x{args.res}, P={P} "
+                 f"surfels/scene, SH degree 1, random-init network (= SURVEY 8d's init regime)")
+                if args.step == "pipeline" and not plumbing else
+                (f"configs[2]: LaRa training step on the hot path (round 2's definition: encoder and raster on independent tensors), per GPU {args.scenes} scenes: "
+                 + (f"VolTransformer fwd+bwd ({enc['layers']} layers, {enc['parameters'] / 1e6:.2f} M parameters) + "
+                    if enc else "")
+                 + f"raster fwd+bwd of {args.views} coarse" + ("" if args.no_fine else f" + {args.views} fine")
+                 + f" views/scene @{args.res}x{args.res}, P={P} surfels/scene, SH degree 1, regime={args.regime}")),
             "step": args.step,
             "frames_per_step": frames_per_step,
             "parallelism": f"dp{joined} (per-scene; raster not sharded)",
             "hip_streams": args.streams,
             "view_lanes": (int(os.environ["LARA2DGS_VIEW_STREAMS"]) if "LARA2DGS_VIEW_STREAMS" in os.environ
-                           else view_lanes_for(args.streams)) if args.raster_api == "views" else None,
+                           else view_lanes_for(args.streams)) if args.raster_api == "views" or args.step == "pipeline" else None,
             "raster_api": ("views: one multi-view rasteriser call per scene and pass (opt-in lara_amd API; `view_lanes` "
-                           "streams per call)" if args.raster_api == "views" else
+                           "streams per call)" if args.raster_api == "views" or args.step == "pipeline" else
                            "loop: one GaussianRasterizer call per view (the reference's loop)"),
             "grad_allreduce": info["grad_allreduce"],
         },
     }
     solo = rank == 0 and world == 1 and not plumbing
+    if solo and args.step == "pipeline" and not args.no_roofline:
+        out["stages"] = pipeline_breakdown(info, args)
+    if solo and args.step == "pipeline" and not args.no_roofline and not args.no_side_legs:
+        # round 2's headline definition, kept for continuity: encoder and raster on independent synthetic tensors,
+        # no decoder / sampler / forward_fine / loss, the fine subset not thinned
+        a2 = argparse.Namespace(**{**vars(args), "step": "train"})
+        step2, info2 = make_training_step(a2, device, rank, world, plumbing)
+        for _ in range(2):
+            step2()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        torch.cuda.synchronize()
+        d2 = time.perf_counter() - t1
+        out["independent_tensors_step"] = {
+            "value": round(info2["frames_per_rank_step"] * args.steps / d2, 3), "unit": "frames/s", "ms_per_step": round(1e3 * d2 / args.steps, 3),
+            "workload": "round 2's headline: VolTransformer fwd+bwd + raster fwd+bwd of 8 coarse + 8 fine views/scene on INDEPENDENT "
+                        "synthetic tensors (no decoder, sampler, forward_fine, loss; fine subset = every surfel above the opacity threshold)"}
+        del step2, info2
+        torch.cuda.empty_cache()
     if solo and not args.no_roofline:
         scenes, settings, gc, ga, fine_idx = info["raster_state"]
 

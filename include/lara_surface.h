@@ -43,6 +43,21 @@ int lara_surface_maps_backward(int32_t H, int32_t W, const float *color, const f
                                const float *g_acc_map, const float *g_rend_normal, const float *g_depth_normal,
                                const float *g_rend_dist, float *d_color, float *d_allmap, void *stream);
 
+/* All views of a scene in one launch per direction, written side by side the way `Network.forward` concatenates them
+ * (lightning/network.py:527: `torch.cat([view[k] ...], dim=1)`): color [n,3,H,W], allmap [n,7,H,W], rays [n,H,W,6],
+ * rots [n,9]; every output (and, in the backward, every output gradient) is ONE [H, n*W, C] map in which view v owns the
+ * columns [v*W, (v+1)*W).  d_color [n,3,H,W] and d_allmap [n,7,H,W] are fully overwritten.  With n = 1 these are the
+ * single-view entry points above. */
+int lara_surface_maps_forward_views(int32_t n_views, int32_t H, int32_t W, const float *color, const float *allmap,
+                                    const float *rays, const float *rots, float depth_ratio, float *image, float *depth,
+                                    float *acc_map, float *rend_normal, float *depth_normal, float *rend_dist, void *stream);
+
+int lara_surface_maps_backward_views(int32_t n_views, int32_t H, int32_t W, const float *color, const float *allmap,
+                                     const float *rays, const float *rots, float depth_ratio, const float *g_image,
+                                     const float *g_depth, const float *g_acc_map, const float *g_rend_normal,
+                                     const float *g_depth_normal, const float *g_rend_dist, float *d_color, float *d_allmap,
+                                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,14 +191,15 @@ class _FineDecoder(torch.autograd.Function):
 def _tn_over_points(a, b, chunk=1024):
     """a^T b for a [n,p], b [n,q] with n in the hundreds of thousands and p, q <= 80: one output tile, so a plain GEMM
     call runs on one or two workgroups (measured 1 ms for [64,524288] x [524288,80]).  Split the point axis into
-    `chunk`-sized slabs -> a batched GEMM that fills the chip, then add the slabs (fixed order: reproducible)."""
+    `chunk`-sized slabs -> a batched GEMM that fills the chip, then add the slabs in fp32 (fixed order: reproducible;
+    bf16 operands give bf16 slab products, summed in fp32)."""
     n = a.shape[0]
     m = n // chunk * chunk
     out = None
     if m:
-        out = torch.bmm(a[:m].view(-1, chunk, a.shape[1]).transpose(1, 2), b[:m].view(-1, chunk, b.shape[1])).sum(0)
+        out = torch.bmm(a[:m].view(-1, chunk, a.shape[1]).transpose(1, 2), b[:m].view(-1, chunk, b.shape[1])).float().sum(0)
     if m < n:
-        tail = a[m:].t() @ b[m:]
+        tail = (a[m:].t() @ b[m:]).float()
         out = tail if out is None else out + tail
     return out
 

@@ -137,12 +137,21 @@ def _dup_factor() -> int:
     return int(os.environ.get("LARA2DGS_DUP_FACTOR", "16"))
 
 
+def _sizing_P(P: int) -> int:
+    """The surfel count the buffers are SIZED for: P rounded up to a multiple of 65 536 (1024 below that).  LaRa's fine
+    pass renders a subset whose size changes with every step (`x[mask]`, network.py:514-524; `_check_mask` thins it at
+    random): a state buffer sized from the exact count is a new ~1 GB allocation size per call, which the caching
+    allocator answers with a fresh hipMalloc (measured: +66 ms on such a step).  Quantised, the same sizes recur."""
+    q = 65536 if P > 65536 else 1024
+    return max(-(-P // q) * q, q)
+
+
 def binning_capacity(P: int) -> int:
     """(tile, surfel) pairs the buffers are sized for.  The real count is data dependent and
     stays on the device (no host sync per view); LaRa's init distribution needs ~3 P, a 288 GB
     part can afford 16 P (~36 B per pair) without thinking about it.  Override with
-    LARA2DGS_DUP_FACTOR."""
-    return min(max(P * _dup_factor(), 1 << 20), 0xFFFFFFFF)
+    LARA2DGS_DUP_FACTOR.  Derived from the quantised surfel count (`_sizing_P`)."""
+    return min(max(_sizing_P(P) * _dup_factor(), 1 << 20), 0xFFFFFFFF)
 
 
 _scratch = {}   # (device index, stream id) -> uint8 tensor
@@ -299,8 +308,8 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
         color = torch.empty((3, H, W), dtype=torch.float32, device=device)
         allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
         radii = torch.empty((P,), dtype=torch.int32, device=device)
-        state = torch.empty((lib.lara2dgs_state_bytes(P, H, W, cap),), dtype=torch.uint8, device=device)
-        scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(P, H, W, cap))
+        state = torch.empty((lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap),), dtype=torch.uint8, device=device)
+        scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap))
         rc = lib.lara2dgs_forward(ctypes.byref(view), _ptr(means3D_c), _ptr(sh_c), _ptr(col_c),
                                   _ptr(opa_c), _ptr(sc_c), _ptr(rot_c), _ptr(tm_c),
                                   color.data_ptr(), allmap.data_ptr(), radii.data_ptr(),
@@ -371,7 +380,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_sc = new(P, 2) if has_sr else None
             g_rot = new(P, 4) if has_sr else None
             g_tm = new(P, 9) if has_tm else None
-            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(P, H, W, ctx.cap))
+            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, ctx.cap))
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = lib.lara2dgs_backward(
                 ctypes.byref(view), _ptr(means3D), _ptr(sh if has_sh else None),
@@ -448,8 +457,8 @@ class _RasterizeViews(torch.autograd.Function):
             color = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
             allmap = torch.empty((n, 7, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((n, P), dtype=torch.int32, device=device)
-            sb = (lib.lara2dgs_state_bytes(P, H, W, cap) + 255) // 256 * 256
-            qb = (lib.lara2dgs_scratch_bytes(P, H, W, cap) + 255) // 256 * 256
+            sb = (lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
+            qb = (lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
             state = torch.empty((n * sb,), dtype=torch.uint8, device=device)
             # a scratch buffer per VIEW: the library then preprocesses all cameras in one launch (the surfels' inputs are
             # read once); with fewer it falls back to one preprocess launch per view on the lanes

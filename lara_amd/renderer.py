@@ -38,6 +38,10 @@ def _lib():
         lib.lara_surface_maps_forward.argtypes = [i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
         lib.lara_surface_maps_backward.restype = ctypes.c_int
         lib.lara_surface_maps_backward.argtypes = [i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.lara_surface_maps_forward_views.restype = ctypes.c_int
+        lib.lara_surface_maps_forward_views.argtypes = [i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
+        lib.lara_surface_maps_backward_views.restype = ctypes.c_int
+        lib.lara_surface_maps_backward_views.argtypes = [i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _configured = True
     return lib
 
@@ -81,6 +85,52 @@ class _SurfaceMaps(torch.autograd.Function):
                                                      torch.cuda.current_stream(color.device).cuda_stream),
                    "lara_surface_maps_backward")
         return d_color, d_allmap, None, None, None
+
+
+class _SurfaceMapsViews(torch.autograd.Function):
+    """(color [n,3,H,W], allmap [n,7,H,W], rays [n,H,W,6], rots [n,3,3], depth_ratio) -> the six maps of all n views side by
+    side, each [H, n*W, C] -- the per-scene concatenation of lightning/network.py:527 written directly by the kernel."""
+
+    @staticmethod
+    def forward(ctx, color, allmap, rays, rots, depth_ratio):
+        if not color.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        color, allmap = color.float().contiguous(), allmap.float().contiguous()
+        rays, rots = rays.detach().float().contiguous(), rots.detach().float().contiguous()
+        n, H, W = color.shape[0], color.shape[2], color.shape[3]
+        if color.shape != (n, 3, H, W) or allmap.shape != (n, 7, H, W) or rays.shape != (n, H, W, 6) or rots.shape != (n, 3, 3):
+            raise RuntimeError("expected color [n,3,H,W], allmap [n,7,H,W], rays [n,H,W,6], rots [n,3,3]")
+        o = dict(dtype=torch.float32, device=color.device)
+        image, depth, acc = torch.empty(H, n * W, 3, **o), torch.empty(H, n * W, 1, **o), torch.empty(H, n * W, **o)
+        rnorm, dnorm, rdist = torch.empty(H, n * W, 3, **o), torch.empty(H, n * W, 3, **o), torch.empty(H, n * W, **o)
+        with torch.cuda.device(color.device):
+            _check(_lib().lara_surface_maps_forward_views(n, H, W, color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), rots.data_ptr(),
+                                                          float(depth_ratio), image.data_ptr(), depth.data_ptr(), acc.data_ptr(),
+                                                          rnorm.data_ptr(), dnorm.data_ptr(), rdist.data_ptr(),
+                                                          torch.cuda.current_stream(color.device).cuda_stream),
+                   "lara_surface_maps_forward_views")
+        ctx.save_for_backward(color, allmap, rays, rots)
+        ctx.depth_ratio = float(depth_ratio)
+        return image, depth, acc, rnorm, dnorm, rdist
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth, g_acc, g_rnorm, g_dnorm, g_rdist):
+        color, allmap, rays, rots = ctx.saved_tensors
+        n, H, W = color.shape[0], color.shape[2], color.shape[3]
+        gs = [None if g is None else g.float().contiguous() for g in (g_image, g_depth, g_acc, g_rnorm, g_dnorm, g_rdist)]
+        d_color, d_allmap = torch.empty_like(color), torch.empty_like(allmap)
+        with torch.cuda.device(color.device):
+            _check(_lib().lara_surface_maps_backward_views(n, H, W, color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), rots.data_ptr(),
+                                                           ctx.depth_ratio, *[None if g is None else g.data_ptr() for g in gs],
+                                                           d_color.data_ptr(), d_allmap.data_ptr(),
+                                                           torch.cuda.current_stream(color.device).cuda_stream),
+                   "lara_surface_maps_backward_views")
+        return d_color, d_allmap, None, None, None
+
+
+def surface_maps_views(color, allmap, rays, rots, depth_ratio=0.0):
+    """The fused post-processing of n views at once, outputs concatenated along the width (see `_SurfaceMapsViews`)."""
+    return _SurfaceMapsViews.apply(color, allmap, rays, rots, depth_ratio)
 
 
 def surface_maps(color, allmap, rays, rot, depth_ratio=0.0):
@@ -180,19 +230,27 @@ class Renderer(nn.Module):
                 f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist}
 
     def render_views(self, cams, rays, centers, shs, opacity, scales, rotations, device, bg_colors=None,
-                     cov3D_precomp=None, prex='', depth_ratio=0.0):
+                     cov3D_precomp=None, prex='', depth_ratio=0.0, concat=False):
         """All views of a scene in ONE rasteriser call (one autograd node, per-camera state carved from one
         allocation, gradients summed over the views inside the library): what the reference's inner loop
         (lightning/network.py:486-497 coarse, :516-525 fine) does with one ``render_img`` per view.  ``cams`` is a
         sequence of cameras, ``rays`` the matching sequence of ray maps (or a stacked tensor), ``bg_colors`` the
         per-view backgrounds the loop passes through ``set_bg_color`` (default: this renderer's colour).  Returns the
-        list of per-view dictionaries ``render_img`` would have returned."""
+        list of per-view dictionaries ``render_img`` would have returned; with ``concat=True`` ONE dictionary whose maps
+        are the views' maps side by side, [H, n*W, C] -- what network.py:527 builds with ``torch.cat(..., dim=1)`` --
+        written by one post-processing launch for all views."""
         n = len(cams)
         bgs = [None] * n if bg_colors is None else list(bg_colors)
         settings = [self._settings(cam, device=device, bg=bg) for cam, bg in zip(cams, bgs)]
         opacity, scales, rotations = self._activated(opacity, scales, rotations)
         color, radii, allmap = rasterize_gaussians_views(settings, centers, self._zero_means2D(centers), opacity, shs=shs,
                                                          scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        if concat and rays is not None:
+            rots = torch.stack([cam.world_view_transform[:3, :3] for cam in cams]).transpose(1, 2)       # renderer_2dgs.py:231
+            rays_t = rays if torch.is_tensor(rays) else torch.stack(list(rays))
+            image, depth, acc, rnorm, dnorm, rdist = surface_maps_views(color, allmap, rays_t, rots, depth_ratio)
+            return {f"image{prex}": image, f"depth{prex}": depth, f"acc_map{prex}": acc, f"rend_normal{prex}": rnorm,
+                    f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist}
         out = []
         for i, cam in enumerate(cams):
             if rays is None:

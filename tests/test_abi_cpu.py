@@ -93,3 +93,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(rz, "_lib", None, raising=False)
     with pytest.raises(RuntimeError, match="HIP library not found"):
         rz.load_library()
+
+
+def test_buffer_sizes_are_quantised_in_the_surfel_count(hip_lib):
+    """The fine pass renders a subset whose size changes every step; buffers sized from the exact count would be a new
+    allocation size per call.  Sizes come from the count rounded up, and a buffer sized for the rounded count holds the
+    exact one."""
+    from lara_amd import rasterizer
+    assert rasterizer._sizing_P(262100) == rasterizer._sizing_P(262144) == 262144
+    assert rasterizer._sizing_P(262145) == 327680 and rasterizer._sizing_P(0) == 1024 and rasterizer._sizing_P(1500) == 2048
+    for P in (1, 1023, 70000, 262100, 524288):
+        q = rasterizer._sizing_P(P)
+        cap = rasterizer.binning_capacity(P)
+        assert q >= P and cap == rasterizer.binning_capacity(q)
+        assert hip_lib.lara2dgs_state_bytes(q, 512, 512, cap) >= hip_lib.lara2dgs_state_bytes(P, 512, 512, cap)
+        assert hip_lib.lara2dgs_scratch_bytes(q, 512, 512, cap) >= hip_lib.lara2dgs_scratch_bytes(P, 512, 512, cap)

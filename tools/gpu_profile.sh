@@ -8,12 +8,16 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# (a) the headline command (training step: encoder + raster, multi-view calls, 2 scene streams)
+# (a) the headline command (the whole pipeline step, multi-view calls, 2 scene streams)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_train -o stats -- \
     python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats_train.log 2>&1
-# (b) the raster kernels one at a time (one call per view, one stream): the durations the roofline object is built from
+# (b) the raster kernels one at a time (one call per view, one stream, ONLY the timed steps: --no-roofline keeps the
+#     bench's two-stream / two-lane side legs out of the averages): the durations the roofline object is built from
+# (a') the pipeline step on ONE stream: every kernel of the step, torch's included, serialised
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_pipe1 -o stats -- \
+    python $REPO/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats_pipe1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -o stats -- \
-    python $REPO/bench.py --steps 2 --warmup 1 --step raster --raster-api loop --streams 1 --no-fine --no-cpu-baseline --no-side-legs $EXTRA > $OUT/prof_${TAG}_stats.log 2>&1
+    python $REPO/bench.py --steps 2 --warmup 1 --step raster --raster-api loop --streams 1 --no-fine --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats.log 2>&1
 # counters in their own passes (no stats / other trace domains); the raster alone, one call per view, one scene
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
     -d $OUT/prof_${TAG}_pmc -o pmc -- \
@@ -22,6 +26,6 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE S
     -d $OUT/prof_${TAG}_pmc2 -o pmc -- \
     python $REPO/bench.py --steps 1 --warmup 0 --scenes 1 --step raster --raster-api loop --streams 1 --no-fine --no-cpu-baseline --no-roofline $EXTRA > $OUT/prof_${TAG}_pmc2.log 2>&1
 # keep only what is small enough to travel back
-find $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_stats_train $OUT/prof_${TAG}_pmc $OUT/prof_${TAG}_pmc2 -type f -size +8M -delete
+find $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_stats_train $OUT/prof_${TAG}_stats_pipe1 $OUT/prof_${TAG}_pmc $OUT/prof_${TAG}_pmc2 -type f -size +8M -delete
 find $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_pmc $OUT/prof_${TAG}_pmc2 -type f | head -50
 du -sh $OUT

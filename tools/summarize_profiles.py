@@ -30,6 +30,9 @@ if st:
 sts = glob.glob(os.path.join(out, f"prof_{tag}_stats_train", "**", "*kernel_stats.csv"), recursive=True)
 if sts:
     shutil.copy(sts[0], os.path.join(prof, f"{tag}_kernel_stats_train_step.csv"))
+sts = glob.glob(os.path.join(out, f"prof_{tag}_stats_pipe1", "**", "*kernel_stats.csv"), recursive=True)
+if sts:
+    shutil.copy(sts[0], os.path.join(prof, f"{tag}_kernel_stats_pipeline_one_stream.csv"))
 agg, cnt = pmc_table(os.path.join(out, f"prof_{tag}_pmc*", "**", "*counter_collection.csv"))
 if agg:
     cols = sorted({c for d in agg.values() for c in d})
