@@ -43,6 +43,17 @@ int lara_surface_maps_backward(int32_t H, int32_t W, const float *color, const f
                                const float *g_acc_map, const float *g_rend_normal, const float *g_depth_normal,
                                const float *g_rend_dist, float *d_color, float *d_allmap, void *stream);
 
+/* The three activations `render_img` applies in front of the rasteriser call (renderer_2dgs.py:181-189) as one launch per
+ * direction: opacity [P,1] -> sigmoid, scales [P,2] -> exp, rotations [P,4] -> x / max(|x|_2, 1e-12) (F.normalize).
+ * scales / rotations (and their outputs) may be NULL (the cov3D_precomp path).  The backward takes the ACTIVATED opacity and
+ * scales and the RAW rotations; gradients may be NULL (= zero), outputs NULL (= not wanted). */
+int lara_activate_gaussians_forward(int64_t P, const float *opacity, const float *scales, const float *rotations,
+                                    float *opacity_out, float *scales_out, float *rotations_out, void *stream);
+
+int lara_activate_gaussians_backward(int64_t P, const float *opacity_act, const float *scales_act, const float *rotations,
+                                     const float *g_opacity, const float *g_scales, const float *g_rotations,
+                                     float *d_opacity, float *d_scales, float *d_rotations, void *stream);
+
 /* All views of a scene in one launch per direction, written side by side the way `Network.forward` concatenates them
  * (lightning/network.py:527: `torch.cat([view[k] ...], dim=1)`): color [n,3,H,W], allmap [n,7,H,W], rays [n,H,W,6],
  * rots [n,9]; every output (and, in the backward, every output gradient) is ONE [H, n*W, C] map in which view v owns the

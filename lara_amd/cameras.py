@@ -58,7 +58,9 @@ def make_cameras(c2w: torch.Tensor, width: int, height: int, fovx: float, fovy: 
     wvt = w2c.transpose(1, 2).contiguous().to(device)
     PT = projection_matrix(znear, zfar, fovx, fovy).t().contiguous().to(device)
     full = (wvt @ PT).float().contiguous()
-    centers = (-c2w[:, :3, 3]).contiguous().to(device)
+    # (rows of 4 floats: every view's centre starts on a 16-byte boundary, which the rasteriser's camera loads want --
+    # a [V,3] tensor's rows do not, and each would be cloned on every rasteriser call)
+    centers = torch.nn.functional.pad(-c2w[:, :3, 3], (0, 1)).contiguous().to(device)[:, :3]
     return [Camera(int(width), int(height), float(fovx), float(fovy), float(znear), float(zfar),
                    wvt[i], PT, full[i], centers[i]) for i in range(c2w.shape[0])]
 

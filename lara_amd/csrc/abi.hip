@@ -389,7 +389,9 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
             ScratchLayout SL;
             sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL);
             rad[i] = out_radii + (int64_t)i * v0.P;
-            HIP_TRY(hipMemsetAsync(sc[i].tile_count, 0, (size_t)(SL.sub_start - SL.tile_count), caller));
+            if (i == 0)   // the views agree in (P, H, W, capacity): one layout, one strided fill for all of them
+                HIP_TRY(hipMemset2DAsync(sc[0].tile_count, (size_t)scratch_stride, 0, (size_t)(SL.sub_start - SL.tile_count),
+                                         (size_t)n_views, caller));
         }
         for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
             const int nb = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
@@ -470,12 +472,13 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
             sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL[i]);
             rad[i] = radii + (int64_t)i * v0.P;
         }
+        // validity bitmaps of all views: one strided fill on the caller's stream, in front of the fork
+        HIP_TRY(hipMemset2DAsync(sc[0].pair_valid, (size_t)scratch_stride, 0, (size_t)(SL[0].total - SL[0].pair_valid),
+                                 (size_t)n_views, caller));
         if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
         for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
         for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
             hipStream_t s = lane_stream(i % lanes);
-            const hipError_t e = hipMemsetAsync(sc[i].pair_valid, 0, (size_t)(SL[i].total - SL[i].pair_valid), s);
-            if (e != hipSuccess) { l2d_set_hip_error(e); rc = LARA2DGS_E_LAUNCH; break; }
             rc = launch_composite_bwd(vd[i], st[i], sc[i], dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW, s);
         }
         for (int k = 1; k < lanes; k++) {

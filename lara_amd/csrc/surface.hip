@@ -152,9 +152,82 @@ surface_bwd_kernel(const SurfP p0, const float *__restrict__ g_image, const floa
     d_allmap[6 * HW + pix] = g_rd ? g_rd[o] : 0.f;
 }
 
+// ---- the three activations in front of the rasteriser call (renderer_2dgs.py:181-189), one thread per Gaussian ----------
+__global__ void __launch_bounds__(256)
+activate_fwd_kernel(const int64_t P, const float *__restrict__ opacity, const float2 *__restrict__ scales,
+                    const float4 *__restrict__ rotations, float *__restrict__ o_out, float2 *__restrict__ s_out,
+                    float4 *__restrict__ r_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    o_out[i] = 1.0f / (1.0f + expf(-opacity[i]));                      // torch.sigmoid
+    if (scales) { const float2 v = scales[i]; s_out[i] = make_float2(expf(v.x), expf(v.y)); }   // torch.exp
+    if (rotations) {                                                    // F.normalize: x / max(|x|, 1e-12)
+        const float4 q = rotations[i];
+        const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        r_out[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+activate_bwd_kernel(const int64_t P, const float *__restrict__ o_act, const float2 *__restrict__ s_act,
+                    const float4 *__restrict__ rotations, const float *__restrict__ g_o, const float2 *__restrict__ g_s,
+                    const float4 *__restrict__ g_r, float *__restrict__ d_o, float2 *__restrict__ d_s, float4 *__restrict__ d_r) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    if (d_o) { const float y = o_act[i]; d_o[i] = g_o ? g_o[i] * (1.0f - y) * y : 0.f; }
+    if (d_s) {
+        const float2 y = s_act[i], g = g_s ? g_s[i] : make_float2(0.f, 0.f);
+        d_s[i] = make_float2(g.x * y.x, g.y * y.y);
+    }
+    if (d_r) {
+        const float4 q = rotations[i], g = g_r ? g_r[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (n > 1e-12f) {      // y = q / n: dq = (g - y (y . g)) / n
+            const float inv = 1.0f / n;
+            const float4 y = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+            const float dot = y.x * g.x + y.y * g.y + y.z * g.z + y.w * g.w;
+            d_r[i] = make_float4((g.x - y.x * dot) * inv, (g.y - y.y * dot) * inv, (g.z - y.z * dot) * inv, (g.w - y.w * dot) * inv);
+        } else {               // clamped denominator: y = q * 1e12
+            d_r[i] = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int lara_activate_gaussians_forward(int64_t P, const float *opacity, const float *scales, const float *rotations,
+                                    float *opacity_out, float *scales_out, float *rotations_out, void *stream) {
+    if (P < 0) return LARA2DGS_E_INVALID;
+    if (P == 0) return LARA2DGS_OK;
+    if (!opacity || !opacity_out || (scales && !scales_out) || (rotations && !rotations_out)) return LARA2DGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        L2D_PROF("activate_fwd", s);
+        hipLaunchKernelGGL(activate_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, opacity, (const float2 *)scales,
+                           (const float4 *)rotations, opacity_out, (float2 *)scales_out, (float4 *)rotations_out);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int lara_activate_gaussians_backward(int64_t P, const float *opacity_act, const float *scales_act, const float *rotations,
+                                     const float *g_opacity, const float *g_scales, const float *g_rotations,
+                                     float *d_opacity, float *d_scales, float *d_rotations, void *stream) {
+    if (P < 0) return LARA2DGS_E_INVALID;
+    if (P == 0) return LARA2DGS_OK;
+    if ((d_opacity && !opacity_act) || (d_scales && !scales_act) || (d_rotations && !rotations)) return LARA2DGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        L2D_PROF("activate_bwd", s);
+        hipLaunchKernelGGL(activate_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, opacity_act,
+                           (const float2 *)scales_act, (const float4 *)rotations, g_opacity, (const float2 *)g_scales,
+                           (const float4 *)g_rotations, d_opacity, (float2 *)d_scales, (float4 *)d_rotations);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
 
 int lara_surface_maps_forward_views(int32_t n_views, int32_t H, int32_t W, const float *color, const float *allmap, const float *rays,
                                     const float *rots, float depth_ratio, float *image, float *depth, float *acc_map,

@@ -38,6 +38,10 @@ def _lib():
         lib.lara_surface_maps_forward.argtypes = [i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
         lib.lara_surface_maps_backward.restype = ctypes.c_int
         lib.lara_surface_maps_backward.argtypes = [i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.lara_activate_gaussians_forward.restype = ctypes.c_int
+        lib.lara_activate_gaussians_forward.argtypes = [ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp]
+        lib.lara_activate_gaussians_backward.restype = ctypes.c_int
+        lib.lara_activate_gaussians_backward.argtypes = [ctypes.c_int64] + [vp] * 10
         lib.lara_surface_maps_forward_views.restype = ctypes.c_int
         lib.lara_surface_maps_forward_views.argtypes = [i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
         lib.lara_surface_maps_backward_views.restype = ctypes.c_int
@@ -70,6 +74,7 @@ class _SurfaceMaps(torch.autograd.Function):
                    "lara_surface_maps_forward")
         ctx.save_for_backward(color, allmap, rays, rot)
         ctx.depth_ratio = float(depth_ratio)
+        ctx.set_materialize_grads(False)     # an output the loss does not read keeps a None gradient (kernel: NULL = zero)
         return image, depth, acc, rnorm, dnorm, rdist
 
     @staticmethod
@@ -85,6 +90,48 @@ class _SurfaceMaps(torch.autograd.Function):
                                                      torch.cuda.current_stream(color.device).cuda_stream),
                    "lara_surface_maps_backward")
         return d_color, d_allmap, None, None, None
+
+
+class _Activate(torch.autograd.Function):
+    """(opacity [P,1], scales [P,2], rotations [P,4]) -> (sigmoid, exp, F.normalize) of them (renderer_2dgs.py:181-189) in one
+    launch per direction instead of ~6 torch kernels forward and ~17 backward per set of Gaussians."""
+
+    @staticmethod
+    def forward(ctx, opacity, scales, rotations):
+        if not opacity.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        P = opacity.shape[0]
+        if opacity.shape != (P, 1) or scales.shape != (P, 2) or rotations.shape != (P, 4):
+            raise RuntimeError("expected opacity [P,1], scales [P,2], rotations [P,4]")
+        o, s, r = (t.detach().float().contiguous() for t in (opacity, scales, rotations))
+        oa, sa, ra = torch.empty_like(o), torch.empty_like(s), torch.empty_like(r)
+        with torch.cuda.device(o.device):
+            _check(_lib().lara_activate_gaussians_forward(P, o.data_ptr(), s.data_ptr(), r.data_ptr(), oa.data_ptr(), sa.data_ptr(),
+                                                          ra.data_ptr(), torch.cuda.current_stream(o.device).cuda_stream),
+                   "lara_activate_gaussians_forward")
+        ctx.save_for_backward(oa, sa, r)
+        ctx.set_materialize_grads(False)
+        return oa, sa, ra
+
+    @staticmethod
+    def backward(ctx, g_o, g_s, g_r):
+        oa, sa, r = ctx.saved_tensors
+        P = oa.shape[0]
+        gs = [None if g is None else g.float().contiguous() for g in (g_o, g_s, g_r)]
+        need = ctx.needs_input_grad
+        d = [torch.empty_like(t) if n else None for t, n in zip((oa, sa, r), need)]
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(oa.device):
+            _check(_lib().lara_activate_gaussians_backward(P, oa.data_ptr(), sa.data_ptr(), r.data_ptr(), ptr(gs[0]), ptr(gs[1]),
+                                                           ptr(gs[2]), ptr(d[0]), ptr(d[1]), ptr(d[2]),
+                                                           torch.cuda.current_stream(oa.device).cuda_stream),
+                   "lara_activate_gaussians_backward")
+        return tuple(d)
+
+
+def activate_gaussians(opacity, scales, rotations):
+    """sigmoid(opacity), exp(scales), F.normalize(rotations): the fused form of renderer_2dgs.py:181-189."""
+    return _Activate.apply(opacity, scales, rotations)
 
 
 class _SurfaceMapsViews(torch.autograd.Function):
@@ -111,6 +158,7 @@ class _SurfaceMapsViews(torch.autograd.Function):
                    "lara_surface_maps_forward_views")
         ctx.save_for_backward(color, allmap, rays, rots)
         ctx.depth_ratio = float(depth_ratio)
+        ctx.set_materialize_grads(False)     # an output the loss does not read keeps a None gradient (kernel: NULL = zero)
         return image, depth, acc, rnorm, dnorm, rdist
 
     @staticmethod
@@ -204,8 +252,14 @@ class Renderer(nn.Module):
         those tensors, as network.py does: a backward in between frees the shared nodes' graph.)"""
         key = tuple(self._tensor_key(t) for t in (opacity, scales, rotations)) + (torch.is_grad_enabled(),)
         if key != self._act_key:
-            self._act_val = (self.get_opacity(opacity), None if scales is None else self.get_scaling(scales),
-                             None if rotations is None else self.get_rotation(rotations), (opacity, scales, rotations))
+            fused = (scales is not None and rotations is not None and opacity.is_cuda and opacity.dim() == 2
+                     and self.scaling_activation is torch.exp and self.opacity_activation is torch.sigmoid
+                     and self.rotation_activation is torch.nn.functional.normalize)
+            if fused:       # one launch per direction for the three of them
+                self._act_val = activate_gaussians(opacity, scales, rotations) + ((opacity, scales, rotations),)
+            else:
+                self._act_val = (self.get_opacity(opacity), None if scales is None else self.get_scaling(scales),
+                                 None if rotations is None else self.get_rotation(rotations), (opacity, scales, rotations))
             self._act_key = key
         return self._act_val[:3]
 
@@ -240,6 +294,8 @@ class Renderer(nn.Module):
         are the views' maps side by side, [H, n*W, C] -- what network.py:527 builds with ``torch.cat(..., dim=1)`` --
         written by one post-processing launch for all views."""
         n = len(cams)
+        if torch.is_tensor(bg_colors) and bg_colors.dim() == 2:     # rows on 16-byte boundaries (see cameras.make_cameras)
+            bg_colors = torch.nn.functional.pad(bg_colors.float(), (0, 1))[:, :3]
         bgs = [None] * n if bg_colors is None else list(bg_colors)
         settings = [self._settings(cam, device=device, bg=bg) for cam, bg in zip(cams, bgs)]
         opacity, scales, rotations = self._activated(opacity, scales, rotations)

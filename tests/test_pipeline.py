@@ -181,10 +181,10 @@ def test_pipeline_equals_the_operators_called_one_by_one(hip_lib, with_fine, n_s
     # gradients: the same terms, summed over the views inside the library instead of by autograd (other order: ~1e-6
     # relative on the Gaussians' gradients).  The fine decoder's parameters see that directly (fp32 path: 2e-4 of max);
     # the coarse MLP (bf16 autocast) and the encoder (bf16 operands in every backward product) round those inputs to
-    # bf16 first, where a last-bit difference is 4e-3 relative: 5e-3 of max, direction to 1 - 1e-5
+    # bf16 first, where a last-bit difference is 4e-3 relative and a few such roundings chain: 1e-2 of max, direction to 1 - 1e-5
     def close(a, b, n):
         fp32_path = n.startswith(("decoder.norm", "decoder.cross_att", "decoder.mlp_fine"))
-        assert float((a - b).abs().max()) <= (2e-4 if fp32_path else 5e-3) * float(b.abs().max()) + 1e-12, n
+        assert float((a - b).abs().max()) <= (2e-4 if fp32_path else 1e-2) * float(b.abs().max()) + 1e-12, n
         cos = float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm() + 1e-300))
         assert cos >= 1 - 1e-5, (n, cos)
     for n in grads_a:
