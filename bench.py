@@ -986,6 +986,7 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     g = torch.Generator(device="cpu").manual_seed(11 + rank)
     batch["tar_rgb"] = torch.rand(batch["tar_rgb"].shape, generator=g).to(device)
     feat_vol = torch.randn(args.scenes, 4, 800, args.grid // 4, args.grid // 4, args.grid // 4, generator=g).to(device)
+    feat_vol.requires_grad_(True)     # the DINO encoder in front is trained too (network.py:314): its features want a gradient
     n_par = sum(p.numel() for p in pipe.parameters() if p.requires_grad)
     info["encoder"] = {"parameters": sum(p.numel() for p in enc.parameters()), "layers": args.encoder_layers}
     model = pipe
@@ -1008,6 +1009,7 @@ def make_pipeline_step(args, device, rank, world, plumbing):
         pipe.join_streams()
         for p in params:
             p.grad = None
+        feat_vol.grad = None
 
     def after_first_step():
         if info["grad_allreduce"] is not None:

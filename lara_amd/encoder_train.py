@@ -306,6 +306,222 @@ class _VolTransFn(torch.autograd.Function):
         return (d_feats, None, None, None, None, d_pos, d_nw, d_nb, d_deconv_w, d_deconv_b, *grads)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The same forward / backward as ONE AUTOGRAD NODE PER BLOCK (the default): a block's 15 parameter gradients are
+# released the moment its backward returns, so torch DDP's reducer (train_lightning.py:68-81) fills and all-reduces
+# its buckets while the earlier blocks' backward is still running -- with `_VolTransFn` above every gradient appears
+# only when the whole 12-layer sweep is over and no bucket can overlap it.  Same kernels, same order, same bits.
+#
+#   image_feats --_CondFn--> (cond_bf16, token) ;  (pos_embed, token) --_StartFn--> x0 --_BlockFn x L--> x_L --_HeadFn--> out
+#
+# `token` is a one-element tensor whose only job is graph order: _StartFn's backward (after block 0's) hands it a
+# gradient, which makes _CondFn's backward the LAST node to run -- it forms dL/d(image_feats) from the dK|dV every
+# block left in the sweep's shared buffer with ONE product (K = layers * 512), as `_VolTransFn.backward` does.
+# ---------------------------------------------------------------------------------------------------------------
+_ws_owner = {}     # device index -> (id of the sweep, layer) whose block backward used the "block_bwd" workspace last
+_block_bwd_log = None   # tests: set to a list to record (event, layer) as the sweep runs
+
+
+class _Sweep:
+    """What the nodes of one forward share (not graph tensors)."""
+
+    def __init__(self, B, R, cond_dim, n_layers, eps_block, dev):
+        self.B, self.R, self.cond_dim, self.n_layers, self.eps_block, self.dev = B, R, cond_dim, n_layers, eps_block, dev
+        self.cond_bf = None
+        self.fs = [None] * n_layers       # bf16 operands of every layer (kept for the dcond product)
+        self.dkv_all = None               # [rows, layers * 512] bf16: dK|dV of every block
+        self.flat = None                  # all layers' gradient accumulators, one zero fill
+        self.offs = self.shapes = self.per_layer = None
+
+    def accumulators(self, l):
+        f = self.fs[l]
+        if self.flat is None:
+            self.shapes = {n: tuple(f[n].shape) for n in _GRAD_FIELDS}
+            self.offs, o = {}, 0
+            for n in _GRAD_FIELDS:
+                self.offs[n] = o
+                o += (math.prod(self.shapes[n]) + 63) // 64 * 64
+            self.per_layer = o
+            self.flat = torch.zeros(self.n_layers * o, dtype=torch.float32, device=self.dev)
+        base = l * self.per_layer
+        return {n: self.flat[base + self.offs[n]:base + self.offs[n] + math.prod(self.shapes[n])].view(self.shapes[n])
+                for n in _GRAD_FIELDS}
+
+
+class _CondFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image_feats, sweep):
+        lib = _lib()
+        dev = image_feats.device
+        B, V, C = image_feats.shape[:3]
+        S = image_feats.shape[3] * image_feats.shape[4] * image_feats.shape[5]
+        feats = image_feats.detach().float().contiguous()
+        cond_bf = torch.empty(B * S, V, C, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            _check(lib.lara_batched_transpose(B, V * C, S, feats.data_ptr(), cond_bf.data_ptr(), 1, _stream(dev)),
+                   "lara_batched_transpose")
+        sweep.cond_bf = cond_bf
+        ctx.sweep, ctx.feat_shape, ctx.feat_dtype = sweep, tuple(image_feats.shape), image_feats.dtype
+        return torch.zeros(1, dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def backward(ctx, g_token):
+        lib, sw = _lib(), ctx.sweep
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        dev = sw.dev
+        cond_bf = sw.cond_bf
+        dcond = torch.empty(cond_bf.shape, dtype=torch.float32, device=dev)
+        lddkv = sw.n_layers * 512
+        with torch.cuda.device(dev):
+            wkv_all_t = torch.cat([f["wkv"] for f in sw.fs], 0).t().contiguous()
+            _check(lib.lara_gemm_nt_bf16(sw.dkv_all.shape[0], sw.cond_dim, lddkv, sw.dkv_all.data_ptr(), wkv_all_t.data_ptr(),
+                                         dcond.data_ptr(), 1, _stream(dev)), "lara_gemm_nt_bf16")
+            Bf, V, C = ctx.feat_shape[:3]
+            S = dcond.shape[0] // Bf
+            d_feats = torch.empty(ctx.feat_shape, dtype=torch.float32, device=dev)
+            _check(lib.lara_batched_transpose(Bf, S, V * C, dcond.data_ptr(), d_feats.data_ptr(), 0, _stream(dev)),
+                   "lara_batched_transpose")
+        sw.dkv_all = sw.flat = None
+        return (d_feats if ctx.feat_dtype == torch.float32 else d_feats.to(ctx.feat_dtype)), None
+
+
+class _StartFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos_embed, token, B, R):
+        ctx.B, ctx.R = B, R
+        return volume_to_tokens(pos_embed.detach().float()).repeat(B, 1)        # network.py:152
+
+    @staticmethod
+    def backward(ctx, g):
+        # the same positional rows enter every scene
+        return tokens_to_volume(g.view(ctx.B, ctx.R ** 3, 256).sum(0), 1, ctx.R), torch.zeros(1, dtype=torch.float32, device=g.device), None, None
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sweep, l, *p):
+        lib, sw = _lib(), sweep
+        dev = x.device
+        f = sw.fs[l] = _layer_bf16([t.detach() for t in p])
+        w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
+        w.eps = sw.eps_block
+        keep = _keep_activations()
+        with torch.cuda.device(dev):
+            if keep:
+                nsave = lib.lara_groupblock_save_bytes(sw.B, sw.R)
+                if nsave < 0:
+                    _check(int(nsave), "lara_groupblock_save_bytes")
+                act = torch.empty(nsave, dtype=torch.uint8, device=dev)
+                x_out = torch.empty_like(x)
+                _check(lib.lara_groupblock_forward_train(sw.B, sw.R, sw.cond_dim, x.data_ptr(), x_out.data_ptr(), sw.cond_bf.data_ptr(),
+                                                         ctypes.byref(w), act.data_ptr(), _stream(dev)),
+                       "lara_groupblock_forward_train")
+            else:
+                act = None
+                x_out = x.clone()
+                ws = _workspace(dev, "fwd", lib.lara_groupblock_workspace_bytes(sw.B, sw.R))
+                _check(lib.lara_groupblock_forward(sw.B, sw.R, sw.cond_dim, x_out.data_ptr(), sw.cond_bf.data_ptr(), ctypes.byref(w),
+                                                   ws.data_ptr(), _stream(dev)), "lara_groupblock_forward")
+        ctx.save_for_backward(x)
+        ctx.sweep, ctx.l, ctx.act = sw, l, act
+        return x_out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib, sw, l = _lib(), ctx.sweep, ctx.l
+        (x_in,) = ctx.saved_tensors
+        dev = sw.dev
+        f = sw.fs[l]
+        ft = _layer_bf16_t(f)
+        w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
+        w.eps = sw.eps_block
+        wt = _fill(_BlockWeightsT(), ft, ("wq_t", "wkv_t", "wo_t", "w1_t", "w2_t", "wconv_t"))
+        lddkv = sw.n_layers * 512
+        if sw.dkv_all is None:
+            sw.dkv_all = torch.empty(sw.cond_bf.shape[0] * sw.cond_bf.shape[1], lddkv, dtype=torch.bfloat16, device=dev)
+        gd = sw.accumulators(l)
+        dw = _fill(_BlockGrads(), gd, _GRAD_FIELDS)
+        g = g.float()
+        if not g.is_contiguous():
+            g = g.contiguous()
+        # `chained`: the workspace still holds what block l + 1 of THIS sweep left (the bf16 copy of g, the neighbour table)
+        chained = int(_ws_owner.get(dev.index) == (id(sw), l + 1))
+        with torch.cuda.device(dev):
+            ws = _workspace(dev, "block_bwd", lib.lara_groupblock_backward_workspace_bytes(sw.B, sw.R))
+            if _block_bwd_log is not None:
+                _block_bwd_log.append(("block_backward_launch", l))
+            _check(lib.lara_groupblock_backward(sw.B, sw.R, sw.cond_dim, x_in.data_ptr(), sw.cond_bf.data_ptr(), ctypes.byref(w),
+                                                ctypes.byref(wt), None if ctx.act is None else ctx.act.data_ptr(), g.data_ptr(), None,
+                                                ctypes.byref(dw), chained, sw.dkv_all.data_ptr() + l * 1024, lddkv, ws.data_ptr(),
+                                                _stream(dev)), "lara_groupblock_backward")
+        _ws_owner[dev.index] = (id(sw), l)
+        ctx.act = None
+        return (g, None, None, gd["ln1_w"], gd["ln1_b"], gd["wq"], gd["wkv"][:256], gd["wkv"][256:], gd["wo"], gd["ln2_w"], gd["ln2_b"],
+                gd["w1"], gd["b1"], gd["w2"], gd["b2"], gd["ln3_w"], gd["ln3_b"],
+                gd["wconv"].view(256, 3, 3, 3, 256).permute(0, 4, 1, 2, 3))
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, deconv_w, deconv_b, sweep, eps_final, out_dim):
+        lib, sw = _lib(), sweep
+        dev = x.device
+        M = sw.B * sw.R ** 3
+        with torch.cuda.device(dev):
+            wd = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).contiguous()
+            nw, nb, db = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous(), deconv_b.detach().float().contiguous()
+            out = torch.empty(sw.B, 2 * sw.R, 2 * sw.R, 2 * sw.R, out_dim, dtype=torch.float32, device=dev)
+            hws = _workspace(dev, "head", M * 512)
+            _check(lib.lara_voltrans_head_forward(sw.B, sw.R, x.data_ptr(), nw.data_ptr(), nb.data_ptr(), float(eps_final),
+                                                  wd.data_ptr(), db.data_ptr(), out_dim, out.data_ptr(), hws.data_ptr(),
+                                                  _stream(dev)), "lara_voltrans_head_forward")
+        ctx.save_for_backward(x, norm_w, norm_b, deconv_w)
+        ctx.sweep, ctx.eps_final, ctx.out_dim = sw, float(eps_final), out_dim
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib, sw = _lib(), ctx.sweep
+        x_last, norm_w, norm_b, deconv_w = ctx.saved_tensors
+        dev, out_dim = sw.dev, ctx.out_dim
+        M = sw.B * sw.R ** 3
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = dout.float().contiguous()
+        g = torch.empty(M, 256, **f32)
+        d_nw, d_nb = torch.zeros(256, **f32), torch.zeros(256, **f32)
+        d_wd, d_b8 = torch.zeros(8 * out_dim, 256, **f32), torch.zeros(8 * out_dim, **f32)
+        with torch.cuda.device(dev):
+            wd_t = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).t().contiguous()
+            nw, nb = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous()
+            hws = _workspace(dev, "head_bwd", lib.lara_voltrans_head_backward_workspace_bytes(sw.B, sw.R, out_dim))
+            _check(lib.lara_voltrans_head_backward(sw.B, sw.R, x_last.data_ptr(), nw.data_ptr(), nb.data_ptr(), ctx.eps_final,
+                                                   wd_t.data_ptr(), out_dim, dout.data_ptr(), g.data_ptr(), d_nw.data_ptr(),
+                                                   d_nb.data_ptr(), d_wd.data_ptr(), d_b8.data_ptr(), hws.data_ptr(),
+                                                   _stream(dev)), "lara_voltrans_head_backward")
+        _ws_owner.pop(dev.index, None)      # a new sweep starts: block L - 1 is not chained to anything
+        return (g, d_nw, d_nb, d_wd.view(2, 2, 2, out_dim, 256).permute(4, 3, 0, 1, 2), d_b8.view(8, out_dim).sum(0), None, None, None)
+
+
+def _forward_per_block(module, image_feats):
+    B, V, C = image_feats.shape[:3]
+    R, n_layers = module.vol_low_res, len(module.layers)
+    sweep = _Sweep(B, R, C, n_layers, float(module.layers[0].norm1.eps), image_feats.device)
+    token = _CondFn.apply(image_feats, sweep)
+    x = _StartFn.apply(module.pos_embed, token, B, R)
+    for l, layer in enumerate(module.layers):
+        x = _BlockFn.apply(x, sweep, l, *layer.flat_params())
+    return _HeadFn.apply(x, module.norm.weight, module.norm.bias, module.deconv.weight, module.deconv.bias, sweep,
+                         float(module.norm.eps), module.out_dim)
+
+
+def _monolithic() -> bool:
+    """LARA_ENCODER_MONOLITHIC=1: the whole transformer as one autograd node (`_VolTransFn`), as in round 2 -- for A/B
+    runs and the equivalence test; gradients are identical bit for bit."""
+    import os
+    return os.environ.get("LARA_ENCODER_MONOLITHIC", "0") == "1"
+
+
 class GroupAttBlock(nn.Module):
     """Parameter container with the reference's attribute names (network.py:57-79)."""
 
@@ -358,6 +574,8 @@ class VolTransformer(nn.Module):
         B, V, C, D = image_feats.shape[:4]
         if D != self.n_groups[0] or V != 4:
             raise RuntimeError("kernels are specialised for one image-feature voxel per group and 4 input views")
+        if torch.is_grad_enabled() and not _monolithic():
+            return _forward_per_block(self, image_feats)
         flat = [p for layer in self.layers for p in layer.flat_params()]
         return _VolTransFn.apply(image_feats, float(self.layers[0].norm1.eps), float(self.norm.eps), self.vol_low_res, self.out_dim,
                                  self.pos_embed, self.norm.weight, self.norm.bias, self.deconv.weight, self.deconv.bias, *flat)

@@ -29,12 +29,21 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        from lara_amd import encoder_train
         torch.cuda.set_device(0)
-        ddp = torch.nn.parallel.DistributedDataParallel(_model(), find_unused_parameters=True)
+        # small buckets, so that the two blocks' parameters land in different ones
+        ddp = torch.nn.parallel.DistributedDataParallel(_model(), find_unused_parameters=True, bucket_cap_mb=1)
+        log = encoder_train._block_bwd_log = []
+
+        def hook(state, bucket):      # called by the reducer the moment a bucket is full: this is where its all-reduce is enqueued
+            log.append(("allreduce_enqueued", bucket.index()))
+            return default_hooks.allreduce_hook(state, bucket)
+        ddp.register_comm_hook(None, hook)
         feats, dout = _inputs(rank)
         (ddp(feats) * dout).sum().backward()
         torch.cuda.synchronize()
-        out.put((rank, {n: p.grad.cpu().numpy() for n, p in ddp.module.named_parameters()}))   # (by value: this process exits)
+        out.put((rank, {n: p.grad.cpu().numpy() for n, p in ddp.module.named_parameters()}, list(log)))   # (by value: this process exits)
     finally:
         dist.destroy_process_group()
 
@@ -46,8 +55,9 @@ def test_hip_backward_feeds_torch_ddp(hip_lib):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(out.get(timeout=600) for _ in range(2))
-    got = {r: {n: torch.from_numpy(a) for n, a in d.items()} for r, d in got.items()}
+    res = [out.get(timeout=600) for _ in range(2)]
+    logs = {r: log for r, _, log in res}
+    got = {r: {n: torch.from_numpy(a) for n, a in d.items()} for r, d, _ in res}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -61,3 +71,13 @@ def test_hip_backward_feeds_torch_ddp(hip_lib):
         assert torch.equal(got[0][n], got[1][n]), n
         mean = (local[0][n] + local[1][n]) / 2
         assert float((got[0][n] - mean).abs().max()) <= 1e-6 * float(mean.abs().max()) + 1e-9, n
+    # Overlap (train_lightning.py:68-81: DDP all-reduces bucket by bucket WHILE the backward runs): the encoder's backward
+    # is one autograd node per block, so the first bucket's all-reduce is enqueued before the last block's backward
+    # (layer 0) is even launched.  (As one node for the whole transformer -- round 2 -- every bucket came after it.)
+    for rank in range(2):
+        log = logs[rank]
+        first_allreduce = next(i for i, e in enumerate(log) if e[0] == "allreduce_enqueued")
+        last_block = next(i for i, e in enumerate(log) if e == ("block_backward_launch", 0))
+        assert [e[1] for e in log if e[0] == "block_backward_launch"] == [1, 0]
+        assert first_allreduce < last_block, log
+        assert sum(e[0] == "allreduce_enqueued" for e in log) >= 3
