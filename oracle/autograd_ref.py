@@ -58,8 +58,13 @@ def _sh_rgb(deg, shs, means, campos):
 
 
 def render(view, means3D, opacities, shs, scales, rotations, ranges, point_list,
-           clamp_passthrough: bool = True, colors_precomp=None):
-    """Differentiable fp64 forward.  Returns (color [3,H,W], allmap [7,H,W])."""
+           clamp_passthrough: bool = True, colors_precomp=None, tiles=None, lowpass_depth_quirk: bool = False):
+    """Differentiable fp64 forward.  Returns (color [3,H,W], allmap [7,H,W]).
+    `tiles`: render only these tile ids (the other pixels stay zero) -- the full-size arbitration of
+    tools/grad_arbiter.py walks a few dozen tiles of a 512 x 512 frame, not all 1024.
+    `lowpass_depth_quirk`: give the screen-space low-pass branch the PUBLISHED backward (dL/dTw += dL_dz * (s.x, s.y, 1)
+    although its forward depth is Tw.z) through a straight-through term, so that the result can be held against
+    `oracle.backward(..., lowpass_depth_quirk=True)` and the HIP path, which both reproduce the published code."""
     dt = torch.float64
     H, W = int(view.image_height), int(view.image_width)
     vm = torch.as_tensor(view.viewmatrix, dtype=dt).reshape(4, 4)
@@ -100,7 +105,8 @@ def render(view, means3D, opacities, shs, scales, rotations, ranges, point_list,
     gx = (W + 15) // 16
     gy = (H + 15) // 16
     outs_c, outs_a, coords = [], [], []
-    for tile in range(gx * gy):
+    for tile in (range(gx * gy) if tiles is None else tiles):
+        tile = int(tile)
         tx, ty = tile % gx, tile // gx
         ys, xs = torch.meshgrid(torch.arange(ty * 16, min(ty * 16 + 16, H)),
                                 torch.arange(tx * 16, min(tx * 16 + 16, W)), indexing="ij")
@@ -130,7 +136,11 @@ def render(view, means3D, opacities, shs, scales, rotations, ranges, point_list,
             rho2d = 2.0 * (dx * dx + dy * dy)
             use3d = rho3d <= rho2d
             rho = torch.where(use3d, rho3d, rho2d)
-            depth = torch.where(use3d, sx * Tw[g, 0] + sy * Tw[g, 1] + Tw[g, 2], Tw[g, 2].expand(n))
+            flat_depth = Tw[g, 2].expand(n)
+            if lowpass_depth_quirk:      # value Tw.z, gradient dL_dz * (s.x, s.y, 1) into Tw (the published backward)
+                q = sx.detach() * Tw[g, 0] + sy.detach() * Tw[g, 1]
+                flat_depth = flat_depth + (q - q.detach())
+            depth = torch.where(use3d, sx * Tw[g, 0] + sy * Tw[g, 1] + Tw[g, 2], flat_depth)
             ok = ok & (depth >= NEAR_N) & (-0.5 * rho <= 0)
             G = torch.exp(-0.5 * rho)
             a_raw = opac[g] * G

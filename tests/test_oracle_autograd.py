@@ -14,7 +14,7 @@ def _compare(act, cam, bg, sh_degree=1, quirk_free=True, tol=2e-4):
     res = run_oracle(v, to_numpy(act))
     inp = {k: torch.tensor(val.numpy(), dtype=torch.float64, requires_grad=True) for k, val in act.items()}
     c, a = autograd_ref.render(v, inp["means3D"], inp["opacities"], inp["shs"], inp["scales"],
-                               inp["rotations"], res.ranges, res.point_list)
+                               inp["rotations"], res.ranges, res.point_list, lowpass_depth_quirk=not quirk_free)
     assert np.abs(c.detach().numpy() - res.color).max() < 2e-5
     assert np.abs(a.detach().numpy() - res.allmap).max() < 5e-5
     H, W = res.color.shape[1:]
@@ -41,6 +41,33 @@ def test_backward_with_low_pass_branch_and_sh3():
     # sub-pixel surfels: most hits take the screen-space low-pass branch (mean2D gradient path)
     act, cams = small_scene(grid=8, size=48, seed=2, scale_boost=0.2, opacity_boost=3.0, sh_coeffs=16)
     _compare(act, cams[0], (0.1, 0.2, 0.3), sh_degree=3)
+
+
+def test_published_low_pass_depth_quirk_is_reproduced_by_the_straight_through_form():
+    # the same sub-pixel scene with the PUBLISHED backward on both sides (what the HIP path implements): the fp64
+    # autograd form of the quirk agrees with the C oracle's hand-written one, so it can arbitrate full-size gradients.
+    # Tolerance: in this scene the quirk's term dL_dz * (s.x, s.y) IS the scale / rotation gradient (it changes them by
+    # 100 % of their maximum) and s -- the ray's intersection with a nearly edge-on surfel's plane, far outside the
+    # surfel -- is large and ill-conditioned in fp32: the fp32 oracle sits 1e-2 (scales) / 2e-3 (rotations) from fp64;
+    # without the quirk the same scene agrees to 2e-8 (test above)
+    act, cams = small_scene(grid=8, size=48, seed=2, scale_boost=0.2, opacity_boost=3.0)
+    _, errs = _compare(act, cams[0], (0.1, 0.2, 0.3), quirk_free=False, tol=3e-2)
+    assert errs["means3D"] < 2e-4 and errs["opacities"] < 2e-4 and errs["shs"] < 2e-4
+
+
+def test_rendering_a_subset_of_tiles_leaves_the_rest_zero_and_the_subset_unchanged():
+    act, cams = small_scene(grid=8, size=64, seed=1, scale_boost=3.0, opacity_boost=2.0)
+    v = oracle_view(cams[1], (1.0, 0.5, 0.2))
+    res = run_oracle(v, to_numpy(act))
+    inp = {k: torch.tensor(val.numpy(), dtype=torch.float64) for k, val in act.items()}
+    full = autograd_ref.render(v, inp["means3D"], inp["opacities"], inp["shs"], inp["scales"], inp["rotations"], res.ranges, res.point_list)
+    part = autograd_ref.render(v, inp["means3D"], inp["opacities"], inp["shs"], inp["scales"], inp["rotations"], res.ranges, res.point_list,
+                               tiles=[5, 10])
+    mask = torch.zeros(64, 64, dtype=torch.bool)
+    for t in (5, 10):
+        mask[(t // 4) * 16:(t // 4) * 16 + 16, (t % 4) * 16:(t % 4) * 16 + 16] = True
+    for f, p in zip(full, part):
+        assert torch.equal(p[:, mask], f[:, mask]) and not p[:, ~mask].any()
 
 
 def test_alpha_clamp_is_straight_through():
