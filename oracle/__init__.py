@@ -62,6 +62,8 @@ def _load():
         lib.oracle_free.argtypes = [ctypes.c_void_p]
         lib.oracle_num_rendered.restype = ctypes.c_int64
         lib.oracle_num_rendered.argtypes = [ctypes.c_void_p]
+        lib.oracle_blended_pairs.restype = ctypes.c_int64
+        lib.oracle_blended_pairs.argtypes = [ctypes.c_void_p]
         lib.oracle_state_ptr.restype = ctypes.c_void_p
         lib.oracle_state_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.oracle_mark_visible.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3
@@ -105,6 +107,7 @@ class Result:
     allmap: np.ndarray
     radii: np.ndarray
     num_rendered: int
+    blended_pairs: int      # (pixel, splat) pairs the composite blended (alpha >= 1/255, before the T < 1e-4 stop)
     # saved state, for bit-exact comparison of the integer stages and for backward
     transMats: np.ndarray
     normal_opacity: np.ndarray
@@ -184,7 +187,7 @@ def forward(view: View, means3D, opacities, shs=None, colors_precomp=None, scale
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     sp = lambda k: lib.oracle_state_ptr(h, k)
     return Result(
-        color=color, allmap=allmap, radii=radii, num_rendered=D,
+        color=color, allmap=allmap, radii=radii, num_rendered=D, blended_pairs=int(lib.oracle_blended_pairs(h)),
         transMats=_view_np(sp(0), np.float32, (P, 9)),
         normal_opacity=_view_np(sp(1), np.float32, (P, 4)),
         rgb=_view_np(sp(2), np.float32, (P, 3)),

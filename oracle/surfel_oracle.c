@@ -78,6 +78,7 @@ typedef struct {
 typedef struct {
     int32_t P, H, W, tiles_x, tiles_y;
     int64_t num_rendered;
+    int64_t blended_pairs; /* (pixel, splat) pairs the composite actually blended: the path's useful work */
     float *transMats;      /* [P,9]  Tu,Tv,Tw */
     float *normal_opacity; /* [P,4] */
     float *rgb;            /* [P,3] */
@@ -413,7 +414,8 @@ OracleState *oracle_forward(const OracleCfg *c, const float *means3D, const floa
 
     /* ---- per-pixel front-to-back composite ---- */
     const size_t HW = (size_t)H * W;
-#pragma omp parallel for schedule(dynamic, 1)
+    int64_t blended_total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : blended_total)
     for (int tile = 0; tile < gx * gy; tile++) {
         const int tx = tile % gx, ty = tile / gx;
         const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
@@ -447,6 +449,7 @@ OracleState *oracle_forward(const OracleCfg *c, const float *means3D, const floa
                     for (int ch = 0; ch < 3; ch++) C[ch] += s->rgb[3 * id + ch] * w;
                     T = test_T;
                     last_contributor = contributor;
+                    blended_total++;
                 }
                 s->final_T[pix] = T;
                 s->final_T[pix + HW] = M1;
@@ -461,6 +464,7 @@ OracleState *oracle_forward(const OracleCfg *c, const float *means3D, const floa
                 out_others[6 * HW + pix] = distortion;
             }
     }
+    s->blended_pairs = blended_total;
     return s;
 }
 
@@ -767,6 +771,7 @@ void oracle_mark_visible(int P, const float *means3D, const float *viewmatrix, u
 
 /* accessors for ctypes */
 int64_t oracle_num_rendered(const OracleState *s) { return s->num_rendered; }
+int64_t oracle_blended_pairs(const OracleState *s) { return s->blended_pairs; }
 const void *oracle_state_ptr(const OracleState *s, int which) {
     switch (which) {
     case 0: return s->transMats; case 1: return s->normal_opacity; case 2: return s->rgb;

@@ -58,6 +58,9 @@ def test_fronto_parallel_single_splat_matches_closed_form():
     np.testing.assert_allclose(res.allmap[2:5], alpha[None] * np.array([0, 0, -1.0])[:, None, None], atol=2e-6)
     np.testing.assert_allclose(res.allmap[5], np.where(alpha > 0, z0, 0), atol=1e-5)  # median depth
     np.testing.assert_allclose(res.allmap[6], 0, atol=1e-7)               # one splat: no distortion
+    # the count of blended (pixel, splat) pairs -- the path's useful work, bench.py's `valu_useful_frac` -- is here
+    # the number of pixels the one splat reaches
+    assert res.blended_pairs == int((alpha > 0).sum()) == int((res.n_contrib[0] > 0).sum())
     assert res.n_contrib[0].max() == 1
 
 

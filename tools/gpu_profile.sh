@@ -8,14 +8,17 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# (a) the headline command (the whole pipeline step, multi-view calls, 2 scene streams)
+# (a) the headline command (the whole pipeline step, multi-view calls, 2 scene streams); ONLY_RASTER=1 skips (a) and (a'):
+#     the pipeline step has no `--regime` (its Gaussians come out of the random-init network)
+if [ "${ONLY_RASTER:-0}" != "1" ]; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_train -o stats -- \
     python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats_train.log 2>&1
+# (a') the pipeline step on ONE stream and one view lane: every kernel of the step, torch's included, serialised
+LARA2DGS_VIEW_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_pipe1 -o stats -- \
+    python $REPO/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats_pipe1.log 2>&1
+fi
 # (b) the raster kernels one at a time (one call per view, one stream, ONLY the timed steps: --no-roofline keeps the
 #     bench's two-stream / two-lane side legs out of the averages): the durations the roofline object is built from
-# (a') the pipeline step on ONE stream: every kernel of the step, torch's included, serialised
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_pipe1 -o stats -- \
-    python $REPO/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats_pipe1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -o stats -- \
     python $REPO/bench.py --steps 2 --warmup 1 --step raster --raster-api loop --streams 1 --no-fine --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats.log 2>&1
 # counters in their own passes (no stats / other trace domains); the raster alone, one call per view, one scene
