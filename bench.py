@@ -317,11 +317,20 @@ def mesh_eval_leg(args, device):
     t_r, _ = timed(False)
     t_all, vol = timed(True)
     occupied = int((vol.weight > 0).sum())
+    vol.extract_triangle_mesh()                 # warm-up (loads the case tables)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    verts, tris, cols = vol.extract_triangle_mesh()
+    torch.cuda.synchronize()
+    t_mesh = time.perf_counter() - t0
     return {"workload": f"one object: {n_views} views @{res}x{res} forward (multi-view calls of {chunk}), each batch fused into a "
-                        f"{grid}^3 TSDF volume on the device (voxel 2/{grid}, trunc 0.08, alpha threshold 0.08)",
+                        f"{grid}^3 TSDF volume on the device (voxel 2/{grid}, trunc 0.08, alpha threshold 0.08; 16^3-voxel blocks touched "
+                        f"by a view's depth samples, as Open3D's ScalableTSDFVolume), then marching cubes on the device "
+                        f"(tools/meshExtractor.py:67-110)",
             "render_frames_per_s": round(n_views / t_r, 1), "ms_per_object_render": round(1e3 * t_r, 2),
             "ms_per_object_render_and_fuse": round(1e3 * t_all, 2), "tsdf_ms_per_object": round(1e3 * (t_all - t_r), 2),
-            "voxels_observed": occupied}
+            "mesh_extract_ms": round(1e3 * t_mesh, 2), "mesh_vertices": int(verts.shape[0]), "mesh_triangles": int(tris.shape[0]),
+            "voxels_observed": occupied, "blocks_allocated": int(vol.allocated.sum()), "blocks_total": int(vol.allocated.numel())}
 
 
 def measure_roofline(scenes, settings, gc, ga, args):

@@ -38,6 +38,37 @@ int lara_tsdf_integrate(int32_t res, const float *origin /* host, [3] */, float 
                         const float *intrinsics, const float *extrinsics, const float *depth_trunc, float *tsdf,
                         float *weight, float *rgb, void *stream);
 
+/* Block-sparse integration: the semantics of Open3D's `ScalableTSDFVolume` (the class tools/meshExtractor.py:67 instantiates;
+ * [RECALLED], Open3D absent).  The volume is cut into 16^3-voxel blocks (Open3D: volume units, volume_unit_resolution 16).  Per
+ * view, every `depth_sampling_stride`-th pixel (Open3D default 4) with a valid depth is back-projected through `cam_to_world`
+ * ([n_views][16], the inverse of `extrinsics`) and the blocks within +- sdf_trunc of the point (per axis) are TOUCHED; a view is
+ * integrated only into the blocks it touched -- free space in front of the surface is never allocated, unlike the dense
+ * `lara_tsdf_integrate`, which folds a view into every voxel whose projection has a depth.  The per-voxel update is the same code
+ * in both: where both integrate a view they produce the same bits.  res % 16 == 0; for Open3D's unit grid origin / (16 *
+ * voxel_length) must be integral.  Storage stays the dense [x][y][z] arrays (HBM is cheap here; the WORK is sparse: one workgroup
+ * per 256 voxels of a touched block); `touched` [n_views][(res/16)^3] bytes is scratch (overwritten), `allocated` [(res/16)^3]
+ * bytes accumulates the blocks ever touched (caller zero-fills once).  n_views <= 64 per call. */
+int lara_tsdf_integrate_blocks(int32_t res, const float *origin /* host, [3] */, float voxel_length, float sdf_trunc,
+                               int32_t n_views, int32_t H, int32_t W, int32_t depth_sampling_stride, const float *depth,
+                               const float *color, const float *intrinsics, const float *extrinsics, const float *cam_to_world,
+                               const float *depth_trunc, float *tsdf, float *weight, float *rgb, uint8_t *touched,
+                               uint8_t *allocated, void *stream);
+
+/* Mesh extraction (`volume.extract_triangle_mesh()`, meshExtractor.py:110): marching cubes over the cells whose 8 corner voxels
+ * were all observed (weight > 0), corners at the voxel centres, a vertex at the linear zero crossing of tsdf along a cell edge,
+ * vertex colour interpolated the same way (0..1).  The case table (csrc/mc_tables.h) is derived by tools/gen_mc_tables.py and is
+ * watertight in the ambiguous cases.  Two launches around a prefix sum the caller owns:
+ *   lara_tsdf_mesh_count -> counts [res^3] int32: triangles of cell (x,y,z) at index (x*res + y)*res + z (caller zero-fills:
+ *                           cells of blocks with allocated[block] == 0 are not visited; allocated may be NULL = visit all);
+ *   ends = inclusive prefix sum of counts (int64), T = ends[last];
+ *   lara_tsdf_mesh_emit  -> vertices [T][3][3], colors [T][3][3] fp32 and edge_keys [T][3] int64: the id of the grid edge a
+ *                           vertex lies on (equal keys = the same vertex: the caller welds with them). */
+int lara_tsdf_mesh_count(int32_t res, const float *origin, float voxel_length, const float *tsdf, const float *weight,
+                         const float *rgb, const uint8_t *allocated, int32_t *counts, void *stream);
+int lara_tsdf_mesh_emit(int32_t res, const float *origin, float voxel_length, const float *tsdf, const float *weight,
+                        const float *rgb, const uint8_t *allocated, const int32_t *counts, const int64_t *ends, float *vertices,
+                        float *colors, int64_t *edge_keys, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

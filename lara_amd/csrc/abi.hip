@@ -321,6 +321,20 @@ void grad_layout(int64_t P, int M, bool sh, bool col, bool sr, bool tm, lara2dgs
     L->total = o;
 }
 
+// zero `bytes` (a multiple of 16) at base + v * stride for v < gridDim.y: one launch for all views of a call.  (hipMemset2DAsync
+// over the scratch stride takes 70 us per call on this runtime; eight hipMemsetAsync calls 8 launches of 5 us.)
+__global__ void __launch_bounds__(256) zero_strided_kernel(char *__restrict__ base, const int64_t stride, const int64_t bytes) {
+    uint4 *p = (uint4 *)(base + (int64_t)blockIdx.y * stride);
+    const int64_t n = bytes / 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+inline void zero_strided(void *base, int64_t stride, int64_t bytes, int n_views, hipStream_t s) {
+    const int64_t n = (bytes + 15) / 16;
+    const unsigned gx = (unsigned)(n < 256 * 64 ? (n + 255) / 256 : 64);
+    hipLaunchKernelGGL(zero_strided_kernel, dim3(gx ? gx : 1, (unsigned)n_views), dim3(256), 0, s, (char *)base, stride, (bytes + 15) / 16 * 16);
+}
+
 // out[i] = sum over the n slices of tmp, slice order fixed (bit-reproducible); float4 lanes
 __global__ void __launch_bounds__(256) sum_slices_kernel(const float4 *__restrict__ tmp, float4 *__restrict__ out,
                                                          int64_t n4, int64_t stride4, int n) {
@@ -390,8 +404,7 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
             sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL);
             rad[i] = out_radii + (int64_t)i * v0.P;
             if (i == 0)   // the views agree in (P, H, W, capacity): one layout, one strided fill for all of them
-                HIP_TRY(hipMemset2DAsync(sc[0].tile_count, (size_t)scratch_stride, 0, (size_t)(SL.sub_start - SL.tile_count),
-                                         (size_t)n_views, caller));
+                zero_strided(sc[0].tile_count, scratch_stride, SL.sub_start - SL.tile_count, n_views, caller);
         }
         for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
             const int nb = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
@@ -473,8 +486,7 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
             rad[i] = radii + (int64_t)i * v0.P;
         }
         // validity bitmaps of all views: one strided fill on the caller's stream, in front of the fork
-        HIP_TRY(hipMemset2DAsync(sc[0].pair_valid, (size_t)scratch_stride, 0, (size_t)(SL[0].total - SL[0].pair_valid),
-                                 (size_t)n_views, caller));
+        zero_strided(sc[0].pair_valid, scratch_stride, SL[0].total - SL[0].pair_valid, n_views, caller);
         if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
         for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
         for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {

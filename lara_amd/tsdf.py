@@ -1,9 +1,12 @@
-"""TSDF fusion of rendered views on the GPU: the `volume.integrate(...)` loop of the
-reference's ``MeshExtractor.extract`` (tools/meshExtractor.py:67-110) without leaving the device -- the reference
-copies depth, alpha and colour of every one of its 48 views to the host and feeds Open3D's CPU
-``ScalableTSDFVolume``.  Dense grid, Open3D's voxel conventions and per-voxel update (include/lara_tsdf.h).
-Mesh extraction from the fused volume (marching cubes + the cluster filter, meshExtractor.py:112-135) is not part of
-the hot path and stays with the caller: ``volume()`` returns the grid as tensors.  No CPU path."""
+"""TSDF fusion of rendered views and mesh extraction on the GPU: the
+`volume.integrate(...)` loop and `volume.extract_triangle_mesh()` of the reference's ``MeshExtractor.extract``
+(tools/meshExtractor.py:67-110) without leaving the device -- the reference copies depth, alpha and colour of every one
+of its 48 views to the host and feeds Open3D's CPU ``ScalableTSDFVolume``.  Open3D's voxel conventions, per-voxel update
+and block semantics (include/lara_tsdf.h): by default a view is integrated only into the 16^3-voxel blocks within
+sdf_trunc of its back-projected depth samples, as ``ScalableTSDFVolume`` does (``block_sparse=False``: every voxel, as
+``UniformTSDFVolume``).  ``extract_triangle_mesh()`` runs marching cubes on the device and returns welded vertices,
+triangles and vertex colours; ``to_open3d_mesh()`` wraps them for the reference's Open3D post-processing (the cluster
+filter, meshExtractor.py:112-135, stays reference code).  No CPU path."""
 from __future__ import annotations
 
 import ctypes
@@ -23,6 +26,12 @@ def _lib():
         vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
         lib.lara_tsdf_integrate.restype = ctypes.c_int
         lib.lara_tsdf_integrate.argtypes = [i32, ctypes.POINTER(f32 * 3), f32, f32, i32, i32, i32] + [vp] * 9
+        lib.lara_tsdf_integrate_blocks.restype = ctypes.c_int
+        lib.lara_tsdf_integrate_blocks.argtypes = [i32, ctypes.POINTER(f32 * 3), f32, f32, i32, i32, i32, i32] + [vp] * 12
+        lib.lara_tsdf_mesh_count.restype = ctypes.c_int
+        lib.lara_tsdf_mesh_count.argtypes = [i32, ctypes.POINTER(f32 * 3), f32] + [vp] * 6
+        lib.lara_tsdf_mesh_emit.restype = ctypes.c_int
+        lib.lara_tsdf_mesh_emit.argtypes = [i32, ctypes.POINTER(f32 * 3), f32] + [vp] * 10
         _configured = True
     return lib
 
@@ -32,9 +41,15 @@ class TSDFVolume:
     origin + voxel_length * (i + 0.5, j + 0.5, k + 0.5); `MeshExtractor.extract` uses voxel_length = radius / 256 and
     sdf_trunc = 2 voxels around the object's bounding box (tools/meshExtractor.py:54-58)."""
 
-    def __init__(self, origin, voxel_length: float, sdf_trunc: float, resolution: int, device="cuda"):
+    BLOCK = 16      # voxels per block edge (ScalableTSDFVolume's volume_unit_resolution)
+
+    def __init__(self, origin, voxel_length: float, sdf_trunc: float, resolution: int, device="cuda", block_sparse=True,
+                 depth_sampling_stride=4):
         self.origin = tuple(float(o) for o in origin)
         self.voxel_length, self.sdf_trunc, self.res = float(voxel_length), float(sdf_trunc), int(resolution)
+        self.block_sparse, self.stride = bool(block_sparse), int(depth_sampling_stride)
+        if self.block_sparse and self.res % self.BLOCK:
+            raise RuntimeError("block-sparse volumes need a resolution that is a multiple of 16")
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
@@ -42,6 +57,8 @@ class TSDFVolume:
         self.tsdf = torch.zeros(n, dtype=torch.float32, device=dev)
         self.weight = torch.zeros(n, dtype=torch.float32, device=dev)
         self.rgb = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        nb = self.res // self.BLOCK
+        self.allocated = torch.zeros(nb ** 3 if self.block_sparse else 0, dtype=torch.uint8, device=dev)   # blocks ever touched
 
     @torch.no_grad()
     def integrate(self, depth, color, intrinsics, extrinsics, depth_trunc):
@@ -55,6 +72,21 @@ class TSDFVolume:
             raise RuntimeError("expected depth [V,H,W], color [V,H,W,3], intrinsics [V,4], extrinsics [V,4,4]")
         depth_trunc = f(depth_trunc).expand(V).contiguous() if torch.as_tensor(depth_trunc).dim() == 0 else f(depth_trunc)
         origin = (ctypes.c_float * 3)(*self.origin)
+        if V > 64:          # (the kernels keep a view mask in 64 bits)
+            for o in range(0, V, 64):
+                self.integrate(depth[o:o + 64], color[o:o + 64], intrinsics[o:o + 64], extrinsics[o:o + 64], depth_trunc[o:o + 64])
+            return
+        if self.block_sparse:
+            c2w = torch.linalg.inv_ex(extrinsics.double())[0].float().contiguous()
+            touched = torch.empty(V * self.allocated.numel(), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _check(_lib().lara_tsdf_integrate_blocks(self.res, ctypes.byref(origin), self.voxel_length, self.sdf_trunc, V, H, W, self.stride,
+                                                         depth.data_ptr(), color.data_ptr(), intrinsics.data_ptr(), extrinsics.data_ptr(),
+                                                         c2w.data_ptr(), depth_trunc.data_ptr(), self.tsdf.data_ptr(), self.weight.data_ptr(),
+                                                         self.rgb.data_ptr(), touched.data_ptr(), self.allocated.data_ptr(),
+                                                         torch.cuda.current_stream(dev).cuda_stream), "lara_tsdf_integrate_blocks")
+            self.last_touched = touched.view(V, -1)
+            return
         with torch.cuda.device(dev):
             _check(_lib().lara_tsdf_integrate(self.res, ctypes.byref(origin), self.voxel_length, self.sdf_trunc, V, H, W,
                                               depth.data_ptr(), color.data_ptr(), intrinsics.data_ptr(), extrinsics.data_ptr(),
@@ -76,3 +108,45 @@ class TSDFVolume:
         """(tsdf [R,R,R], weight [R,R,R], rgb [R,R,R,3]) indexed [x][y][z]."""
         r = self.res
         return self.tsdf.view(r, r, r), self.weight.view(r, r, r), self.rgb.view(r, r, r, 3)
+
+    @torch.no_grad()
+    def extract_triangle_mesh(self, weld=True):
+        """`volume.extract_triangle_mesh()` (meshExtractor.py:110) on the device: (vertices [Nv,3], triangles [T,3] int64,
+        vertex_colors [Nv,3] in 0..1).  ``weld=False``: three private vertices per triangle."""
+        dev, r = self.tsdf.device, self.res
+        if r % self.BLOCK:
+            raise RuntimeError("mesh extraction needs a resolution that is a multiple of 16")
+        origin = (ctypes.c_float * 3)(*self.origin)
+        alloc = self.allocated.data_ptr() if self.block_sparse else None
+        counts = torch.zeros(r ** 3, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _check(_lib().lara_tsdf_mesh_count(r, ctypes.byref(origin), self.voxel_length, self.tsdf.data_ptr(), self.weight.data_ptr(),
+                                               self.rgb.data_ptr(), alloc, counts.data_ptr(), stream), "lara_tsdf_mesh_count")
+            ends = torch.cumsum(counts, 0, dtype=torch.int64)
+            T = int(ends[-1])                    # the one host read: the output's size
+            verts = torch.empty(T, 3, 3, dtype=torch.float32, device=dev)
+            cols = torch.empty(T, 3, 3, dtype=torch.float32, device=dev)
+            keys = torch.empty(T, 3, dtype=torch.int64, device=dev)
+            if T:
+                _check(_lib().lara_tsdf_mesh_emit(r, ctypes.byref(origin), self.voxel_length, self.tsdf.data_ptr(), self.weight.data_ptr(),
+                                                  self.rgb.data_ptr(), alloc, counts.data_ptr(), ends.data_ptr(), verts.data_ptr(),
+                                                  cols.data_ptr(), keys.data_ptr(), stream), "lara_tsdf_mesh_emit")
+        if not weld:
+            return verts.view(-1, 3), torch.arange(3 * T, device=dev).view(T, 3), cols.view(-1, 3)
+        uniq, inverse = torch.unique(keys.view(-1), return_inverse=True)
+        first = torch.full((uniq.numel(),), 3 * T, dtype=torch.int64, device=dev).scatter_reduce_(
+            0, inverse, torch.arange(3 * T, device=dev), reduce="amin", include_self=True)
+        return verts.view(-1, 3)[first], inverse.view(T, 3), cols.view(-1, 3)[first]
+
+    def to_open3d_mesh(self):
+        """The extracted mesh as an `open3d.geometry.TriangleMesh`, for the reference's own post-processing and writer
+        (meshExtractor.py:112-135).  Needs Open3D (absent from this image; the reference needs it too)."""
+        try:
+            import open3d as o3d
+        except ImportError as e:   # pragma: no cover
+            raise RuntimeError("lara_amd.tsdf.TSDFVolume.to_open3d_mesh needs open3d") from e
+        v, t, c = (x.cpu().numpy() for x in self.extract_triangle_mesh())
+        mesh = o3d.geometry.TriangleMesh(o3d.utility.Vector3dVector(v.astype("float64")), o3d.utility.Vector3iVector(t.astype("int32")))
+        mesh.vertex_colors = o3d.utility.Vector3dVector(c.astype("float64"))
+        return mesh
