@@ -1,254 +1,331 @@
 // finedec.hip -- Decoder.forward_fine (lightning/network.py:280-284) as one kernel per direction.  See
-// include/lara_finedec.h for the algebra.  thread = point; the folded weights (40 KB) live in LDS and are read by
-// broadcast (every lane the same address); workgroups are persistent and walk tiles of 256 points.
+// include/lara_finedec.h for the algebra.  One wave = 32 points; the three folded products run on the matrix cores in fp32
+// with the folded weights (45 KB forward, 83 KB backward) in LDS; workgroups are persistent and walk tiles of 128 points.
 #include "common.h"
 #include "../../include/lara_finedec.h"
 
 namespace {
 
 constexpr int FD = 80, NH = 8, CD = 8, NV = 4, HID = 64, SH = 12, TQ = NH * CD;  // TQ = 64 folded query rows
-constexpr int W_QK = 0, W_1 = W_QK + TQ * FD, W_B1 = W_1 + HID * TQ, W_2 = W_B1 + HID, W_B2 = W_2 + SH * HID,
-              W_END = W_B2 + 16;  // floats of LDS
 
-__device__ __forceinline__ void load_weights(float *sw, const float *Wqk, const float *W1ov, const float *b1,
-                                             const float *W2, const float *b2) {
-    for (int i = threadIdx.x; i < TQ * FD; i += blockDim.x) sw[W_QK + i] = Wqk[i];
-    for (int i = threadIdx.x; i < HID * TQ; i += blockDim.x) sw[W_1 + i] = W1ov[i];
-    for (int i = threadIdx.x; i < HID; i += blockDim.x) sw[W_B1 + i] = b1[i];
-    for (int i = threadIdx.x; i < SH * HID; i += blockDim.x) sw[W_2 + (i % HID) * SH + i / HID] = W2[i];   // transposed: [HID][12]
-    for (int i = threadIdx.x; i < 16; i += blockDim.x) sw[W_B2 + i] = i < SH ? b2[i] : 0.f;
+// The three folded products run on the matrix cores in FP32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+// accumulation -- the fixture parity of the VALU version carries over unchanged; the part's fp32 matrix rate is ~5x what
+// the 10.6 kFMA-per-point VALU kernel reached).  One wave = 32 points = the 32 columns of every product:
+//     t^T   [64 x 32] = Wqk  [64 x 80] . xn^T [80 x 32]
+//     hid^T [64 x 32] = W1ov [64 x 64] . u^T  [64 x 32]
+//     sh^T  [12 x 32] = W2   [12 x 64] . h^T  [64 x 32]          (and their transposes in the backward)
+// A 32x32x2 MFMA takes A[i = lane % 32][k = lane / 32], B[k = lane / 32][j = lane % 32] and leaves
+// D[i = 8 (r / 4) + 4 (lane / 32) + r % 4][j = lane % 32] in register r of 16.  Two consequences shape the kernel:
+//  * a lane owns ONE point (column j) and, of every 8 consecutive rows, 4: of head h's 8 channels lanes 0-31 hold c = 0..3
+//    and lanes 32-63 c = 4..7.  The attention (4-way softmax per head) runs on the lane's own 4 channels plus one
+//    exchange with lane ^ 32 per (head, view) dot product;
+//  * an accumulator tile IS a B operand: step (tile, r) of the next product takes k = row(tile, r, 0) from the lower
+//    half-wave and k = row(tile, r, 1) from the upper one -- register r of every lane, as it stands.  The reduction
+//    index is just walked in that order, and the A operand (the weights, staged in LDS with k as the slow index) is
+//    read at the matching rows.  Nothing is transposed, nothing leaves the registers between the products.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int crow(const int tile, const int r, const int hf) { return tile * 32 + (r >> 2) * 8 + hf * 4 + (r & 3); }
+__device__ __forceinline__ f32x16 mfma2(const float a, const float b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// The product loops are fully unrolled (accumulator registers are addressed statically); left alone, the scheduler hoists ALL
+// of a loop's LDS weight reads in front of it (350-480 VGPRs, one wave per SIMD).  A compiler-level memory fence every few
+// steps bounds how far the reads run ahead, which keeps the kernels at 256 registers = two waves per SIMD.
+#define FD_FENCE(i, every) do { if (((i) % (every)) == (every) - 1) asm volatile("" ::: "memory"); } while (0)
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.f;
+    return z;
+}
+
+// LDS images of the folded weights (floats).  "T" = reduction index slow, output index fast (conflict-free A reads).
+constexpr int L_WQKT = 0;                     // [80][64]   WqkT[f][q]  = Wqk[q][f]
+constexpr int L_W1T = L_WQKT + FD * TQ;       // [64][64]   W1T[k][m]   = W1ov[m][k]
+constexpr int L_W2T = L_W1T + TQ * HID;       // [64][32]   W2T[m][o]   = W2[o][m], o < 12, else 0
+constexpr int L_B1 = L_W2T + HID * 32;        // [64]
+constexpr int L_B2 = L_B1 + HID;              // [32]  (12 used)
+constexpr int L_FWD_END = L_B2 + 32;
+// backward only
+constexpr int L_W2P = L_FWD_END;              // [16][64]   W2P[o][m]   = W2[o][m], o < 12, else 0
+constexpr int L_W1 = L_W2P + 16 * HID;        // [64][64]   W1[m][k]    = W1ov[m][k]
+constexpr int L_WQK = L_W1 + HID * TQ;        // [64][96]   WqkP[q][f]  = Wqk[q][f], f < 80, else 0
+constexpr int L_BWD_END = L_WQK + TQ * 96;
+
+__device__ __forceinline__ void stage_weights(float *sw, const float *Wqk, const float *W1ov, const float *b1, const float *W2,
+                                              const float *b2, const bool bwd) {
+    for (int i = threadIdx.x; i < TQ * FD; i += blockDim.x) sw[L_WQKT + (i % FD) * TQ + i / FD] = Wqk[i];
+    for (int i = threadIdx.x; i < HID * TQ; i += blockDim.x) sw[L_W1T + (i % TQ) * HID + i / TQ] = W1ov[i];
+    for (int i = threadIdx.x; i < HID * 32; i += blockDim.x) sw[L_W2T + i] = (i % 32) < SH ? W2[(i % 32) * HID + i / 32] : 0.f;
+    for (int i = threadIdx.x; i < HID; i += blockDim.x) sw[L_B1 + i] = b1[i];
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) sw[L_B2 + i] = i < SH ? b2[i] : 0.f;
+    if (bwd) {
+        for (int i = threadIdx.x; i < 16 * HID; i += blockDim.x) sw[L_W2P + i] = i < SH * HID ? W2[i] : 0.f;
+        for (int i = threadIdx.x; i < HID * TQ; i += blockDim.x) sw[L_W1 + i] = W1ov[i];
+        for (int i = threadIdx.x; i < TQ * 96; i += blockDim.x) sw[L_WQK + i] = (i % 96) < FD ? Wqk[(i / 96) * FD + i % 96] : 0.f;
+    }
     __syncthreads();
 }
 
-// phase 1: t = Wqk xn, four input features at a time (only 4 of the point's 80 features are live at once)
-__device__ __forceinline__ void folded_queries(const float *sw, const float *xn_g, const int64_t i, float t[TQ]) {
+// the lane's half of its point's normalised features: xh[s] = xn[pt][40 hf + s]  (K order of the first product: step s
+// takes feature s from the lower half-wave and feature 40 + s from the upper one)
+__device__ __forceinline__ void load_xn_half(const float *xn_g, const int64_t pt, const int hf, float xh[40]) {
+    const float4 *x4 = (const float4 *)(xn_g + pt * FD + hf * 40);
 #pragma unroll
-    for (int r = 0; r < TQ; r++) t[r] = 0.f;
-    const float4 *x4 = (const float4 *)(xn_g + i * FD);
-#pragma unroll 2
-    for (int k = 0; k < FD / 4; k++) {
-        const float4 x = x4[k];
-        const float4 *w = (const float4 *)(sw + W_QK) + k;
+    for (int k = 0; k < 10; k++) { const float4 v = x4[k]; xh[4 * k] = v.x; xh[4 * k + 1] = v.y; xh[4 * k + 2] = v.z; xh[4 * k + 3] = v.w; }
+}
+
+// t = Wqk xn: two 32-row tiles
+__device__ __forceinline__ void folded_queries(const float *sw, const float xh[40], const int col, const int hf, f32x16 t[2]) {
+    t[0] = zero16(); t[1] = zero16();
 #pragma unroll
-        for (int r = 0; r < TQ; r++) {
-            const float4 q = w[r * (FD / 4)];
-            t[r] += (q.x * x.x + q.y * x.y) + (q.z * x.z + q.w * x.w);
-        }
+    for (int s = 0; s < 40; s++) {
+        const float *w = sw + L_WQKT + (hf * 40 + s) * TQ + col;
+        t[0] = mfma2(w[0], xh[s], t[0]);
+        t[1] = mfma2(w[32], xh[s], t[1]);
+        FD_FENCE(s, 4);
     }
 }
 
-__device__ __forceinline__ void load_pf(const float *pf_g, const int64_t n, const int64_t i, float pf[NV][CD]) {
+// the lane's 4 channels of the 4 views' sampled features: pf[j][cl] = point_feats[j][4 hf + cl][pt]
+__device__ __forceinline__ void load_pf_half(const float *pf_g, const int64_t n, const int64_t pt, const int hf, float pf[NV][4]) {
 #pragma unroll
     for (int j = 0; j < NV; j++)
 #pragma unroll
-        for (int c = 0; c < CD; c++) pf[j][c] = pf_g[(int64_t)(j * CD + c) * n + i];
+        for (int c = 0; c < 4; c++) pf[j][c] = pf_g[(int64_t)(j * CD + hf * 4 + c) * n + pt];
 }
 
-// one head's 4-way softmax from its folded query t (8 values)
-__device__ __forceinline__ void head_softmax(const float *t, const float pf[NV][CD], float p[NV]) {
-    float s[NV], m = -1e30f;
+__device__ __forceinline__ float other_half(const float x) { return __shfl_xor(x, 32, 64); }
+
+// softmax weights of all 8 heads from the folded queries (register r of tile mt: head 4 mt + r / 4, channel 4 hf + r % 4)
+__device__ __forceinline__ void attention_weights(const f32x16 t[2], const float pf[NV][4], float p[NH][NV]) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-        float a = 0.f;
+    for (int h = 0; h < NH; h++) {
+        float sc[NV], m = -1e30f;
 #pragma unroll
-        for (int c = 0; c < CD; c++) a += t[c] * pf[j][c];
-        s[j] = a;
-        m = fmaxf(m, a);
+        for (int j = 0; j < NV; j++) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) a += t[h >> 2][(h & 3) * 4 + c] * pf[j][c];
+            a += other_half(a);
+            sc[j] = a;
+            m = fmaxf(m, a);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; j++) { p[h][j] = __expf(sc[j] - m); z += p[h][j]; }
+        const float rz = 1.0f / z;
+#pragma unroll
+        for (int j = 0; j < NV; j++) p[h][j] *= rz;
     }
-    float z = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; j++) { p[j] = __expf(s[j] - m); z += p[j]; }
-    const float rz = 1.0f / z;
-#pragma unroll
-    for (int j = 0; j < NV; j++) p[j] *= rz;
 }
 
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ void attend(const float p[NH][NV], const float pf[NV][4], f32x16 u[2]) {
+#pragma unroll
+    for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            u[h >> 2][(h & 3) * 4 + c] = p[h][0] * pf[0][c] + p[h][1] * pf[1][c] + p[h][2] * pf[2][c] + p[h][3] * pf[3][c];
+}
+
+// pre-activation hidden units: W1ov u + b1 (two tiles)
+__device__ __forceinline__ void hidden_pre(const float *sw, const f32x16 u[2], const int col, const int hf, f32x16 hid[2]) {
+    hid[0] = zero16(); hid[1] = zero16();
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float *w = sw + L_W1T + crow(mt, r, hf) * HID + col;
+            hid[0] = mfma2(w[0], u[mt][r], hid[0]);
+            hid[1] = mfma2(w[32], u[mt][r], hid[1]);
+            FD_FENCE(r, 4);
+        }
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) hid[mt][r] += sw[L_B1 + crow(mt, r, hf)];
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fine_decoder_fwd_kernel(const int n, const float *__restrict__ xn_g, const float *__restrict__ pf_g,
                         const float *__restrict__ Wqk, const float *__restrict__ W1ov, const float *__restrict__ b1,
                         const float *__restrict__ W2, const float *__restrict__ b2, float *__restrict__ sh_g) {
-    __shared__ __attribute__((aligned(16))) float sw[W_END];
-    load_weights(sw, Wqk, W1ov, b1, W2, b2);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float tu[TQ];   // the folded queries t, then (head by head, in place) the attended features u
-        folded_queries(sw, xn_g, i, tu);
+    __shared__ __attribute__((aligned(16))) float sw[L_FWD_END];
+    stage_weights(sw, Wqk, W1ov, b1, W2, b2, false);
+    const int lane = threadIdx.x & 63, col = lane & 31, hf = lane >> 5, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 128; base < n; base += (int64_t)gridDim.x * 128) {
+        const int64_t pt = base + wave * 32 + col;
+        const bool live = pt < n;
+        const int64_t ptc = live ? pt : (int64_t)n - 1;        // (rows beyond n recompute the last point; nothing is stored)
+        float xh[40];
+        load_xn_half(xn_g, ptc, hf, xh);
+        f32x16 tu[2];
+        folded_queries(sw, xh, col, hf, tu);
         {
-            float pf[NV][CD];
-            load_pf(pf_g, n, i, pf);
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-                float p[NV];
-                head_softmax(tu + h * CD, pf, p);
-#pragma unroll
-                for (int c = 0; c < CD; c++) tu[h * CD + c] = p[0] * pf[0][c] + p[1] * pf[1][c] + p[2] * pf[2][c] + p[3] * pf[3][c];
-            }
+            float pf[NV][4], p[NH][NV];
+            load_pf_half(pf_g, n, ptc, hf, pf);
+            attention_weights(tu, pf, p);
+            attend(p, pf, tu);
         }
-        // phase 2: one hidden unit at a time, consumed at once by the output layer (hid is never an array)
-        float out[SH];
+        f32x16 hid[2];
+        hidden_pre(sw, tu, col, hf, hid);
+        f32x16 out = zero16();
 #pragma unroll
-        for (int m = 0; m < SH; m++) out[m] = sw[W_B2 + m];
-#pragma unroll 2
-        for (int o = 0; o < HID; o++) {
-            const float4 *w1 = (const float4 *)(sw + W_1 + o * TQ);
-            float a0 = sw[W_B1 + o], a1 = 0.f;
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int k = 0; k < TQ / 4; k++) {
-                const float4 w = w1[k];
-                a0 += w.x * tu[4 * k] + w.z * tu[4 * k + 2];
-                a1 += w.y * tu[4 * k + 1] + w.w * tu[4 * k + 3];
+            for (int r = 0; r < 16; r++) {
+                out = mfma2(sw[L_W2T + crow(mt, r, hf) * 32 + col], fmaxf(hid[mt][r], 0.f), out);
+                FD_FENCE(r, 8);
             }
-            const float hv = fmaxf(a0 + a1, 0.f);
-            const float4 *w2 = (const float4 *)(sw + W_2 + o * 12);   // W2 is staged transposed: [HID][12]
-            const float4 wa = w2[0], wb = w2[1], wc = w2[2];
-            out[0] += wa.x * hv; out[1] += wa.y * hv; out[2] += wa.z * hv; out[3] += wa.w * hv;
-            out[4] += wb.x * hv; out[5] += wb.y * hv; out[6] += wb.z * hv; out[7] += wb.w * hv;
-            out[8] += wc.x * hv; out[9] += wc.y * hv; out[10] += wc.z * hv; out[11] += wc.w * hv;
+        if (live) {     // rows 4 hf + (0..3) in registers 0..3, rows 8 + 4 hf + (0..3) in registers 4..7 (hf 0: 8..11)
+            float4 *o4 = (float4 *)(sh_g + pt * SH);
+            const float *bb = sw + L_B2;
+            o4[hf] = make_float4(out[0] + bb[4 * hf], out[1] + bb[4 * hf + 1], out[2] + bb[4 * hf + 2], out[3] + bb[4 * hf + 3]);
+            if (hf == 0) o4[2] = make_float4(out[4] + bb[8], out[5] + bb[9], out[6] + bb[10], out[7] + bb[11]);
         }
-        float4 *o4 = (float4 *)(sh_g + i * SH);
-        o4[0] = make_float4(out[0], out[1], out[2], out[3]);
-        o4[1] = make_float4(out[4], out[5], out[6], out[7]);
-        o4[2] = make_float4(out[8], out[9], out[10], out[11]);
     }
 }
 
-// Backward.  Pass A recomputes the forward (t parked in the DT array, u and relu(hid) written out: the weight
-// gradients are GEMMs of them) and, hidden unit by hidden unit, forms dL/du; pass B is the attention's backward
-// head by head (dL/dt replaces t in DT); pass C maps dL/dt back through Wqk, four features at a time.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// Backward: the forward recomputed up to the hidden units, then the chain backwards through the same register layouts.
+// U, H, DH, DT ([n, 64] each) are written for the weight gradients, which are GEMMs over the point axis (the caller's).
+__global__ void __launch_bounds__(256)
 fine_decoder_bwd_kernel(const int n, const float *__restrict__ xn_g, const float *__restrict__ pf_g,
                         const float *__restrict__ Wqk, const float *__restrict__ W1ov, const float *__restrict__ b1,
                         const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ dsh_g,
                         float *__restrict__ dxn_g, float *__restrict__ dpf_g, float *__restrict__ U_g,
                         float *__restrict__ H_g, float *__restrict__ DH_g, float *__restrict__ DT_g) {
-    __shared__ __attribute__((aligned(16))) float sw[W_END];
-    load_weights(sw, Wqk, W1ov, b1, W2, b2);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float u[TQ];
-        folded_queries(sw, xn_g, i, u);
-        {
-            float4 *tq = (float4 *)(DT_g + i * TQ);
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    stage_weights(sw, Wqk, W1ov, b1, W2, b2, true);
+    const int lane = threadIdx.x & 63, col = lane & 31, hf = lane >> 5, wave = threadIdx.x >> 6;
+    // a [n, 64] row as the accumulator layout holds it: registers 4 q .. 4 q + 3 of tile mt = columns 32 mt + 8 q + 4 hf + (0..3)
+    auto store64 = [&](float *g, const int64_t pt, const f32x16 v[2]) {
 #pragma unroll
-            for (int k = 0; k < TQ / 4; k++) tq[k] = make_float4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]);
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *(float4 *)(g + pt * 64 + mt * 32 + q * 8 + hf * 4) = make_float4(v[mt][4 * q], v[mt][4 * q + 1], v[mt][4 * q + 2], v[mt][4 * q + 3]);
+    };
+    for (int64_t base = (int64_t)blockIdx.x * 128; base < n; base += (int64_t)gridDim.x * 128) {
+        const int64_t pt = base + wave * 32 + col;
+        const bool live = pt < n;
+        const int64_t ptc = live ? pt : (int64_t)n - 1;
+        f32x16 t[2], u[2];
+        {
+            float xh[40];
+            load_xn_half(xn_g, ptc, hf, xh);
+            folded_queries(sw, xh, col, hf, t);
         }
+        float pf[NV][4], p[NH][NV];
+        load_pf_half(pf_g, n, ptc, hf, pf);
+        attention_weights(t, pf, p);
+        attend(p, pf, u);
+        if (live) store64(U_g, pt, u);
+        asm volatile("" ::: "memory");
+        f32x16 hid[2], dh[2];
+        hidden_pre(sw, u, col, hf, hid);
+        // dL/dhid = W2^T dL/dsh: K = the 12 outputs (padded to 16): step s takes output s from the lower half-wave, 8 + s from the upper
         {
-            float pf[NV][CD];   // (loaded again for pass B: 32 registers less across the hidden-unit loop)
-            load_pf(pf_g, n, i, pf);
+            float ds[8];
+            const float4 *d4 = (const float4 *)(dsh_g + ptc * SH);
+            if (hf == 0) {
+                const float4 a = d4[0], b = d4[1];
+                ds[0] = a.x; ds[1] = a.y; ds[2] = a.z; ds[3] = a.w; ds[4] = b.x; ds[5] = b.y; ds[6] = b.z; ds[7] = b.w;
+            } else {
+                const float4 c = d4[2];
+                ds[0] = c.x; ds[1] = c.y; ds[2] = c.z; ds[3] = c.w; ds[4] = ds[5] = ds[6] = ds[7] = 0.f;
+            }
+            dh[0] = zero16(); dh[1] = zero16();
 #pragma unroll
-            for (int h = 0; h < NH; h++) {
-                float p[NV];
-                head_softmax(u + h * CD, pf, p);
-#pragma unroll
-                for (int c = 0; c < CD; c++) u[h * CD + c] = p[0] * pf[0][c] + p[1] * pf[1][c] + p[2] * pf[2][c] + p[3] * pf[3][c];
+            for (int s_ = 0; s_ < 8; s_++) {
+                const float *w = sw + L_W2P + (hf * 8 + s_) * HID + col;
+                dh[0] = mfma2(w[0], ds[s_], dh[0]);
+                dh[1] = mfma2(w[32], ds[s_], dh[1]);
+                FD_FENCE(s_, 4);
             }
         }
-        {
-            float4 *uq = (float4 *)(U_g + i * TQ);
 #pragma unroll
-            for (int k = 0; k < TQ / 4; k++) uq[k] = make_float4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]);
-        }
-        float dsh[SH];
-        {
-            const float4 *d4 = (const float4 *)(dsh_g + i * SH);
-            const float4 a = d4[0], b = d4[1], c = d4[2];
-            dsh[0] = a.x; dsh[1] = a.y; dsh[2] = a.z; dsh[3] = a.w; dsh[4] = b.x; dsh[5] = b.y; dsh[6] = b.z; dsh[7] = b.w;
-            dsh[8] = c.x; dsh[9] = c.y; dsh[10] = c.z; dsh[11] = c.w;
-        }
-#pragma unroll 2
-        for (int o = 0; o < HID; o++) {
-            const float4 *w1 = (const float4 *)(sw + W_1 + o * TQ);
-            float a0 = sw[W_B1 + o], a1 = 0.f;
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int k = 0; k < TQ / 4; k++) {
-                const float4 w = w1[k];
-                a0 += w.x * u[4 * k] + w.z * u[4 * k + 2];
-                a1 += w.y * u[4 * k + 1] + w.w * u[4 * k + 3];
+            for (int r = 0; r < 16; r++) {
+                const bool on = hid[mt][r] > 0.f;
+                hid[mt][r] = on ? hid[mt][r] : 0.f;
+                dh[mt][r] = on ? dh[mt][r] : 0.f;
             }
-            const float pre = a0 + a1;
-            const float4 *w2 = (const float4 *)(sw + W_2 + o * 12);
-            const float4 wa = w2[0], wb = w2[1], wc = w2[2];
-            const float g = (wa.x * dsh[0] + wa.y * dsh[1] + wa.z * dsh[2] + wa.w * dsh[3]) +
-                            (wb.x * dsh[4] + wb.y * dsh[5] + wb.z * dsh[6] + wb.w * dsh[7]) +
-                            (wc.x * dsh[8] + wc.y * dsh[9] + wc.z * dsh[10] + wc.w * dsh[11]);
-            const bool on = pre > 0.f;
-            const float hv = on ? pre : 0.f, dv = on ? g : 0.f;
-            H_g[i * HID + o] = hv;
-            DH_g[i * HID + o] = dv;
-        }
-        // dL/du = W1ov^T dL/dhid, in a loop of its own (u is dead by now: 64 registers less than doing it above)
-        float du[TQ];
+        if (live) { store64(H_g, pt, hid); store64(DH_g, pt, dh); }
+        asm volatile("" ::: "memory");
+        // dL/du = W1ov^T dL/dhid  (A = W1ov[m][k] with m walked in accumulator order)
+        f32x16 du[2];
+        du[0] = zero16(); du[1] = zero16();
 #pragma unroll
-        for (int k = 0; k < TQ; k++) du[k] = 0.f;
-#pragma unroll 2
-        for (int o = 0; o < HID; o++) {
-            const float dv = DH_g[i * HID + o];
-            const float4 *w1 = (const float4 *)(sw + W_1 + o * TQ);
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int k = 0; k < TQ / 4; k++) {
-                const float4 w = w1[k];
-                du[4 * k] += w.x * dv; du[4 * k + 1] += w.y * dv; du[4 * k + 2] += w.z * dv; du[4 * k + 3] += w.w * dv;
+            for (int r = 0; r < 16; r++) {
+                const float *w = sw + L_W1 + crow(mt, r, hf) * TQ + col;
+                du[0] = mfma2(w[0], dh[mt][r], du[0]);
+                du[1] = mfma2(w[32], dh[mt][r], du[1]);
+                FD_FENCE(r, 4);
             }
-        }
-        // pass B: du -> dt in place, dpf accumulated over the heads
-        float pf[NV][CD], dpf[NV][CD];
-        load_pf(pf_g, n, i, pf);
+        asm volatile("" ::: "memory");
+        // the attention's backward on the lane's own 4 channels: du -> dt in place, dpf accumulated over the heads
+        float dpf[NV][4];
 #pragma unroll
         for (int j = 0; j < NV; j++)
 #pragma unroll
-            for (int c = 0; c < CD; c++) dpf[j][c] = 0.f;
+            for (int c = 0; c < 4; c++) dpf[j][c] = 0.f;
 #pragma unroll
         for (int h = 0; h < NH; h++) {
-            float t[CD], p[NV];
-            {
-                const float4 *tq = (const float4 *)(DT_g + i * TQ + h * CD);
-                const float4 a = tq[0], b = tq[1];
-                t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y; t[6] = b.z; t[7] = b.w;
-            }
-            head_softmax(t, pf, p);
+            const int mt = h >> 2, r0 = (h & 3) * 4;
             float dp[NV], dot = 0.f;
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 float a = 0.f;
 #pragma unroll
-                for (int c = 0; c < CD; c++) a += du[h * CD + c] * pf[j][c];
+                for (int c = 0; c < 4; c++) a += du[mt][r0 + c] * pf[j][c];
+                a += other_half(a);
                 dp[j] = a;
-                dot += p[j] * a;
+                dot += p[h][j] * a;
             }
-            float dt[CD];
-#pragma unroll
-            for (int c = 0; c < CD; c++) dt[c] = 0.f;
+            float dt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NV; j++) {
-                const float ds = p[j] * (dp[j] - dot);
+                const float dsc = p[h][j] * (dp[j] - dot);
 #pragma unroll
-                for (int c = 0; c < CD; c++) {
-                    dt[c] += ds * pf[j][c];
-                    dpf[j][c] += p[j] * du[h * CD + c] + ds * t[c];
+                for (int c = 0; c < 4; c++) {
+                    dt[c] += dsc * pf[j][c];
+                    dpf[j][c] += p[h][j] * du[mt][r0 + c] + dsc * t[mt][r0 + c];
                 }
             }
 #pragma unroll
-            for (int c = 0; c < CD; c++) du[h * CD + c] = dt[c];
+            for (int c = 0; c < 4; c++) du[mt][r0 + c] = dt[c];
+            asm volatile("" ::: "memory");
         }
-        {
-            float4 *tq = (float4 *)(DT_g + i * TQ);
+        if (live) {
+            store64(DT_g, pt, du);
 #pragma unroll
-            for (int k = 0; k < TQ / 4; k++) tq[k] = make_float4(du[4 * k], du[4 * k + 1], du[4 * k + 2], du[4 * k + 3]);
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) dpf_g[(int64_t)(j * CD + hf * 4 + c) * n + pt] = dpf[j][c];
         }
+        // dL/dxn = Wqk^T dL/dt: 80 rows = three tiles (the last one half empty)
 #pragma unroll
-        for (int j = 0; j < NV; j++)
+        for (int ft = 0; ft < 3; ft++) {
+            f32x16 dx = zero16();
 #pragma unroll
-            for (int c = 0; c < CD; c++) dpf_g[(int64_t)(j * CD + c) * n + i] = dpf[j][c];
-        // pass C: dxn = Wqk^T dt
-        float4 *x4 = (float4 *)(dxn_g + i * FD);
-#pragma unroll 2
-        for (int k = 0; k < FD / 4; k++) {
-            const float4 *w = (const float4 *)(sw + W_QK) + k;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int r = 0; r < TQ; r++) {
-                const float4 q = w[r * (FD / 4)];
-                a.x += q.x * du[r]; a.y += q.y * du[r]; a.z += q.z * du[r]; a.w += q.w * du[r];
+                for (int r = 0; r < 16; r++) {
+                    dx = mfma2(sw[L_WQK + crow(mt, r, hf) * 96 + ft * 32 + col], du[mt][r], dx);
+                    FD_FENCE(r, 8);
+                }
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int f0 = ft * 32 + q * 8 + hf * 4;
+                    if (f0 < FD) *(float4 *)(dxn_g + pt * FD + f0) = make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
+                }
             }
-            x4[k] = a;
         }
     }
 }
@@ -351,7 +428,7 @@ fine_ln_bwd_kernel(const int n, const float *__restrict__ x_g, const float *__re
 }
 
 unsigned fd_grid(int n) {
-    const unsigned tiles = (unsigned)((n + 255) / 256);
+    const unsigned tiles = (unsigned)((n + 127) / 128);
     return tiles < 1024u ? tiles : 1024u;
 }
 
@@ -383,8 +460,14 @@ int lara_fine_decoder_backward(int32_t n, const float *xn, const float *pf, cons
     hipStream_t s = (hipStream_t)stream;
     {
         L2D_PROF("fine_decoder_bwd", s);
-        hipLaunchKernelGGL(fine_decoder_bwd_kernel, dim3(fd_grid(n)), dim3(256), 0, s, n, xn, pf, Wqk, W1ov, b1, W2, b2,
-                           d_sh, d_xn, d_pf, U, HID_, DH, DT);
+        static bool lds_set = false;
+        if (!lds_set) {     // 83 KB of folded weights (both orientations): beyond the 64 KB a kernel gets without asking
+            if (hipFuncSetAttribute((const void *)fine_decoder_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L_BWD_END * 4) != hipSuccess) return LARA2DGS_E_LAUNCH;
+            lds_set = true;
+        }
+        hipLaunchKernelGGL(fine_decoder_bwd_kernel, dim3(fd_grid(n) < 512u ? fd_grid(n) : 512u), dim3(256), L_BWD_END * 4, s, n, xn, pf,
+                           Wqk, W1ov, b1, W2, b2, d_sh, d_xn, d_pf, U, HID_, DH, DT);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
