@@ -156,6 +156,12 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
  * issues from two streams (one per scene) is better off with 1 (measured: training step 762 -> 786 frames/s).
  * Returns the previous value. */
 int lara2dgs_set_view_lanes(int32_t lanes);
+/* Forward composite: cut tile lists longer than 2048 entries into (at most 8) depth segments composited by different
+ * workgroups (a transmittance prepass gives every segment its starting T, M1, M2, so the 1e-4 stop, the median and the
+ * contributor records keep the reference's sequential semantics; images equal to rounding).  Off by default -- at LaRa's
+ * statistics it measured slower than one workgroup per tile --, initialised from LARA2DGS_FWD_SPLIT.
+ * Process-wide like the lane count.  Returns the previous value. */
+int lara2dgs_set_forward_split(int32_t on);
 int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                            const float *shs, const float *colors_precomp, const float *opacities,
                            const float *scales, const float *rotations, const float *transmat_precomp,

@@ -44,6 +44,13 @@ L2dProfScope::~L2dProfScope() {
 
 namespace {
 
+// forward composite: cut lists beyond 2048 entries into depth segments (opt-in; composite.hip: launch_composite_fwd)
+int env_flag(const char *name) {
+    const char *e = getenv(name);
+    return e && atoi(e) != 0 ? 1 : 0;
+}
+std::atomic<int> g_fwd_split{env_flag("LARA2DGS_FWD_SPLIT")};
+
 bool make_view(const lara2dgs_view *view, ViewDev &v) {
     if (!view) return false;
     if (view->P < 0 || view->image_height <= 0 || view->image_width <= 0) return false;
@@ -64,7 +71,7 @@ bool make_view(const lara2dgs_view *view, ViewDev &v) {
     v.cap = (unsigned)view->capacity;
     {
         static const unsigned dbg = getenv("LARA2DGS_DEBUG_FLAGS") ? (unsigned)strtoul(getenv("LARA2DGS_DEBUG_FLAGS"), nullptr, 0) : 0u;
-        v.dbg = dbg;
+        v.dbg = (dbg & ~128u) | (g_fwd_split.load() ? 128u : 0u);
     }
     v.bg = view->bg;
     v.viewmatrix = view->viewmatrix;
@@ -106,6 +113,7 @@ ScratchView carve_scratch(const ViewDev &v, void *scratch, ScratchLayout &L) {
     s.sub_start = (uint32_t *)(b + L.sub_start);
     s.sort_parts = (uint32_t *)(b + L.sort_parts);
     s.sort_items = (uint2 *)(b + L.sort_items);
+    s.fwd_slabs = (void *)(b + L.fwd_slabs);
     s.rect = (uint4 *)(b + L.rect);
     s.keys = (uint64_t *)(b + L.keys);
     s.block_tot = (uint32_t *)(b + L.block_tot);
@@ -180,7 +188,7 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
     if (rc) return rc;
     rc = launch_binning(v, st, sc, s);
     if (rc) return rc;
-    return launch_composite_fwd(v, st, out_color, out_allmap, s);
+    return launch_composite_fwd(v, st, sc, out_color, out_allmap, s);
 }
 
 int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const float *shs,
@@ -351,6 +359,8 @@ __global__ void __launch_bounds__(256) sum_slices_kernel(const float4 *__restric
 
 extern "C" {
 
+int lara2dgs_set_forward_split(int32_t on) { return g_fwd_split.exchange(on != 0); }
+
 int lara2dgs_set_view_lanes(int32_t lanes) {
     const int k = lanes < 1 ? 1 : (lanes > MAX_SIDE ? MAX_SIDE : lanes);
     return g_lanes.exchange(k);
@@ -417,7 +427,7 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
         for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
             hipStream_t s = lane_stream(i % lanes);
             rc = launch_binning(vd[i], st[i], sc[i], s);
-            if (rc == LARA2DGS_OK) rc = launch_composite_fwd(vd[i], st[i], out_color + i * 3 * HW, out_allmap + i * 7 * HW, s);
+            if (rc == LARA2DGS_OK) rc = launch_composite_fwd(vd[i], st[i], sc[i], out_color + i * 3 * HW, out_allmap + i * 7 * HW, s);
         }
     } else {
         if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));

@@ -59,6 +59,7 @@ struct ScratchView {
     uint32_t *block_tot;   // [ceil(P/256)] pairs per surfel block, then (in place) their exclusive scan
     float4 *pair_grad;     // [cap][5] backward: per (tile, surfel) gradient rows, surfel-major (aliases the forward region)
     uint32_t *pair_valid;  // [cap] bytes, backward: byte q != 0 <=> gradient row q (surfel-major) was written
+    void *fwd_slabs;       // forward composite of split tiles: per (tile, segment) rows (aliases the region the sort is done with)
 };
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -91,7 +92,7 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->total = o;
 }
 
-struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, sort_parts, sort_items, rect, keys, block_tot, pair_grad, pair_valid, total; };
+struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, sort_parts, sort_items, rect, keys, block_tot, pair_grad, pair_valid, fwd_slabs, total; };
 static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     int64_t o = 0;
@@ -108,7 +109,11 @@ static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayou
     L->pair_grad = fwd0;  // backward reuses the forward-only region
     L->pair_valid = align_up(fwd0 + cap * GRAD_F * 4, 256);
     const int64_t bwd_end = align_up(L->pair_valid + cap + 256, 256);
+    // forward composite of split tiles (after the sort: rect / keys are dead): 18 rows of 256 floats per (tile, 512 entries)
+    L->fwd_slabs = fwd0;
+    const int64_t slab_end = align_up(fwd0 + (cap / L2D_SEG + tiles + 1) * 18 * 256 * 4, 256);
     L->total = fwd_end > bwd_end ? fwd_end : bwd_end;
+    if (slab_end > L->total) L->total = slab_end;
 }
 
 // ---- launchers (one per .hip translation unit) -------------------------------------------------
@@ -121,7 +126,7 @@ int launch_preprocess_fwd_views(const ViewDev &v, int n, const ViewDev *views, c
                                 const float *rotations, const float *transmat_precomp, const StateView *st,
                                 const ScratchView *sc, int32_t *const *radii, hipStream_t s);
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s);
-int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float *out_allmap,
+int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
                          hipStream_t s);
 int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const float *dL_dcolor,
                          const float *dL_dallmap, hipStream_t s);

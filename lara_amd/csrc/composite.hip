@@ -260,8 +260,45 @@ struct FwdPixel {
         T = valid ? test_T : T;
         last_contributor = valid ? (uint32_t)(base + j + 1) : last_contributor;
     }
+
+    // transmittance prepass of a heavy tile's segment (see composite_fwd_kernel): only what a LATER segment needs to start
+    // from -- the segment's transmittance and its M1 / M2 sums, all relative to T = 1 at the segment's first entry; no
+    // termination here (a pixel that ends inside the segment makes every later segment start below 1e-4, i.e. finished)
+    __device__ __forceinline__ void blend_prepass(bool valid, const Hit &h) {
+        const float a = valid ? h.alpha : 0.f;
+        const float depth = valid ? h.depth : 1.0f;
+        const float w = a * T;
+        const float mm = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N * __builtin_amdgcn_rcpf(depth));
+        M1 += mm * w;
+        M2 += mm * mm * w;
+        T *= 1.0f - a;
+        done = done || T < 0.0001f;     // every later segment starts below 1e-4 whatever follows: nothing more to add up
+    }
 };
 
+// A tile whose list is longer than FWD_SPLIT is composited by several workgroups, one per depth segment, instead of one
+// (a single workgroup per tile makes the launch last as long as its longest list: 5.3 k entries against a mean of 1.5 k at
+// LaRa's init statistics).  Segments are cut on multiples of L2D_SEG; at most 8 per tile.
+constexpr int FWD_SPLIT = 2048;
+__device__ __forceinline__ int fwd_seg_len(const int total) {
+    const int n = (((total + 7) / 8 + L2D_SEG - 1) / L2D_SEG) * L2D_SEG;
+    return n < 2 * L2D_SEG ? 2 * L2D_SEG : n;
+}
+// per (tile, segment) scratch rows of 256 floats (thread = pixel): [0..2] prepass t, M1', M2'; [3..] the main pass' results
+constexpr int FSLAB_F = 18;
+enum { FS_T = 3, FS_M1, FS_M2, FS_C0, FS_C1, FS_C2, FS_DD, FS_N0, FS_N1, FS_N2, FS_DIST, FS_MEDD, FS_MEDC, FS_LAST, FS_DONE };
+__device__ __forceinline__ float *fwd_slab(float *slabs, const uint32_t *seg_base, const int tile, const int lo) {
+    return slabs + ((size_t)seg_base[tile] + (size_t)tile + (size_t)(lo / L2D_SEG)) * (FSLAB_F * 256);
+}
+
+// MODE 0: the whole list of a tile with at most FWD_SPLIT entries (one workgroup per tile; longer lists return at once).
+// MODE 1: transmittance prepass of segment blockIdx.y of a longer list: per pixel the product of (1 - alpha) and the M1 / M2
+//         sums over the segment, relative to T = 1 at its start -> slab rows 0..2.
+// MODE 2: the segment's real walk.  It starts from T, M1, M2 = the prefix of the EARLIER segments' prepass rows (so every
+//         decision that reads T -- the 1e-4 stop, the median -- is taken on the true transmittance, with the reference's
+//         sequential semantics), accumulates colour / normal / depth / distortion from zero and leaves them, with the
+//         contributor records, in slab rows FS_*; composite_fwd_combine_kernel adds the segments of a tile in order.
+template <int MODE>
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
@@ -269,7 +306,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
                      float *__restrict__ ckpt, uint2 *__restrict__ pair_mask,
-                     float *__restrict__ out_color, float *__restrict__ out_allmap) {
+                     float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs) {
     constexpr int CHUNK = FWD_CHUNK;
     static_assert(L2D_SEG % FWD_CHUNK == 0, "segment boundaries must fall on round boundaries");
     __shared__ float4 rec[REC4 * CHUNK];
@@ -288,6 +325,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
 
     if (header[1]) {  // binning capacity exceeded: make the failure loud in the data
+        if (MODE != 0) return;
         if (inside) {
             const float qnan = __uint_as_float(0x7fc00000u);
             for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = qnan;
@@ -300,8 +338,24 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    const bool split = total > FWD_SPLIT && (v.dbg & 128u);      // flag 128: lara2dgs_set_forward_split (opt-in, see launch_composite_fwd)
+    if ((MODE == 0) == split) return;
+    const int segf = MODE == 0 ? total : fwd_seg_len(total);
+    const int lo = MODE == 0 ? 0 : (int)blockIdx.y * segf, hi = min(total, lo + segf);   // this workgroup's entries [lo, hi)
+    if (lo >= hi && MODE != 0) return;
     FwdPixel px;
     px.done = !inside;
+    if (MODE == 2 && lo > 0) {      // the prefix of the earlier segments (at most 7 of them)
+        float T = 1.0f, M1 = 0.f, M2 = 0.f;
+        for (int l0 = 0; l0 < lo; l0 += segf) {
+            const float *sl = fwd_slab(slabs, seg_base, tile, l0) + threadIdx.x;
+            M1 += T * sl[256];
+            M2 += T * sl[512];
+            T *= sl[0];
+        }
+        px.T = T; px.M1 = M1; px.M2 = M2;
+        px.done = px.done || T < 0.0001f;        // the walk ended in an earlier segment (T never drops below 1e-4 otherwise)
+    }
     uint32_t *dbg_hdr = const_cast<uint32_t *>(header);
     const long long dbg_t0 = (v.dbg & 32u) ? (long long)__builtin_readcyclecounter() : 0ll;
     int dbg_rounds = 0;
@@ -313,16 +367,16 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     float4 cb1[SPT];
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
-        const int o = q * 256 + tid;
-        id1[q] = o < total ? point_list[range.x + o] : 0u;
-        id2[q] = CHUNK + o < total ? point_list[range.x + CHUNK + o] : 0u;
+        const int o = lo + q * 256 + tid;
+        id1[q] = o < hi ? point_list[range.x + o] : 0u;
+        id2[q] = CHUNK + o < hi ? point_list[range.x + CHUNK + o] : 0u;
     }
 #pragma unroll
-    for (int q = 0; q < SPT; q++) cb1[q] = q * 256 + tid < total ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0; base < total; base += CHUNK) {
+    for (int q = 0; q < SPT; q++) cb1[q] = lo + q * 256 + tid < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = lo; base < hi; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
         dbg_rounds++;
-        if (base && base % L2D_SEG == 0 && !px.done && (uint32_t)(base / L2D_SEG) <= seg_cnt[tile]) {
+        if (MODE != 1 && base && base % L2D_SEG == 0 && !px.done && (uint32_t)(base / L2D_SEG) <= seg_cnt[tile]) {
             // crossing a segment boundary: park the running sums over entries [0, base) so that the
             // backward can start a walk here (pixels that are done never read theirs)
             float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)(base / L2D_SEG - 1)) * (L2D_CKPT_F * 256) + tid;
@@ -336,10 +390,10 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             const uint32_t id0 = id1[q];
             const float4 cb0 = cb1[q];
             id1[q] = id2[q];
-            id2[q] = base + 2 * CHUNK + o < total ? point_list[range.x + base + 2 * CHUNK + o] : 0u;
-            cb1[q] = base + CHUNK + o < total ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
-            stage_entry<CHUNK>(geom, id0, cb0, base + o < total, X0, Y0, rec, nullptr, o,
-                               base + o < total ? pair_mask + range.x + base + o : nullptr);
+            id2[q] = base + 2 * CHUNK + o < hi ? point_list[range.x + base + 2 * CHUNK + o] : 0u;
+            cb1[q] = base + CHUNK + o < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            stage_entry<CHUNK>(geom, id0, cb0, base + o < hi, X0, Y0, rec, nullptr, o,
+                               (MODE != 1 && base + o < hi) ? pair_mask + range.x + base + o : nullptr);
         }
         __syncthreads();
         if (__ballot(!px.done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
@@ -348,7 +402,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         // wave's own LDS slice) and then walks all of it in one loop: a wave iteration lasts as long
         // as its busiest quad, and over 512 entries the quads' candidate counts are far more even
         // than over 64 (quad-slot efficiency 50 % -> 70 %).
-        const int nw = (min(CHUNK, total - base) + 63) >> 6;
+        const int nw = (min(CHUNK, hi - base) + 63) >> 6;
         unsigned long long *qm = &qmask[wave][grp][0];
 #pragma unroll 1
         for (int w = 0; w < nw; w++) {
@@ -394,8 +448,13 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 atomicAdd(&dbg_hdr[5], (unsigned)e0 + (unsigned)e1);
                 if (lane == 0) atomicAdd(&dbg_hdr[6], 1u);
             }
-            px.blend<CHUNK>(rec, j0, base, e0, h0);
-            px.blend<CHUNK>(rec, j1, base, e1, h1);
+            if (MODE == 1) {
+                px.blend_prepass(e0 && !px.done, h0);
+                px.blend_prepass(e1 && !px.done, h1);
+            } else {
+                px.blend<CHUNK>(rec, j0, base, e0, h0);
+                px.blend<CHUNK>(rec, j1, base, e1, h1);
+            }
             if (((__ballot(px.done) >> (lane & ~3)) & 0xfull) == 0xfull) { mm = 0ull; w = nw; n0 = false; n1 = false; }
         };
         while (true) {
@@ -406,6 +465,21 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         }
     }
     const float T = px.T;
+    if (MODE == 1) {
+        float *sl = fwd_slab(slabs, seg_base, tile, lo) + threadIdx.x;
+        sl[0] = px.T; sl[256] = px.M1; sl[512] = px.M2;
+        return;
+    }
+    if (MODE == 2) {
+        float *sl = fwd_slab(slabs, seg_base, tile, lo) + threadIdx.x;
+        sl[FS_T * 256] = px.T; sl[FS_M1 * 256] = px.M1; sl[FS_M2 * 256] = px.M2;
+        sl[FS_C0 * 256] = px.C0; sl[FS_C1 * 256] = px.C1; sl[FS_C2 * 256] = px.C2;
+        sl[FS_DD * 256] = px.Dd; sl[FS_N0 * 256] = px.N0; sl[FS_N1 * 256] = px.N1; sl[FS_N2 * 256] = px.N2;
+        sl[FS_DIST * 256] = px.distortion; sl[FS_MEDD * 256] = px.median_depth;
+        sl[FS_MEDC * 256] = __uint_as_float(px.median_contributor); sl[FS_LAST * 256] = __uint_as_float(px.last_contributor);
+        sl[FS_DONE * 256] = px.done ? 1.0f : 0.f;
+        return;
+    }
 
     if (inside) {
         final_T[pix] = T;
@@ -431,6 +505,68 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             out_allmap[5 * HW + pix] = (float)dbg_rounds;
         }
     }
+}
+
+// Adds the depth segments of a split tile in list order (thread = pixel): colour, normal, depth and distortion sums add up --
+// every segment blended with the true T, M1 and M2 --, the transmittance and the M sums are the last live segment's, the
+// contributor records the last segment's that has one; a pixel whose walk ended in segment s ignores the later ones.  The
+// checkpoint rows a segment parked hold its C / Dd / N sums from the SEGMENT's start: the earlier segments' totals are added
+// here, so that the backward finds the same absolute prefix sums as after a single-workgroup walk.
+__global__ void __launch_bounds__(256)
+composite_fwd_combine_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
+                             const uint32_t *__restrict__ tile_order, float *__restrict__ final_T,
+                             uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ seg_base,
+                             const uint32_t *__restrict__ seg_cnt, float *__restrict__ ckpt, float *__restrict__ out_color,
+                             float *__restrict__ out_allmap, float *__restrict__ slabs) {
+    if (header[1]) return;
+    const int tile = (int)tile_order[blockIdx.x];
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    if (total <= FWD_SPLIT || !(v.dbg & 128u)) return;
+    const int tx = tile % v.gx, ty = tile / v.gx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 2;
+    const int lxi = (wave & 1) * 8 + (grp & 3) * 2 + (lane & 1), lyi = (wave >> 1) * 8 + (grp >> 2) * 2 + ((lane >> 1) & 1);
+    const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
+    const bool inside = pxi < v.W && pyi < v.H;
+    const size_t HW = (size_t)v.H * v.W, pix = (size_t)pyi * v.W + pxi;
+    const int segf = fwd_seg_len(total);
+    float T = 1.0f, M1 = 0.f, M2 = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, dist = 0.f, medd = 0.f;
+    uint32_t medc = 0, last = 0;
+    bool done = false;
+    for (int lo = 0; lo < total; lo += segf) {
+        const float *sl = fwd_slab(slabs, seg_base, tile, lo) + threadIdx.x;
+        if (lo > 0 && !done) {       // this segment's checkpoint rows: + the prefix of the segments in front of it
+            const int hi = min(total, lo + segf);
+            for (int b = lo; b < hi; b += L2D_SEG) {
+                if ((uint32_t)(b / L2D_SEG) > seg_cnt[tile]) break;
+                float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)(b / L2D_SEG - 1)) * (L2D_CKPT_F * 256) + threadIdx.x;
+                ck[3 * 256] += C0; ck[4 * 256] += C1; ck[5 * 256] += C2; ck[6 * 256] += Dd;
+                ck[7 * 256] += N0; ck[8 * 256] += N1; ck[9 * 256] += N2;
+            }
+        }
+        if (done) continue;
+        T = sl[FS_T * 256]; M1 = sl[FS_M1 * 256]; M2 = sl[FS_M2 * 256];
+        C0 += sl[FS_C0 * 256]; C1 += sl[FS_C1 * 256]; C2 += sl[FS_C2 * 256];
+        Dd += sl[FS_DD * 256]; N0 += sl[FS_N0 * 256]; N1 += sl[FS_N1 * 256]; N2 += sl[FS_N2 * 256];
+        dist += sl[FS_DIST * 256];
+        const uint32_t mc = __float_as_uint(sl[FS_MEDC * 256]), lc = __float_as_uint(sl[FS_LAST * 256]);
+        if (mc) { medc = mc; medd = sl[FS_MEDD * 256]; }
+        if (lc) last = lc;
+        done = sl[FS_DONE * 256] != 0.f;
+    }
+    if (!inside) return;
+    final_T[pix] = T; final_T[pix + HW] = M1; final_T[pix + 2 * HW] = M2;
+    final_T[pix + 3 * HW] = C0; final_T[pix + 4 * HW] = C1; final_T[pix + 5 * HW] = C2;
+    final_T[pix + 6 * HW] = Dd; final_T[pix + 7 * HW] = N0; final_T[pix + 8 * HW] = N1; final_T[pix + 9 * HW] = N2;
+    n_contrib[pix] = last; n_contrib[pix + HW] = medc;
+    out_color[0 * HW + pix] = C0 + T * v.bg[0];
+    out_color[1 * HW + pix] = C1 + T * v.bg[1];
+    out_color[2 * HW + pix] = C2 + T * v.bg[2];
+    out_allmap[0 * HW + pix] = Dd;
+    out_allmap[1 * HW + pix] = 1.0f - T;
+    out_allmap[2 * HW + pix] = N0; out_allmap[3 * HW + pix] = N1; out_allmap[4 * HW + pix] = N2;
+    out_allmap[5 * HW + pix] = medd;
+    out_allmap[6 * HW + pix] = dist;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -910,15 +1046,30 @@ selftest_butterfly_kernel(const float *__restrict__ in, float *__restrict__ out)
 
 }  // namespace
 
-int launch_composite_fwd(const ViewDev &v, StateView st, float *out_color, float *out_allmap,
+int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
                          hipStream_t s) {
+    float *slabs = (float *)sc.fwd_slabs;
+#define FWD_ARGS v, st.header, st.ranges, st.point_list, (const float4 *)st.geom, st.tile_order, (const float4 *)st.cullbox, \
+                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, out_color, out_allmap, slabs
     {
+        // Depth-segment split of the long lists: OPT-IN (lara2dgs_set_forward_split / LARA2DGS_FWD_SPLIT=1), off by default
+        // because it measured SLOWER: at LaRa's init statistics the four launches take 123 (prepass) + 142 (segment walks) + 14
+        // (combine) + 127 us (short lists) = 406 us against 254 us for the single launch.  The prepass repeats the staging and
+        // the alpha evaluation of 45 % of the pairs (the blend it leaves out is the small part), and the short lists alone
+        // still take 127 us for 55 % of the pairs: what idles the single launch (VALU issue 0.59) is mostly the four waves of a
+        // workgroup waiting for each other at the round barriers, not the one long list at the end.  Kept because it is
+        // exact (parity-tested in both settings) and documents the measurement.
         L2D_PROF("composite_fwd", s);
-        hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges,
-                           st.point_list, (const float4 *)st.geom, st.tile_order,
-                           (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt,
-                           st.pair_mask, out_color, out_allmap);
+        if (v.dbg & 128u) {
+            // long lists first (workgroups of short lists and of segments beyond a list's end return on their first loads)
+            hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(v.tiles, 8), dim3(256), 0, s, FWD_ARGS);
+            hipLaunchKernelGGL(composite_fwd_kernel<2>, dim3(v.tiles, 8), dim3(256), 0, s, FWD_ARGS);
+            hipLaunchKernelGGL(composite_fwd_combine_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges, st.tile_order,
+                               st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, out_color, out_allmap, slabs);
+        }
+        hipLaunchKernelGGL(composite_fwd_kernel<0>, dim3(v.tiles), dim3(256), 0, s, FWD_ARGS);
     }
+#undef FWD_ARGS
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }

@@ -90,6 +90,8 @@ def load_library():
     lib.lara2dgs_backward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 10 + [i64, vp, i64, i32, vp, vp, vp]
     lib.lara2dgs_set_view_lanes.restype = ctypes.c_int
     lib.lara2dgs_set_view_lanes.argtypes = [i32]
+    lib.lara2dgs_set_forward_split.restype = ctypes.c_int
+    lib.lara2dgs_set_forward_split.argtypes = [i32]
     lib.lara2dgs_get_grad_layout.restype = ctypes.c_int
     lib.lara2dgs_get_grad_layout.argtypes = [i32, i32, i32, i32, i32, i32, ctypes.POINTER(GradLayout)]
     lib.lara2dgs_mark_visible.restype = ctypes.c_int
@@ -408,6 +410,12 @@ def set_view_lanes(n):
     application already issues from two streams (one per scene).  None returns to LARA2DGS_VIEW_STREAMS."""
     global _lanes
     _lanes = None if n is None else max(1, min(8, int(n)))
+
+
+def set_forward_split(on: bool) -> bool:
+    """Opt-in: composite tile lists beyond 2048 entries as depth segments on several workgroups (include/lara2dgs.h:
+    lara2dgs_set_forward_split; off by default -- measured slower at LaRa's statistics).  Returns the previous setting."""
+    return bool(load_library().lara2dgs_set_forward_split(int(bool(on))))
 
 
 def _view_lanes() -> int:

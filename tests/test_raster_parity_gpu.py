@@ -276,6 +276,41 @@ def test_backward_deep_lists_cross_segment_boundaries(hip_lib):
     _grad_check(act, cam, bg)
 
 
+@pytest.fixture
+def forward_split():
+    from lara_amd import rasterizer
+    prev = rasterizer.set_forward_split(True)
+    yield
+    rasterizer.set_forward_split(prev)
+
+
+def test_forward_split_of_long_lists_keeps_every_parity_class(hip_lib, forward_split):
+    """Opt-in `set_forward_split`: lists beyond 2048 entries are composited as depth segments by several workgroups (a
+    transmittance prepass gives each segment its starting T, M1, M2).  Same bars as the one-workgroup walk: integers exact,
+    contributor records under the explained-threshold rule, images and gradients within their bars -- forward (lists up
+    to > 2048, ragged image), and backward through lists several segments deep (the checkpoint rows of a split tile get the
+    earlier segments' sums added by the combine kernel)."""
+    from lara_amd import cameras
+    act, cams = small_scene(grid=12, size=150, seed=5, scale_boost=6.0, opacity_boost=-2.0)
+    cam = cameras.make_cameras(cameras.turntable_c2w(4)[2:3], 150, 90, 0.75, 0.6, 0.5, 2.5)[0]
+    ref = run_oracle(oracle_view(cam, (0.2, 0.4, 0.6)), to_numpy(act))
+    assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 2048
+    r = _gpu_forward(raster_settings(cam, (0.2, 0.4, 0.6), device=DEV), act)
+    _check_forward(r, ref, 90, 150)
+    act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)
+    ref = run_oracle(oracle_view(cams[1], (1.0, 1.0, 1.0)), to_numpy(act))
+    assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 3 * 1024 and ref.n_contrib[0].max() > 2 * 1024 + 100
+    _grad_check(act, cams[1], (1.0, 1.0, 1.0))
+    # and against the one-workgroup walk of the same frame: the same image to rounding
+    from lara_amd import rasterizer
+    rs = raster_settings(cams[1], (1.0, 1.0, 1.0), device=DEV)
+    a = _gpu_forward(rs, act)
+    rasterizer.set_forward_split(False)
+    b = _gpu_forward(rs, act)
+    rasterizer.set_forward_split(True)
+    assert float((a["color"] - b["color"]).abs().max()) <= 2e-6 and float((a["allmap"] - b["allmap"]).abs().max()) <= 2e-5
+
+
 def test_backward_when_checkpoint_rows_run_out(hip_lib, monkeypatch):
     """Checkpoint rows are a fixed slab (capacity / 1024 + 1): with the pair capacity barely above the real
     count, about half of the deep tiles do not get rows and must run their backward unsegmented -- same
