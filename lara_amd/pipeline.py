@@ -206,10 +206,18 @@ class LaRaPipeline(nn.Module):
 
     # -- the step ------------------------------------------------------------------------------------------------
     def forward(self, batch, feat_vol, with_fine=True):
-        dev = feat_vol.device
+        return self._step(batch, lambda: self.gaussians(feat_vol), feat_vol.device, feat_vol.shape[0], with_fine)
+
+    def forward_from_volume(self, batch, volume_feat_up, with_fine=True, autocast=True):
+        """The step from the encoder's OUTPUT on (network.py:458-532): what tests hold against the reference's own
+        `Network.forward` run with the same volume features (tests/golden/network_ref.npz)."""
+        return self._step(batch, lambda: self.gaussians_from_volume(volume_feat_up, autocast), volume_feat_up.device,
+                          volume_feat_up.shape[0], with_fine)
+
+    def _step(self, batch, make_gaussians, dev, B, with_fine):
         if dev.type != "cuda":
             raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
-        B, n_sel = feat_vol.shape[0], self.n_views
+        n_sel = self.n_views
         scalars = self.host_scalars(batch)
         cur = torch.cuda.current_stream(dev)
         n_streams = min(self.n_streams, B)
@@ -220,7 +228,7 @@ class LaRaPipeline(nn.Module):
 
         cams_of = [self.scene_cameras(batch, i, scalars) for i in range(B)]
         self._mark("start")
-        g = self.gaussians(feat_vol)
+        g = make_gaussians()
         # the input images as [B, n_sel, 3, H, W] (network.py:437-438, :469): what the sampler reads as `img_ref`
         inps = batch["tar_rgb"][:, :n_sel].permute(0, 1, 4, 2, 3).float().contiguous()
         if with_fine:

@@ -221,3 +221,42 @@ def test_pipeline_reference_mask_thins_dense_masks_in_training(hip_lib):
     P = 8 ** 3 * 2
     assert sizes[False] == [P, P, P, P]
     assert sizes[True][:2] == [P, P] and all(0.4 * P < n < 0.6 * P for n in sizes[True][2:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_streams", [2, 1])
+def test_pipeline_reproduces_the_references_own_network_forward(hip_lib, n_streams):
+    """tests/golden/network_ref.npz: the REFERENCE's unmodified `Network.forward` (eval, with_fine) run on CPU with the CPU
+    oracle standing in for its absent CUDA rasteriser (tests/golden/make_network_fixture.py).  From the encoder's output on --
+    coarse decoder, centres, masks, `MiniCam`, `render_img` with its post-processing, the stacked coarse renders, the
+    sampler, `forward_fine`, the fine views over `x[mask]`, the concatenated output dictionary -- the fixture is the
+    reference's own composition; here the same volume features and decoder parameters go through `LaRaPipeline` on the GPU
+    (fp32 on both sides: the HIP rasteriser against the oracle is a tolerance class)."""
+    from lara_amd.pipeline import CoarseFineDecoder, LaRaPipeline
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "network_ref.npz"))
+    dev = torch.device("cuda:0")
+    dec = CoarseFineDecoder()
+    dec.load_state_dict({k[len("decoder."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("decoder.")})
+    pipe = LaRaPipeline(torch.nn.Identity(), dec.to(dev), grid_reso=4, n_offset_groups=4, n_views=4, n_streams=n_streams).to(dev).eval()
+    pipe.opacity_shift = float(fx["opacity_shift"])
+    B, H, W = int(fx["B"]), int(fx["H"]), int(fx["W"])
+    batch = {k[len("batch."):]: torch.from_numpy(fx[k]).to(dev) for k in fx.files if k.startswith("batch.")}
+    batch["meta"] = {"tar_h": torch.full((B,), H), "tar_w": torch.full((B,), W)}
+    with torch.no_grad():
+        out = pipe.forward_from_volume(batch, torch.from_numpy(fx["volume_feat_up"]).to(dev), with_fine=True, autocast=False)
+        pipe.join_streams()
+    torch.cuda.synchronize()
+    want = {k[len("out."):]: fx[k] for k in fx.files if k.startswith("out.")}
+    assert set(out) == set(want) and 0.5 < float(fx["kept_fraction"]) < 0.95
+    for k, w in want.items():
+        got = out[k].cpu().numpy()
+        assert got.shape == w.shape, k
+        err = np.abs(got - w)
+        scale = max(1.0, float(np.abs(w).max()))
+        # a depth normal is a normalised cross product of finite differences: where the surface depth is ~0 on both sides it
+        # is ill-conditioned, so that map gets the looser bar on its worst pixels
+        worst, typical = (5e-2, 2e-3) if k.startswith("depth_normal") else (5e-3, 1e-4)
+        assert err.max() <= worst * scale, (k, float(err.max()))
+        assert np.quantile(err, 0.999) <= typical * scale, (k, float(np.quantile(err, 0.999)))
+    mse = float(((out["image_fine"].cpu().numpy() - want["image_fine"]) ** 2).mean())
+    assert 10 * np.log10(1.0 / max(mse, 1e-30)) >= 70.0
