@@ -1032,6 +1032,8 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     from lara_amd.encoder_train import VolTransformer
     from lara_amd.pipeline import CoarseFineDecoder, LaRaPipeline, lara_loss
     rasterizer.load_library()
+    if args.views < 4 and not args.no_fine:
+        raise SystemExit("bench.py --step pipeline: the fine stage samples the 4 input views (configs/base.yaml: n_views 4); --views >= 4 or --no-fine")
     info = {"grad_allreduce": None}
     torch.manual_seed(0)          # identical initial parameters on every rank, as DDP expects
     enc = VolTransformer(256, 800, [args.grid // 4], args.grid // 2, args.grid, 80, args.encoder_layers, 16)

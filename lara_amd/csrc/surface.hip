@@ -163,8 +163,8 @@ activate_fwd_kernel(const int64_t P, const float *__restrict__ opacity, const fl
     if (scales) { const float2 v = scales[i]; s_out[i] = make_float2(expf(v.x), expf(v.y)); }   // torch.exp
     if (rotations) {                                                    // F.normalize: x / max(|x|, 1e-12)
         const float4 q = rotations[i];
-        const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        r_out[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        r_out[i] = make_float4(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm);      // (divisions, as torch: x / clamp_min(norm, eps))
     }
 }
 

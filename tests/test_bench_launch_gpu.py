@@ -1,6 +1,6 @@
 """`python bench.py --gpus 2` on the GPU box: the launcher starts two ranks itself; each runs the REAL step -- the
-trainable HIP VolTransformer under torch's DistributedDataParallel (forward, backward, bucketed all-reduce) around
-the HIP raster's forward + backward (coarse + fine views).  The box has one GPU and RCCL wants one device per rank,
+whole pipeline step (trainable HIP VolTransformer -> decoder -> coarse views -> sampler -> forward_fine -> fine views -> loss
+-> backward) under torch's DistributedDataParallel (bucketed all-reduce of the encoder + decoder gradients).  The box has one GPU and RCCL wants one device per rank,
 so both ranks share cuda:0 and the process group is gloo (LARA_BENCH_BACKEND=gloo): the number means nothing, the
 code path is the one `--gpus N` takes with nccl on an N-GPU node."""
 import json
@@ -19,15 +19,16 @@ def test_bench_gpus_2_real_step_over_gloo(hip_lib):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LARA_BENCH_PLUMBING"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes", "1",
-           "--views", "2", "--grid", "16", "--res", "128", "--encoder-layers", "2", "--no-cpu-baseline", "--no-roofline"]
+           "--views", "4", "--grid", "16", "--res", "128", "--encoder-layers", "2", "--no-cpu-baseline", "--no-roofline"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["data"] == "synthetic"
-    assert out["config"]["frames_per_step"] == 2 * 1 * 2 * 2           # ranks x scenes x views x (coarse + fine)
+    assert out["config"]["frames_per_step"] == 2 * 1 * 4 * 2           # ranks x scenes x views x (coarse + fine)
+    assert out["config"]["step"] == "pipeline"
     ar = out["config"]["grad_allreduce"]
     assert ar["backend"] == "gloo" and ar["buckets"] and sum(ar["buckets"]) == ar["bytes_per_step"]
-    assert ar["bytes_per_step"] > 4 * 6_000_000                        # two GroupAttBlocks + pos_embed + tail, fp32
+    assert ar["bytes_per_step"] > 4 * 5_000_000                        # two GroupAttBlocks + pos_embed + tail + decoder, fp32
     assert out["value"] > 0
