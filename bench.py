@@ -1,39 +1,42 @@
 #!/usr/bin/env python
 """bench.py -- novel-view frames/sec @512x512 (4-view in, 2DGS fwd+bwd) on MI355X.
 
-One *step* = one pass of the hot path (every row of SURVEY.md section 8a) over one training batch, ordered as a LaRa
-training step orders it (lightning/network.py:431-532, lightning/system.py:38-60): on every rank, for its B = 4
-scenes,
-    1. the volume transformer's forward (`encoder_train.VolTransformer`, rows A1-A3; under
-       `DistributedDataParallel` when N > 1, as train_lightning.py:68-81 does with DDPStrategy),
-    2. the raster: per scene 8 coarse views (4 input + 4 novel, dataLoader/gobjverse.py:46-47) and -- LaRa's fine
-       stage, network.py:502-525 -- 8 more over the opacity > 0.005 subset; each view = one GaussianRasterizer
-       forward over the scene's P = 524 288 surfels at 512x512 (configs/base.yaml:13,23,34),
-    3. the backward of all of it: every view's rasteriser backward, then the transformer's backward, whose
-       parameter gradients DDP all-reduces bucket by bucket (25 MB buckets, RCCL over xGMI) while the backward is
-       still running.  That all-reduce is the path's only exchange step; the raster is per view and NOT sharded
-       (BASELINE.json north_star) -> per-scene data parallel, weak scaling.
-A *frame* is one rasteriser forward + backward.  `value` = frames of all ranks /
-max-over-ranks wall time of the timed steps, with scenes, cameras, image features and incoming gradients already
-resident in HBM.  Data is synthetic (no dataset / checkpoint in this environment): SURVEY.md section 8d,
-lara_amd/synthetic.py; the encoder and the raster run on independent synthetic tensors of the right shapes (the
-decoder MLP between them is outside section 8a), but in LaRa's ORDER: the raster's forward is enqueued behind the
-encoder's forward and the encoder's backward behind the raster's backward (stream waits), so the two never overlap on
-the device, as the data dependence through the decoder forbids.  `--step raster` times the raster alone (round 1's definition);
-the default line carries it as `raster_only`.
+One *step* (default `--step pipeline`) = one pass of the WHOLE data-dependent LaRa training step on the hot path (every row
+of SURVEY.md section 8a, composed as lightning/network.py:455-532 composes them, `lara_amd.pipeline.LaRaPipeline`), on
+every rank for its B = 4 scenes:
+    1. the volume transformer's forward (`encoder_train.VolTransformer`, rows A1-A3) on the image-feature volume;
+    2. `Decoder.forward_coarse` (plain torch, outside section 8a) -> the scenes' P = 524 288 Gaussians each, centres, masks;
+    3. per scene 8 coarse views (4 input + 4 novel, dataLoader/gobjverse.py:46-47) at 512x512 through ONE multi-view
+       rasteriser call + ONE fused post-processing launch (`Renderer.render_views`);
+    4. LaRa's fine stage (network.py:502-525): `_check_mask` (in training a mask keeping > 50 % is thinned to about half at
+       random), the point sampler on the 4 input views, `Decoder.forward_fine`, 8 fine views over the masked subset;
+    5. the loss of lightning/loss.py minus MS-SSIM (package absent) on the reference's output dictionary;
+    6. ONE backward through all of it -- every view's rasteriser backward, the sampler, the decoders, then the transformer's
+       backward, whose encoder is one autograd node per block, so that under DistributedDataParallel (N > 1,
+       train_lightning.py:68-81) each 25 MB bucket's RCCL all-reduce starts while the earlier blocks' backward still runs.
+       That all-reduce is the path's only exchange step; the raster is per view and NOT sharded (BASELINE.json north_star)
+       -> per-scene data parallel, weak scaling.
+A *frame* is one rasteriser forward + backward; a step holds 64 of them.  `value` = frames of all
+ranks / max-over-ranks wall time of the timed steps, with the collated batch (cameras, images, rays) and the image-feature
+volume already resident in HBM.  Data is synthetic (no dataset / checkpoint in this environment): random-init network of the
+reference's architecture = SURVEY.md section 8d's "init" regime (mean opacity 0.10, every pixel walks ~1.5 k surfels).
+`--step train` is round 2's definition (encoder and raster on INDEPENDENT synthetic tensors, no decoder / sampler /
+forward_fine / loss), carried on the default line as `independent_tensors_step`; `--step raster` times the raster alone.
 
 `python bench.py --gpus N` with N > 1 launches its own N ranks (torch.distributed.run, one per GPU, backend nccl =
 RCCL) when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py --gpus N`
 it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
-The scenes of a step are independent, so their raster work is spread over `--streams` HIP streams (default 2: the
-composite kernels end in a tail of a few heavy tiles; a second stream fills those holes).
+The scenes of a step are independent after the decoder, so scene i runs on HIP stream i % `--streams` (default 2).
 
-Extra objects on the JSON line (rank 0, N = 1): "roofline" (dominant kernel, HIP-event timed, algorithmic bytes of
-SURVEY.md section 8d; `bound` says what binds it), "cpu_baseline" (the CPU oracle of the raster AND the fixture-pinned
-fp32 restatement of the reference's encoder, both on this box's host cores), "raster_only", "single_stream",
-"forward_only", "mesh_eval" (configs[4]: 48 views @1024x1024 + TSDF fusion), "attention", "encoder", "encoder_train", "rays",
-"render_img", "point_feats", "fine_decoder", "fine_stage".
+Extra objects on the JSON line (rank 0, N = 1): "stages" (where the step's time goes: forward stages + backward on one
+stream, the library's kernels grouped by stage), "roofline" (dominant kernel on the seeded synthetic scenes of SURVEY 8d,
+HIP-event timed, algorithmic bytes of section 8d; `bound` says what binds it; `valu_useful_frac` = useful FMA lane-ops /
+issued lane-slots), "cpu_baseline" (the CPU oracle of the raster AND the fixture-pinned fp32 restatement of the
+reference's encoder, both on this box's host cores; `parity_vs_oracle` with the committed fp64 arbitration),
+"independent_tensors_step", "raster_only", "single_stream", "forward_only", "mesh_eval" (configs[4]: 48 views @1024x1024 +
+block-sparse TSDF fusion + marching cubes), "attention", "encoder", "encoder_train", "rays", "render_img", "point_feats",
+"fine_decoder", "fine_stage".
 """
 import argparse
 import contextlib
@@ -1352,7 +1355,7 @@ def main():
         # no decoder / sampler / forward_fine / loss, the fine subset not thinned
         a2 = argparse.Namespace(**{**vars(args), "step": "train"})
         step2, info2 = make_training_step(a2, device, rank, world, plumbing)
-        for _ in range(2):
+        for _ in range(3):
             step2()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
