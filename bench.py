@@ -1042,6 +1042,8 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     enc = VolTransformer(256, 800, [args.grid // 4], args.grid // 2, args.grid, 80, args.encoder_layers, 16)
     pipe = LaRaPipeline(enc, CoarseFineDecoder(), grid_reso=args.grid // 2, n_streams=args.streams).to(device)
     pipe.fine_mask = args.fine_mask
+    pipe._streams = _streams      # one pair of scene streams for every leg of this process: the device has 4 hardware queues, and a
+                                  # second pair (the side legs' `step`) would alias onto them and serialise (93.5 vs 82.3 ms)
     pipe.train()
     if "LARA2DGS_VIEW_STREAMS" not in os.environ:
         rasterizer.set_view_lanes(view_lanes_for(args.streams))
@@ -1103,7 +1105,7 @@ def pipeline_breakdown(info, args):
         rasterizer.set_view_lanes(1)      # strictly serial: stage times add up
     res = {}
     try:
-        for _ in range(2):
+        for _ in range(3):      # (the caller's stream has its own allocator pool: let it see the step's sizes first)
             full_step()
         torch.cuda.synchronize()
         pipe.stage_events = []

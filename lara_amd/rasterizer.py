@@ -140,12 +140,15 @@ def _dup_factor() -> int:
 
 
 def _sizing_P(P: int) -> int:
-    """The surfel count the buffers are SIZED for: P rounded up to a multiple of 65 536 (1024 below that).  LaRa's fine
-    pass renders a subset whose size changes with every step (`x[mask]`, network.py:514-524; `_check_mask` thins it at
-    random): a state buffer sized from the exact count is a new ~1 GB allocation size per call, which the caching
-    allocator answers with a fresh hipMalloc (measured: +66 ms on such a step).  Quantised, the same sizes recur."""
-    q = 65536 if P > 65536 else 1024
-    return max(-(-P // q) * q, q)
+    """The surfel count the buffers are SIZED for: P rounded up to the next odd multiple of 32 768 (to a multiple of 1024
+    below 32 768).  LaRa's fine pass renders a subset whose size changes with every step (`x[mask]`, network.py:514-524;
+    `_check_mask` thins it at random): a state buffer sized from the exact count is a new ~1 GB allocation size per call,
+    which the caching allocator answers with a fresh hipMalloc (measured: +66 ms on such a step).  Quantised, the same
+    sizes recur.  The bucket edges sit at ODD multiples of 32 768 because LaRa's counts cluster at even ones (P = 2 (2r)^3
+    and the thinned half of it): a subset of 262 144 +- 500 then always lands in one bucket, not in two."""
+    if P <= 32768:
+        return max(-(-P // 1024) * 1024, 1024)
+    return (P + 32767) // 65536 * 65536 + 32768
 
 
 def binning_capacity(P: int) -> int:

@@ -100,9 +100,10 @@ def test_buffer_sizes_are_quantised_in_the_surfel_count(hip_lib):
     allocation size per call.  Sizes come from the count rounded up, and a buffer sized for the rounded count holds the
     exact one."""
     from lara_amd import rasterizer
-    assert rasterizer._sizing_P(262100) == rasterizer._sizing_P(262144) == 262144
-    assert rasterizer._sizing_P(262145) == 327680 and rasterizer._sizing_P(0) == 1024 and rasterizer._sizing_P(1500) == 2048
-    for P in (1, 1023, 70000, 262100, 524288):
+    assert rasterizer._sizing_P(261600) == rasterizer._sizing_P(262144) == rasterizer._sizing_P(262700) == 294912
+    assert rasterizer._sizing_P(524288) == 557056 and rasterizer._sizing_P(0) == 1024 and rasterizer._sizing_P(1500) == 2048
+    assert rasterizer._sizing_P(32768) == 32768 and rasterizer._sizing_P(32769) == 98304 and rasterizer._sizing_P(98305) == 163840
+    for P in (1, 1023, 32768, 32769, 70000, 98304, 262100, 524288):
         q = rasterizer._sizing_P(P)
         cap = rasterizer.binning_capacity(P)
         assert q >= P and cap == rasterizer.binning_capacity(q)
