@@ -180,7 +180,7 @@ mc_emit_kernel(const McP p, const uint8_t *__restrict__ allocated, const int32_t
 
 }  // namespace
 
-static bool mc_tables_loaded = false;
+static bool mc_tables_loaded[64] = {};   // per device: constant memory is per device
 
 extern "C" {
 
@@ -238,12 +238,14 @@ int lara_tsdf_integrate_blocks(int32_t res, const float *origin, float voxel_len
 static int mc_params(int32_t res, const float *origin, float voxel_length, const float *tsdf, const float *weight, const float *rgb,
                      McP *p) {
     if (res <= 0 || res > 2048 || res % TB || !(voxel_length > 0.f) || !origin || !tsdf || !weight || !rgb) return LARA2DGS_E_INVALID;
-    if (!mc_tables_loaded) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LARA2DGS_E_LAUNCH;
+    if (!mc_tables_loaded[dev]) {
         if (hipMemcpyToSymbol(HIP_SYMBOL(c_mc_ntri), MC_NTRI, sizeof(MC_NTRI)) != hipSuccess ||
             hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri), MC_TRI, sizeof(MC_TRI)) != hipSuccess ||
             hipMemcpyToSymbol(HIP_SYMBOL(c_mc_edge), MC_EDGE_CORNERS, sizeof(MC_EDGE_CORNERS)) != hipSuccess)
             return LARA2DGS_E_LAUNCH;
-        mc_tables_loaded = true;
+        mc_tables_loaded[dev] = true;
     }
     *p = McP{res, origin[0], origin[1], origin[2], voxel_length, tsdf, weight, rgb};
     return LARA2DGS_OK;

@@ -236,3 +236,32 @@ def test_hip_mesh_extraction_matches_the_oracle_and_the_sphere():
     _mesh_checks(v.cpu().numpy(), t.cpu().numpy(), radius, vl)
     empty = TSDFVolume((-0.5, -0.5, -0.5), vl, 3 * vl, 32).extract_triangle_mesh()
     assert empty[0].shape == (0, 3) and empty[1].shape == (0, 3)
+
+
+def test_marching_cubes_table_is_the_generators_output_and_watertight():
+    """csrc/mc_tables.h is generated (tools/gen_mc_tables.py): the committed header equals what the generator derives, every
+    case has at most 5 triangles, complementary cases produce the same vertices, and on a random field with a positive shell
+    every edge of the extracted surface is shared by exactly two triangles with opposite directions."""
+    import subprocess
+    import sys
+    from collections import Counter
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    assert subprocess.run([sys.executable, __import__("os").path.join(root, "tools", "gen_mc_tables.py"), "--check"]).returncode == 0
+    sys.path.insert(0, __import__("os").path.join(root, "tools"))
+    import gen_mc_tables as g
+    table = g.build()
+    assert max(len(t) for t in table) == 5 and not table[0] and not table[255]
+    for c in range(256):
+        assert sorted({e for t in table[c] for e in t}) == sorted({e for t in table[255 - c] for e in t})
+    rng = np.random.default_rng(3)
+    R = 10
+    f = rng.normal(size=(R, R, R)).astype(np.float32)
+    f[0] = f[-1] = 1; f[:, 0] = f[:, -1] = 1; f[:, :, 0] = f[:, :, -1] = 1
+    verts, _, keys = tsdf_ref.extract_mesh(R, (0.0, 0.0, 0.0), 1.0, f.reshape(-1), np.ones(R ** 3, np.float32), np.zeros((R ** 3, 3), np.float32))
+    und, dirc = Counter(), Counter()
+    for t in keys:
+        for i in range(3):
+            a, b = int(t[i]), int(t[(i + 1) % 3])
+            und[(min(a, b), max(a, b))] += 1
+            dirc[(a, b)] += 1
+    assert len(keys) > 200 and set(und.values()) == {2} and set(dirc.values()) == {1}
