@@ -1092,6 +1092,52 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     return full_step, info
 
 
+def ddp_single_rank_leg(info, args, device):
+    """The pipeline step under torch DistributedDataParallel with backend nccl (= RCCL) and ONE rank: the reducer's hooks on
+    the per-block encoder nodes, its bucket copies and RCCL's all-reduce launches (a one-member ring) -- the local cost of the
+    path's exchange step, measurable on the one GPU this environment exposes.  N > 1 adds the xGMI transfers themselves."""
+    import socket
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from lara_amd import dp
+    from lara_amd.pipeline import lara_loss
+    pipe, batch, feat_vol, _ = info["pipeline"]
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        model = DDP(pipe, device_ids=[device.index], find_unused_parameters=True, bucket_cap_mb=dp.DDP_BUCKET_MB)
+        params = [p for p in pipe.parameters() if p.requires_grad]
+
+        def one():
+            loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=not args.no_fine), 2000)
+            loss.backward()
+            pipe.join_streams()
+            for p in params:
+                p.grad = None
+            feat_vol.grad = None
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        try:
+            sizes = [int(x) for x in str(model._get_ddp_logging_data().get("bucket_sizes", "")).split(",") if x.strip()]
+        except Exception:
+            sizes = None
+        return {"ms_per_step": round(1e3 * dt, 3), "value": round(info["frames_per_rank_step"] / dt, 3), "unit": "frames/s", "buckets": sizes,
+                "what": "the same step wrapped in DistributedDataParallel, backend nccl (RCCL), world size 1: reducer hooks, bucket copies "
+                        "and one-member all-reduces included"}
+    finally:
+        dist.destroy_process_group()
+
+
 def pipeline_breakdown(info, args):
     """Where the pipeline step's time goes: (a) forward stages on ONE stream (HIP events at the stage boundaries of
     `LaRaPipeline.forward`) + the whole backward; (b) the library's kernels of one whole step grouped by stage (HIP events
@@ -1248,6 +1294,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
+    # Exactly ONE line on stdout, the JSON: libraries that print there on their own (RCCL's version banner at communicator
+    # creation, for one) are sent to stderr at the file-descriptor level until the line is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1353,6 +1404,10 @@ def main():
     if solo and args.step == "pipeline" and not args.no_roofline:
         out["stages"] = pipeline_breakdown(info, args)
     if solo and args.step == "pipeline" and not args.no_roofline and not args.no_side_legs:
+        try:
+            out["ddp_single_rank_rccl"] = ddp_single_rank_leg(info, args, device)
+        except Exception as e:      # (a box without a usable RCCL: say so instead of losing the line)
+            out["ddp_single_rank_rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # round 2's headline definition, kept for continuity: encoder and raster on independent synthetic tensors,
         # no decoder / sampler / forward_fine / loss, the fine subset not thinned
         a2 = argparse.Namespace(**{**vars(args), "step": "train"})
@@ -1441,10 +1496,13 @@ def main():
             roof["valu_useful_frac"] = round(pairs * USEFUL_FMA_PER_PAIR[roof["kernel"]] / (roof["valu_insts_per_launch"] * 64.0), 4)
             roof["valu_useful_what"] = (f"{pairs} blended (pixel, splat) pairs of view 0 (counted by the CPU oracle in this run) x "
                                         f"{USEFUL_FMA_PER_PAIR[roof['kernel']]} FMA-equivalents / (SQ_INSTS_VALU x 64 lanes, committed PMC)")
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

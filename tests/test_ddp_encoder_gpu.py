@@ -81,3 +81,48 @@ def test_hip_backward_feeds_torch_ddp(hip_lib):
         assert [e[1] for e in log if e[0] == "block_backward_launch"] == [1, 0]
         assert first_allreduce < last_block, log
         assert sum(e[0] == "allreduce_enqueued" for e in log) >= 3
+
+
+def _rccl_worker(port, out):
+    """One rank, backend nccl (= RCCL on ROCm): the communicator initialises and DDP's bucketed all-reduce runs through it
+    around the whole pipeline step.  (One GPU here, so the ring has one member; what this pins is that the RCCL path --
+    init, streams, the reducer's hooks on the per-block encoder nodes and the multi-stream raster -- works end to end.)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        from lara_amd.pipeline import lara_loss
+        from tests.test_pipeline import _small_problem
+        t = torch.ones(1024, device="cuda:0")
+        dist.all_reduce(t)
+        pipe, batch, feat_vol = _small_problem(torch.device("cuda:0"))
+        pipe.fine_mask = "plain"
+
+        def grads(model):
+            for p in pipe.parameters():
+                p.grad = None
+            loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=True), 2000)
+            loss.backward()
+            pipe.join_streams()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().cpu().numpy() for n, p in pipe.named_parameters()}
+        plain = grads(pipe)
+        ddp = torch.nn.parallel.DistributedDataParallel(pipe, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=1)
+        reduced = grads(ddp)
+        out.put((float(t.sum()), plain, reduced))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_initialises_and_ddp_reduces_through_it(hip_lib):
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29500 + (os.getpid() % 2000) + 7, out))
+    p.start()
+    total, plain, reduced = out.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and total == 1024.0
+    for n in plain:      # world size 1: the mean over ranks is the rank's own gradient (bf16 backward: same kernels, same bits
+        a, b = plain[n], reduced[n]     # up to the order autograd accumulates the views' terms in)
+        assert np.isfinite(b).all() and np.abs(a - b).max() <= 1e-2 * np.abs(a).max() + 1e-12, n
