@@ -162,6 +162,11 @@ int lara2dgs_set_view_lanes(int32_t lanes);
  * statistics it measured slower than one workgroup per tile --, initialised from LARA2DGS_FWD_SPLIT.
  * Process-wide like the lane count.  Returns the previous value. */
 int lara2dgs_set_forward_split(int32_t on);
+/* Multi-view calls with a scratch buffer per view: run binning and composite of ALL views as one launch per kernel on the
+ * caller's stream (workgroup z index = view; the views' buffers sit at a constant stride), instead of one launch per view and
+ * kernel dealt to the lanes.  On by default (LARA2DGS_VIEWS_BATCH_KERNELS=0 turns it off); same results bit for bit.  Returns
+ * the previous value. */
+int lara2dgs_set_views_batch_kernels(int32_t on);
 int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                            const float *shs, const float *colors_precomp, const float *opacities,
                            const float *scales, const float *rotations, const float *transmat_precomp,

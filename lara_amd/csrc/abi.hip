@@ -45,10 +45,12 @@ L2dProfScope::~L2dProfScope() {
 namespace {
 
 // forward composite: cut lists beyond 2048 entries into depth segments (opt-in; composite.hip: launch_composite_fwd)
-int env_flag(const char *name) {
+int env_flag(const char *name, int dflt = 0) {
     const char *e = getenv(name);
-    return e && atoi(e) != 0 ? 1 : 0;
+    return e ? (atoi(e) != 0 ? 1 : 0) : dflt;
 }
+// multi-view calls: binning + composite of all views as one launch per kernel (default) instead of per view on the lanes
+std::atomic<int> g_batch_kernels{env_flag("LARA2DGS_VIEWS_BATCH_KERNELS", 1)};
 std::atomic<int> g_fwd_split{env_flag("LARA2DGS_FWD_SPLIT")};
 
 bool make_view(const lara2dgs_view *view, ViewDev &v) {
@@ -361,6 +363,8 @@ extern "C" {
 
 int lara2dgs_set_forward_split(int32_t on) { return g_fwd_split.exchange(on != 0); }
 
+int lara2dgs_set_views_batch_kernels(int32_t on) { return g_batch_kernels.exchange(on != 0); }
+
 int lara2dgs_set_view_lanes(int32_t lanes) {
     const int k = lanes < 1 ? 1 : (lanes > MAX_SIDE ? MAX_SIDE : lanes);
     return g_lanes.exchange(k);
@@ -422,6 +426,21 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
                                              transmat_precomp, &st[i0], &sc[i0], &rad[i0], caller);
         }
         if (rc != LARA2DGS_OK) return rc;
+        if (g_batch_kernels.load()) {
+            // binning and composite of ALL views as one launch per kernel on the caller's stream (blockIdx.z = view): one
+            // kernel's tail of long lists is filled by the next view's workgroups, and 4 launches replace 4 per view
+            for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
+                ViewBatch vb{};
+                vb.n = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
+                vb.state_stride = state_stride; vb.scratch_stride = scratch_stride;
+                for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
+                rc = launch_binning(vd[i0], st[i0], sc[i0], caller, &vb);
+                if (rc == LARA2DGS_OK)
+                    rc = launch_composite_fwd(vd[i0], st[i0], sc[i0], out_color + (int64_t)i0 * 3 * HW, out_allmap + (int64_t)i0 * 7 * HW,
+                                              caller, &vb);
+            }
+            return rc;
+        }
         if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
         for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
         for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
@@ -497,15 +516,25 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
         }
         // validity bitmaps of all views: one strided fill on the caller's stream, in front of the fork
         zero_strided(sc[0].pair_valid, scratch_stride, SL[0].total - SL[0].pair_valid, n_views, caller);
-        if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
-        for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
-        for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
-            hipStream_t s = lane_stream(i % lanes);
-            rc = launch_composite_bwd(vd[i], st[i], sc[i], dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW, s);
-        }
-        for (int k = 1; k < lanes; k++) {
-            HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
-            HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
+        if (g_batch_kernels.load()) {
+            for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
+                ViewBatch vb{};
+                vb.n = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
+                vb.state_stride = state_stride; vb.scratch_stride = scratch_stride;
+                for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
+                rc = launch_composite_bwd(vd[i0], st[i0], sc[i0], dL_dcolor + (int64_t)i0 * 3 * HW, dL_dallmap + (int64_t)i0 * 7 * HW, caller, &vb);
+            }
+        } else {
+            if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
+            for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
+            for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
+                hipStream_t s = lane_stream(i % lanes);
+                rc = launch_composite_bwd(vd[i], st[i], sc[i], dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW, s);
+            }
+            for (int k = 1; k < lanes; k++) {
+                HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
+                HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
+            }
         }
         for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
             const int nb = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;

@@ -58,7 +58,12 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
                  uint32_t *__restrict__ tile_order, uint32_t *__restrict__ block_tot,
                  uint32_t *__restrict__ seg_base, uint32_t *__restrict__ seg_cnt,
                  uint32_t *__restrict__ bwd_order, uint2 *__restrict__ bwd_items,
-                 uint32_t *__restrict__ sort_parts, uint2 *__restrict__ sort_items) {
+                 uint32_t *__restrict__ sort_parts, uint2 *__restrict__ sort_items, const long long sst, const long long qst) {
+    tile_count = l2d_view_ptr(tile_count, qst); sub_start = l2d_view_ptr(sub_start, qst); block_tot = l2d_view_ptr(block_tot, qst);
+    sort_parts = l2d_view_ptr(sort_parts, qst); sort_items = l2d_view_ptr(sort_items, qst);
+    ranges = l2d_view_ptr(ranges, sst); header = l2d_view_ptr(header, sst); tile_order = l2d_view_ptr(tile_order, sst);
+    seg_base = l2d_view_ptr(seg_base, sst); seg_cnt = l2d_view_ptr(seg_cnt, sst); bwd_order = l2d_view_ptr(bwd_order, sst);
+    bwd_items = l2d_view_ptr(bwd_items, sst);
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s, s_max;
     __shared__ uint32_t bcnt[64];
@@ -285,7 +290,10 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
 __global__ void __launch_bounds__(256)
 scatter_kernel(ViewDev v, const uint4 *__restrict__ rect, const uint32_t *__restrict__ sub_start,
                const uint32_t *__restrict__ block_base, uint32_t *__restrict__ pair_base,
-               uint32_t *__restrict__ tile_fill, uint64_t *__restrict__ keys, const int use_lds) {
+               uint32_t *__restrict__ tile_fill, uint64_t *__restrict__ keys, const int use_lds, const long long sst,
+               const long long qst) {
+    rect = l2d_view_ptr(rect, qst); sub_start = l2d_view_ptr(sub_start, qst); block_base = l2d_view_ptr(block_base, qst);
+    tile_fill = l2d_view_ptr(tile_fill, qst); keys = l2d_view_ptr(keys, qst); pair_base = l2d_view_ptr(pair_base, sst);
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int slice = blockIdx.x % L2D_SLICES;
@@ -564,7 +572,11 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
                  const uint32_t *__restrict__ tile_order, uint64_t *__restrict__ keys,
                  uint32_t *__restrict__ point_list, const uint4 *__restrict__ rect,
                  const uint32_t *__restrict__ pair_base, uint32_t *__restrict__ pair_pos,
-                 uint32_t *__restrict__ sort_parts, const uint2 *__restrict__ sort_items) {
+                 uint32_t *__restrict__ sort_parts, const uint2 *__restrict__ sort_items, const long long sst, const long long qst) {
+    ranges = l2d_view_ptr(ranges, sst); header = l2d_view_ptr(header, sst); tile_order = l2d_view_ptr(tile_order, sst);
+    point_list = l2d_view_ptr(point_list, sst); pair_base = l2d_view_ptr(pair_base, sst); pair_pos = l2d_view_ptr(pair_pos, sst);
+    keys = l2d_view_ptr(keys, qst); rect = l2d_view_ptr(rect, qst); sort_parts = l2d_view_ptr(sort_parts, qst);
+    sort_items = l2d_view_ptr(sort_items, qst);
     __shared__ uint64_t lds[L2D_SORT_LDS_KEYS];
     __shared__ uint32_t bkt[L2D_SORT_BUCKETS + 1], sh[16];
     __shared__ uint32_t s_min, s_max, s_mine, s_ticket, s_hist[L2D_SORT_PARTS];
@@ -676,27 +688,30 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
 
 }  // namespace
 
-int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s) {
+int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb) {
+    // vb != nullptr: the binning of ALL views of a multi-view call in three launches (blockIdx.z = view; st / sc are view 0's)
+    const unsigned nz = vb ? (unsigned)vb->n : 1u;
+    const long long sst = vb ? vb->state_stride : 0, qst = vb ? vb->scratch_stride : 0;
     {
         L2D_PROF("tile_scan", s);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(v.P > 0 ? 2 : 1), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(v.P > 0 ? 2 : 1, 1, nz), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
                            st.ranges, st.header, st.tile_order, sc.block_tot, st.seg_base, st.seg_cnt, st.bwd_order,
-                           st.bwd_items, sc.sort_parts, sc.sort_items);
+                           st.bwd_items, sc.sort_parts, sc.sort_items, sst, qst);
     }
     L2D_CHECK_LAUNCH();
     if (v.P == 0) return LARA2DGS_OK;
     {
         L2D_PROF("scatter", s);
         const int use_lds = v.tiles <= L2D_LDS_HIST_TILES;
-        hipLaunchKernelGGL(scatter_kernel, dim3((v.P + 255) / 256), dim3(256),
+        hipLaunchKernelGGL(scatter_kernel, dim3((v.P + 255) / 256, 1, nz), dim3(256),
                            use_lds ? (size_t)v.tiles * 4 : 0, s, v, sc.rect, sc.sub_start, sc.block_tot,
-                           st.pair_base, sc.tile_fill, sc.keys, use_lds);
+                           st.pair_base, sc.tile_fill, sc.keys, use_lds, sst, qst);
     }
     L2D_CHECK_LAUNCH();
     {
         L2D_PROF("tile_sort", s);
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(v.tiles * 2), dim3(512), 0, s, v, st.ranges, st.header, st.tile_order,
-                           sc.keys, st.point_list, sc.rect, st.pair_base, st.pair_pos, sc.sort_parts, sc.sort_items);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(v.tiles * 2, 1, nz), dim3(512), 0, s, v, st.ranges, st.header, st.tile_order,
+                           sc.keys, st.point_list, sc.rect, st.pair_base, st.pair_pos, sc.sort_parts, sc.sort_items, sst, qst);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -29,6 +29,22 @@ struct ViewDev {
     const float *bg, *viewmatrix, *projmatrix, *campos;
 };
 
+// A multi-view call carves the views' `state` / `scratch` buffers out of one allocation each at a constant stride, and all
+// views agree in every size: the binning and composite kernels of ALL views are then ONE launch each -- blockIdx.z = view, every
+// state / scratch / output pointer advanced by view * stride (0 and gridDim.z = 1 for a single view).  Only the background
+// colours are separate tensors per view.
+struct ViewBatch {
+    int n;                      // views of this launch (<= L2D_MAX_VIEWS)
+    long long state_stride, scratch_stride;   // bytes between consecutive views' buffers
+    const float *bg[L2D_MAX_VIEWS];
+};
+#ifdef __HIPCC__
+template <class T>
+__device__ __forceinline__ T *l2d_view_ptr(T *p, const long long stride_bytes) {
+    return (T *)((unsigned long long)p + (unsigned long long)((long long)blockIdx.z * stride_bytes));
+}
+#endif
+
 struct StateView {  // typed pointers into the caller's `state` buffer
     uint32_t *header;
     float4 *geom;         // [P][5] float4
@@ -125,11 +141,11 @@ int launch_preprocess_fwd_views(const ViewDev &v, int n, const ViewDev *views, c
                                 const float *colors_precomp, const float *opacities, const float *scales,
                                 const float *rotations, const float *transmat_precomp, const StateView *st,
                                 const ScratchView *sc, int32_t *const *radii, hipStream_t s);
-int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s);
+int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb = nullptr);
 int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
-                         hipStream_t s);
+                         hipStream_t s, const ViewBatch *vb = nullptr);
 int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const float *dL_dcolor,
-                         const float *dL_dallmap, hipStream_t s);
+                         const float *dL_dallmap, hipStream_t s, const ViewBatch *vb = nullptr);
 int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *shs,
                           const float *colors_precomp, const float *scales, const float *rotations,
                           const float *transmat_precomp, const int32_t *radii, StateView st,

@@ -306,7 +306,18 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
                      float *__restrict__ ckpt, uint2 *__restrict__ pair_mask,
-                     float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs) {
+                     float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs,
+                     const ViewBatch vb) {
+    {   // this workgroup's view (blockIdx.z; a single-view launch has strides 0)
+        const long long sst = vb.state_stride, HWb = (long long)v.H * v.W * 4;
+        header = l2d_view_ptr(header, sst); ranges = l2d_view_ptr(ranges, sst); point_list = l2d_view_ptr(point_list, sst);
+        geom = l2d_view_ptr(geom, sst); tile_order = l2d_view_ptr(tile_order, sst); cullbox = l2d_view_ptr(cullbox, sst);
+        final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
+        seg_cnt = l2d_view_ptr(seg_cnt, sst); ckpt = l2d_view_ptr(ckpt, sst); pair_mask = l2d_view_ptr(pair_mask, sst);
+        slabs = l2d_view_ptr(slabs, vb.scratch_stride);
+        out_color = l2d_view_ptr(out_color, vb.n ? 3 * HWb : 0); out_allmap = l2d_view_ptr(out_allmap, vb.n ? 7 * HWb : 0);
+        if (vb.n) v.bg = vb.bg[blockIdx.z];
+    }
     constexpr int CHUNK = FWD_CHUNK;
     static_assert(L2D_SEG % FWD_CHUNK == 0, "segment boundaries must fall on round boundaries");
     __shared__ float4 rec[REC4 * CHUNK];
@@ -517,7 +528,15 @@ composite_fwd_combine_kernel(ViewDev v, const uint32_t *__restrict__ header, con
                              const uint32_t *__restrict__ tile_order, float *__restrict__ final_T,
                              uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ seg_base,
                              const uint32_t *__restrict__ seg_cnt, float *__restrict__ ckpt, float *__restrict__ out_color,
-                             float *__restrict__ out_allmap, float *__restrict__ slabs) {
+                             float *__restrict__ out_allmap, float *__restrict__ slabs, const ViewBatch vb) {
+    {
+        const long long sst = vb.state_stride, HWb = (long long)v.H * v.W * 4;
+        header = l2d_view_ptr(header, sst); ranges = l2d_view_ptr(ranges, sst); tile_order = l2d_view_ptr(tile_order, sst);
+        final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
+        seg_cnt = l2d_view_ptr(seg_cnt, sst); ckpt = l2d_view_ptr(ckpt, sst); slabs = l2d_view_ptr(slabs, vb.scratch_stride);
+        out_color = l2d_view_ptr(out_color, vb.n ? 3 * HWb : 0); out_allmap = l2d_view_ptr(out_allmap, vb.n ? 7 * HWb : 0);
+        if (vb.n) v.bg = vb.bg[blockIdx.z];
+    }
     if (header[1]) return;
     const int tile = (int)tile_order[blockIdx.x];
     const uint2 range = ranges[tile];
@@ -641,7 +660,18 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint2 *__restrict__ pair_mask,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                      const uint32_t *__restrict__ pair_pos,
-                     float4 *__restrict__ pair_grad, uint8_t *__restrict__ pair_valid) {
+                     float4 *__restrict__ pair_grad, uint8_t *__restrict__ pair_valid, const ViewBatch vb) {
+    {
+        const long long sst = vb.state_stride, qst = vb.scratch_stride, HWb = (long long)v.H * v.W * 4;
+        header = l2d_view_ptr(header, sst); ranges = l2d_view_ptr(ranges, sst); point_list = l2d_view_ptr(point_list, sst);
+        geom = l2d_view_ptr(geom, sst); tile_order = l2d_view_ptr(tile_order, sst); cullbox = l2d_view_ptr(cullbox, sst);
+        final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
+        seg_cnt = l2d_view_ptr(seg_cnt, sst); bwd_order = l2d_view_ptr(bwd_order, sst); bwd_items = l2d_view_ptr(bwd_items, sst);
+        ckpt = l2d_view_ptr(ckpt, sst); pair_mask = l2d_view_ptr(pair_mask, sst); pair_pos = l2d_view_ptr(pair_pos, sst);
+        pair_grad = l2d_view_ptr(pair_grad, qst); pair_valid = l2d_view_ptr(pair_valid, qst);
+        dL_dcolor = l2d_view_ptr(dL_dcolor, vb.n ? 3 * HWb : 0); dL_dallmap = l2d_view_ptr(dL_dallmap, vb.n ? 7 * HWb : 0);
+        if (vb.n) v.bg = vb.bg[blockIdx.z];
+    }
     constexpr int WIN = SLAB_WIN;
     __shared__ float4 rec[REC4 * WIN];
     __shared__ __attribute__((aligned(16))) float pool[SLAB_POOL * SLAB_F];
@@ -1047,10 +1077,13 @@ selftest_butterfly_kernel(const float *__restrict__ in, float *__restrict__ out)
 }  // namespace
 
 int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
-                         hipStream_t s) {
+                         hipStream_t s, const ViewBatch *vbp) {
     float *slabs = (float *)sc.fwd_slabs;
+    ViewBatch vb{};
+    if (vbp) vb = *vbp;
+    const unsigned nz = vbp ? (unsigned)vb.n : 1u;    // blockIdx.z = view (st / sc / out_* are view 0's)
 #define FWD_ARGS v, st.header, st.ranges, st.point_list, (const float4 *)st.geom, st.tile_order, (const float4 *)st.cullbox, \
-                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, out_color, out_allmap, slabs
+                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, out_color, out_allmap, slabs, vb
     {
         // Depth-segment split of the long lists: OPT-IN (lara2dgs_set_forward_split / LARA2DGS_FWD_SPLIT=1), off by default
         // because it measured SLOWER: at LaRa's init statistics the four launches take 123 (prepass) + 142 (segment walks) + 14
@@ -1062,12 +1095,12 @@ int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *
         L2D_PROF("composite_fwd", s);
         if (v.dbg & 128u) {
             // long lists first (workgroups of short lists and of segments beyond a list's end return on their first loads)
-            hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(v.tiles, 8), dim3(256), 0, s, FWD_ARGS);
-            hipLaunchKernelGGL(composite_fwd_kernel<2>, dim3(v.tiles, 8), dim3(256), 0, s, FWD_ARGS);
-            hipLaunchKernelGGL(composite_fwd_combine_kernel, dim3(v.tiles), dim3(256), 0, s, v, st.header, st.ranges, st.tile_order,
-                               st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, out_color, out_allmap, slabs);
+            hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(v.tiles, 8, nz), dim3(256), 0, s, FWD_ARGS);
+            hipLaunchKernelGGL(composite_fwd_kernel<2>, dim3(v.tiles, 8, nz), dim3(256), 0, s, FWD_ARGS);
+            hipLaunchKernelGGL(composite_fwd_combine_kernel, dim3(v.tiles, 1, nz), dim3(256), 0, s, v, st.header, st.ranges, st.tile_order,
+                               st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, out_color, out_allmap, slabs, vb);
         }
-        hipLaunchKernelGGL(composite_fwd_kernel<0>, dim3(v.tiles), dim3(256), 0, s, FWD_ARGS);
+        hipLaunchKernelGGL(composite_fwd_kernel<0>, dim3(v.tiles, 1, nz), dim3(256), 0, s, FWD_ARGS);
     }
 #undef FWD_ARGS
     L2D_CHECK_LAUNCH();
@@ -1075,17 +1108,19 @@ int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *
 }
 
 int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const float *dL_dcolor,
-                         const float *dL_dallmap, hipStream_t s) {
+                         const float *dL_dallmap, hipStream_t s, const ViewBatch *vbp) {
+    ViewBatch vb{};
+    if (vbp) vb = *vbp;
     {
         L2D_PROF("composite_bwd", s);
         // one workgroup per (tile, segment); the count lives on the device (header[3]), so launch
         // the upper bound -- surplus workgroups exit on their first instruction
         const unsigned grid = (unsigned)v.tiles + v.cap / L2D_SEG;
-        hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid), dim3(256), 0, s, v, st.header, st.ranges,
+        hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid, 1, vbp ? (unsigned)vb.n : 1u), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
                            (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.bwd_order,
                            st.bwd_items, st.ckpt, st.pair_mask, dL_dcolor, dL_dallmap, st.pair_pos, sc.pair_grad,
-                           (uint8_t *)sc.pair_valid);
+                           (uint8_t *)sc.pair_valid, vb);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -261,13 +261,21 @@ def _fold_fine_weights(decoder):
     return Wqk, W1 @ Wov, b1, W2, b2
 
 
-def forward_fine(decoder, volume_feat, point_feats):
+def fold_fine_weights(decoder):
+    """The folded matrices `forward_fine` runs on (include/lara_finedec.h), formed with autograd from the decoder's
+    parameters.  A caller that runs several scenes with the same parameters (a training step: network.py:473-525) folds once
+    and passes the result as `folded=`: the ~12 small products of the fold, and their backward, run once per step instead
+    of once per scene (the scenes' gradients accumulate on the folded tensors first)."""
+    return _fold_fine_weights(decoder)
+
+
+def forward_fine(decoder, volume_feat, point_feats, folded=None):
     """Same arguments and return value as ``Decoder.forward_fine`` (network.py:280-284): volume_feat [n,80],
     point_feats [n,4,8] (the reference passes the sampler's [4,8,n] output through `einsum('lcb->blc')`, a view --
-    its storage is used as it is) -> sh [n,1,12] fp32."""
+    its storage is used as it is) -> sh [n,1,12] fp32.  `folded`: the result of `fold_fine_weights(decoder)`."""
     if point_feats.dim() != 3 or point_feats.shape[1:] != (_NV, _CD) or volume_feat.shape[-1] != _FD:
         raise RuntimeError("expected volume_feat [n,80] and point_feats [n,4,8]")
     xn = _FineLayerNorm.apply(volume_feat.float(), decoder.norm.weight, decoder.norm.bias, decoder.norm.eps)
     pf = point_feats.float().permute(1, 2, 0)      # [4,8,n]; contiguous() is a no-op on the sampler's own layout
-    sh = _FineDecoder.apply(xn, pf, *_fold_fine_weights(decoder))
+    sh = _FineDecoder.apply(xn, pf, *(_fold_fine_weights(decoder) if folded is None else folded))
     return sh.unsqueeze(1)

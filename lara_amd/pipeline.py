@@ -36,7 +36,7 @@ import torch
 from torch import nn
 
 from . import cameras
-from .fine import _tn_over_points, forward_fine, sample_point_feats, take_rows
+from .fine import _tn_over_points, fold_fine_weights, forward_fine, sample_point_feats, take_rows
 from .renderer import Renderer
 
 
@@ -255,6 +255,10 @@ class LaRaPipeline(nn.Module):
             # the sizes of the masked subsets: host reads on the stream that holds only the encoder + decoder + masks
             # (every scene's coarse views are already enqueued on the side streams)
             idx = [masks[i].nonzero().squeeze(-1) for i in range(B)]
+            folded = fold_fine_weights(self.decoder)      # once per step, shared by the scenes (on the caller's stream)
+            for s in sides:
+                if s is not None:
+                    s.wait_stream(cur)
             for i in range(B):                                                  # network.py:502-525
                 s = sides[i % len(sides)]
                 with on(s):
@@ -267,7 +271,7 @@ class LaRaPipeline(nn.Module):
                     pf = sample_point_feats(centers_f, batch["tar_w2c"][i, :n_sel], batch["tar_ixt"][i, :n_sel], inps[i],
                                             sel(co["image"]), sel(co["acc_map"]).squeeze(-1), sel(co["depth"]))
                     vox = torch.div(idx[i], self.K, rounding_mode="floor")
-                    sh_res = forward_fine(self.decoder, _TakeVoxelRows.apply(sc["vol"][i], vox), torch.einsum("lcb->blc", pf))
+                    sh_res = forward_fine(self.decoder, _TakeVoxelRows.apply(sc["vol"][i], vox), torch.einsum("lcb->blc", pf), folded)
                     shs_f = sh_res.view(-1, *g["shs"].shape[-2:]) + take_rows(sc["shs"][i], idx[i])
                     self._mark("sampler+forward_fine")
                     co.update(self.gs_render.render_views(

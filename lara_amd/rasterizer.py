@@ -92,6 +92,8 @@ def load_library():
     lib.lara2dgs_set_view_lanes.argtypes = [i32]
     lib.lara2dgs_set_forward_split.restype = ctypes.c_int
     lib.lara2dgs_set_forward_split.argtypes = [i32]
+    lib.lara2dgs_set_views_batch_kernels.restype = ctypes.c_int
+    lib.lara2dgs_set_views_batch_kernels.argtypes = [i32]
     lib.lara2dgs_get_grad_layout.restype = ctypes.c_int
     lib.lara2dgs_get_grad_layout.argtypes = [i32, i32, i32, i32, i32, i32, ctypes.POINTER(GradLayout)]
     lib.lara2dgs_mark_visible.restype = ctypes.c_int
@@ -419,6 +421,12 @@ def set_forward_split(on: bool) -> bool:
     """Opt-in: composite tile lists beyond 2048 entries as depth segments on several workgroups (include/lara2dgs.h:
     lara2dgs_set_forward_split; off by default -- measured slower at LaRa's statistics).  Returns the previous setting."""
     return bool(load_library().lara2dgs_set_forward_split(int(bool(on))))
+
+
+def set_views_batch_kernels(on: bool) -> bool:
+    """Multi-view calls: binning + composite of all views as ONE launch per kernel (default on) or per view on the lanes
+    (include/lara2dgs.h: lara2dgs_set_views_batch_kernels).  Same results bit for bit.  Returns the previous setting."""
+    return bool(load_library().lara2dgs_set_views_batch_kernels(int(bool(on))))
 
 
 def _view_lanes() -> int:

@@ -129,7 +129,8 @@ def test_views_with_precomputed_colour_and_transmat(monkeypatch, batched):
 
 
 def test_views_repeatable_and_independent_of_stream_count(monkeypatch):
-    """Same bits run to run, and whether the library spreads the views over 1 or 4 side streams."""
+    """Same bits run to run, whether the library spreads the views over 1 or 4 side streams, and whether the views'
+    binning / compositing kernels run as one launch each (grid z = view) or one launch per view."""
     from lara_amd import rasterize_gaussians_views
     act, cams = small_scene(grid=12, size=96, n_views=6, seed=4)
     settings = [raster_settings(c, [1.0, 1.0, 1.0], device=DEV) for c in cams]
@@ -155,10 +156,17 @@ def test_views_repeatable_and_independent_of_stream_count(monkeypatch):
     c5, g5 = run()
     monkeypatch.delenv("LARA2DGS_VIEWS_BATCH_PREPROCESS")
     c6, g6 = run()                                      # four lanes, batched preprocess
-    for c in (c1, c2, c3, c4, c5, c6):
+    from lara_amd import rasterizer
+    rasterizer.set_views_batch_kernels(False)           # binning + compositing one launch per view on the lanes (round 2's
+    try:                                                # path) instead of one launch per kernel with blockIdx.z = view
+        c7, g7 = run()
+    finally:
+        rasterizer.set_views_batch_kernels(True)
+    c8, g8 = run()
+    for c in (c1, c2, c3, c4, c5, c6, c7, c8):
         assert torch.equal(c0, c)
     for k in g0:
-        for g in (g1, g2, g3, g4, g5, g6):
+        for g in (g1, g2, g3, g4, g5, g6, g7, g8):
             assert torch.equal(g0[k], g[k]), k
 
 
