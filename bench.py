@@ -36,7 +36,7 @@ issued lane-slots), "cpu_baseline" (the CPU oracle of the raster AND the fixture
 reference's encoder, both on this box's host cores; `parity_vs_oracle` with the committed fp64 arbitration),
 "independent_tensors_step", "raster_only", "single_stream", "forward_only", "mesh_eval" (configs[4]: 48 views @1024x1024 +
 block-sparse TSDF fusion + marching cubes), "attention", "encoder", "encoder_train", "rays", "render_img", "point_feats",
-"fine_decoder", "fine_stage".
+"coarse_decoder", "fine_decoder", "fine_stage".
 """
 import argparse
 import contextlib
@@ -682,6 +682,56 @@ def point_feats_leg(device, args):
         res[fused] = e0.elapsed_time(e1) / 5 * 1e3
     return {"workload": f"get_point_feats fwd+bwd, {n} points x {V} views @{h}x{w} (incl. cloning the inputs)", "unit": "us",
             "torch_sequence_us": round(res[False], 1), "fused_us": round(res[True], 1)}
+
+
+def coarse_decoder_leg(device, scenes):
+    """`Decoder.forward_coarse` (network.py:259-278) on the batch's scenes x 64^3 voxel rows, forward + backward with gradients
+    to the volume features and the six parameters: the torch sequence under bf16 autocast arithmetic (`pipeline.decode_coarse`:
+    three bf16 GEMMs with chip-filling weight gradients, split, activations) and the fused HIP kernels (`lara_amd.coarse`)."""
+    from lara_amd import coarse, rasterizer
+    from lara_amd.pipeline import CoarseFineDecoder, decode_coarse
+    torch.manual_seed(0)
+    dec = CoarseFineDecoder().to(device)
+    M = 64 ** 3
+    x0 = torch.randn(scenes, M, 80, device=device)
+    gouts = None
+
+    def one(mode):
+        nonlocal gouts
+        x = x0.clone().requires_grad_(True)
+        res = coarse.forward_coarse(dec, x, -2.1792, -5.26) if mode == "fused" else decode_coarse(dec, x, -2.1792, -5.26, True)
+        if gouts is None:
+            gouts = [torch.randn_like(r) for r in res]
+        torch.autograd.backward(res, gouts)
+        for p in dec.parameters():
+            p.grad = None
+
+    res = {}
+    for mode in ("torch", "fused"):
+        one(mode)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            one(mode)
+        e1.record()
+        torch.cuda.synchronize()
+        res[mode] = e0.elapsed_time(e1) / 3 * 1e3
+    rasterizer.profile_enable(True)
+    one("fused")
+    torch.cuda.synchronize()
+    k = {name: round(ms * 1e3, 1) for name, ms in rasterizer.profile_collect()}
+    rasterizer.profile_enable(False)
+    rows = scenes * M
+    fwd_bytes, bwd_bytes = rows * (320 + 88 * 2), rows * (320 + 88 * 2 + 12 * 2 + 320 + 896)
+    out = {"workload": f"Decoder.forward_coarse fwd+bwd, {rows} voxel rows ({scenes} scenes), K = 2, gradients to the features and "
+                       "the parameters (incl. cloning the input)", "unit": "us", "torch_sequence_bf16_us": round(res["torch"], 1),
+           "fused_us": round(res["fused"], 1), "kernels_us": k, "bound": "hbm"}
+    if "coarse_decoder_fwd" in k:
+        out["fwd_GBs"] = round(fwd_bytes / (k["coarse_decoder_fwd"] * 1e-6) / 1e9, 1)
+    if "coarse_decoder_bwd" in k:
+        out["bwd_GBs"] = round(bwd_bytes / (k["coarse_decoder_bwd"] * 1e-6) / 1e9, 1)
+    return out
 
 
 def fine_decoder_leg(device):
@@ -1485,6 +1535,7 @@ def main():
         out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
         out["render_img"] = render_img_leg(device, args)
         out["point_feats"] = point_feats_leg(device, args)
+        out["coarse_decoder"] = coarse_decoder_leg(device, args.scenes)
         out["fine_decoder"] = fine_decoder_leg(device)
         out["fine_stage"] = fine_stage_leg(device, args)
     if solo and not args.no_cpu_baseline:

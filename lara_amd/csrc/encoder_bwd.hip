@@ -345,6 +345,30 @@ accum_partials4_kernel(float *__restrict__ dst, const float *__restrict__ part, 
     }
 }
 
+// few elements, hundreds of parts (the coarse decoder's 80 x 80 weight gradients: 25 workgroups of the kernel above would
+// each walk 1024 parts, 256 dependent loads per thread): 16 slices of the parts per workgroup instead of 4
+__global__ void __launch_bounds__(1024)
+accum_partials4_wide_kernel(float *__restrict__ dst, const float *__restrict__ part, const int n, const int parts,
+                            const size_t stride) {
+    __shared__ float4 red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n)
+        for (int q = sl; q < parts; q += 16) {
+            const float4 v = *(const float4 *)(part + (size_t)q * stride + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && c < n) {
+        float4 d = *(float4 *)(dst + c);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const float4 v = red[k][lane]; d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w; }
+        *(float4 *)(dst + c) = d;
+    }
+}
+
 // the three column sums of ln_bwd_kernel's partials in one launch: blockIdx.y = quantity (its dst may be null)
 __global__ void __launch_bounds__(1024)
 accum_ln_partials_kernel(float *d0, float *d1, float *d2, const float *__restrict__ part, const int parts) {
@@ -638,7 +662,9 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
         else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
     }
     const int n = N * T * Kc;
-    if ((n & 3) == 0 && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0)
+    if ((n & 3) == 0 && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0 && (n / 4 + 63) / 64 < 128 && splits >= 64)
+        hipLaunchKernelGGL(accum_partials4_wide_kernel, dim3((n / 4 + 63) / 64), dim3(1024), 0, s, dst, part, n, splits, (size_t)n);
+    else if ((n & 3) == 0 && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0)
         hipLaunchKernelGGL(accum_partials4_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
     else
         hipLaunchKernelGGL(accum_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);

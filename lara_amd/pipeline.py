@@ -35,7 +35,7 @@ import math
 import torch
 from torch import nn
 
-from . import cameras
+from . import cameras, coarse
 from .fine import _tn_over_points, fold_fine_weights, forward_fine, sample_point_feats, take_rows
 from .renderer import Renderer
 
@@ -167,6 +167,7 @@ class LaRaPipeline(nn.Module):
         self.register_buffer("group_centers", (grid * scene_size).reshape(1, -1, 3).float())
         self.n_streams = n_streams
         self._streams = []
+        self.fused_coarse = True          # False: `decode_coarse` (torch operators) instead of lara_amd.coarse
         self.fine_mask = "reference"      # "reference": _check_mask as the reference applies it; "plain": opacity > 0.005 only
         self.stage_events = None          # set to a list to collect (stage, start event, end event) per call
 
@@ -176,7 +177,11 @@ class LaRaPipeline(nn.Module):
         return self.gaussians_from_volume(self.vol_decoder(feat_vol))
 
     def gaussians_from_volume(self, vol, autocast=True):
-        offset, shs, scaling, rotation, opacity = decode_coarse(self.decoder, vol, self.opacity_shift, self.scaling_shift, autocast)
+        if autocast and self.fused_coarse and vol.is_cuda and coarse.supported(self.decoder):
+            # the three bf16 Linear layers, the split and its activations as one HIP kernel per direction (lara_coarsedec.h)
+            offset, shs, scaling, rotation, opacity = coarse.forward_coarse(self.decoder, vol, self.opacity_shift, self.scaling_shift)
+        else:
+            offset, shs, scaling, rotation, opacity = decode_coarse(self.decoder, vol, self.opacity_shift, self.scaling_shift, autocast)
         half_cell = 0.5 * self.scene_size / self.n_offset_groups                # network.py:425-429
         B = offset.shape[0]
         centers = self.group_centers.unsqueeze(-2).expand(B, -1, self.K, -1).reshape(offset.shape) + offset * half_cell

@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for hdr in ("lara2dgs.h", "lara_groupattn.h", "lara_rays.h", "lara_surface.h", "lara_pointfeat.h"):
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):        # every header of the C ABI
+        if not hdr.endswith(".h"):
+            continue
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(lara2dgs_[a-z0-9_]+|lara_[a-z0-9_]+)\s*\(", text))

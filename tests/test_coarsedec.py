@@ -1,0 +1,150 @@
+"""`Decoder.forward_coarse` (lightning/network.py:259-278): the oracle against the reference's own output and autograd
+gradients in fp32 and under CPU bf16 autocast (tests/golden/coarsedec_ref.npz, generated from the imported reference class
+by tests/golden/make_coarsedec_fixture.py), and the fused HIP path against both.
+
+Tolerances.  fp32 oracle vs fp32 reference: 1e-5 of max|ref|.  The bf16 arithmetic rounds every layer's result to 8
+significant bits: two implementations that add the 80 products of a row in a different order land on neighbouring bf16
+values now and then, and a flipped value moves everything downstream of it by up to 2^-8 of its size -- bar: 2e-2 of
+max|ref| for outputs and input gradients (observed ~4e-3), 2e-2 for the parameter gradients (sums over all rows: the
+flips average out, observed ~2e-3), and >= 97 % of the last layer's raw values equal bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coarsedec_ref
+
+FX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coarsedec_ref.npz")
+NAMES = ["offset", "sh", "scaling", "rotation", "opacity"]
+PARAMS = ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
+
+
+def _close(got, want, rel, what):
+    got, want = np.asarray(got, np.float64).reshape(np.asarray(want).shape), np.asarray(want, np.float64)
+    err = np.abs(got - want).max()
+    assert err <= rel * max(np.abs(want).max(), 1e-12), f"{what}: max err {err:.3e} vs max |ref| {np.abs(want).max():.3e}"
+
+
+def _close_l2(got, want, rel, what):
+    """Against the fp32 reference: a hidden unit whose pre-activation rounds across zero in bf16 switches its whole
+    gradient path on or off -- single entries differ by O(1), the tensors agree in the mean."""
+    got, want = np.asarray(got, np.float64).reshape(np.asarray(want).shape), np.asarray(want, np.float64)
+    err = np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-12)
+    assert err <= rel, f"{what}: relative L2 error {err:.3e}"
+
+
+def _params(fx, device="cpu", grad=True):
+    return [torch.from_numpy(fx["p." + k]).to(device).requires_grad_(grad) for k in PARAMS]
+
+
+@pytest.mark.parametrize("tag,rel_out,rel_grad", [("fp32", 1e-5, 1e-4), ("bf16", 2e-2, 2e-2)])
+def test_oracle_matches_the_reference_fixture(tag, rel_out, rel_grad):
+    fx = np.load(FX)
+    x = torch.from_numpy(fx["feats"]).reshape(-1, 80).requires_grad_(True)
+    ps = _params(fx)
+    res = coarsedec_ref.forward_coarse(x, *ps, 2, 12, float(fx["opacity_shift"]), float(fx["scaling_shift"]), bf16=tag == "bf16")
+    sum((r * torch.from_numpy(fx["gout." + n]).reshape(r.shape)).sum() for r, n in zip(res, NAMES)).backward()
+    for r, n in zip(res, NAMES):
+        _close(r.detach().numpy(), fx[f"{tag}.{n}"], rel_out, f"{tag} {n}")
+    _close(x.grad.numpy(), fx[f"{tag}.d_feats"], rel_grad, f"{tag} d_feats")
+    for p, k in zip(ps, PARAMS):
+        _close(p.grad.numpy(), fx[f"{tag}.g.{k}"], rel_grad, f"{tag} grad {k}")
+    if tag == "bf16":      # the raw last-layer values (sh, rotation: no activation) are the same bf16 numbers almost everywhere
+        same = np.mean(res[1].detach().numpy().reshape(-1) == fx["bf16.sh"].reshape(-1))
+        assert same >= 0.97, same
+
+
+def test_supported_sizes():
+    from lara_amd import coarse
+    from lara_amd.pipeline import CoarseFineDecoder
+    assert coarse.supported(CoarseFineDecoder())
+    assert coarse.supported(CoarseFineDecoder(K=1))
+    assert not coarse.supported(CoarseFineDecoder(K=3))                 # 66 outputs
+    assert not coarse.supported(CoarseFineDecoder(sh_dim=27, K=2))      # 74 outputs
+    with pytest.raises(RuntimeError):
+        coarse.forward_coarse(CoarseFineDecoder(K=3), torch.zeros(1, 4, 80), 0.0, 0.0)
+
+
+def _decoder(fx, K=2, sh_dim=12, device="cuda:0"):
+    from lara_amd.pipeline import CoarseFineDecoder
+    dec = CoarseFineDecoder(K=K, sh_dim=sh_dim)
+    with torch.no_grad():
+        if fx is not None:
+            for k, p in dec.mlp_coarse.named_parameters():
+                p.copy_(torch.from_numpy(fx["p." + k]))
+        else:
+            for i in (0, 2, 4):
+                dec.mlp_coarse[i].bias.add_(torch.randn_like(dec.mlp_coarse[i].bias) * 0.3)
+    return dec.to(device)
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_reference_fixture(hip_lib):
+    from lara_amd import coarse
+    fx = np.load(FX)
+    dec = _decoder(fx)
+    x = torch.from_numpy(fx["feats"]).cuda().requires_grad_(True)
+    res = coarse.forward_coarse(dec, x, float(fx["opacity_shift"]), float(fx["scaling_shift"]))
+    sum((r * torch.from_numpy(fx["gout." + n]).cuda()).sum() for r, n in zip(res, NAMES)).backward()
+    torch.cuda.synchronize()
+    for r, n in zip(res, NAMES):
+        assert r.shape == fx["bf16." + n].shape
+        _close(r.detach().cpu().numpy(), fx["bf16." + n], 2e-2, "bf16 " + n)
+        _close(r.detach().cpu().numpy(), fx["fp32." + n], 3e-2, "fp32 " + n)
+    same = np.mean(res[1].detach().cpu().numpy().reshape(-1) == fx["bf16.sh"].reshape(-1))
+    assert same >= 0.97, same
+    _close(x.grad.cpu().numpy(), fx["bf16.d_feats"], 2e-2, "d_feats")
+    # the reference's own bf16 run sits 6e-2 (relative L2) from its fp32 run on these gradients: the HIP path may not sit further
+    ref_gap = lambda a, b: float(np.sqrt(((fx[a] - fx[b]) ** 2).sum()) / np.sqrt((fx[b] ** 2).sum()))
+    _close_l2(x.grad.cpu().numpy(), fx["fp32.d_feats"], 1.2 * ref_gap("bf16.d_feats", "fp32.d_feats") + 1e-3, "d_feats vs fp32")
+    for (k, p) in dec.mlp_coarse.named_parameters():
+        _close(p.grad.cpu().numpy(), fx["bf16.g." + k], 2e-2, "grad " + k)
+        _close_l2(p.grad.cpu().numpy(), fx["fp32.g." + k], 1.2 * ref_gap("bf16.g." + k, "fp32.g." + k) + 1e-3, "grad vs fp32 " + k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,sh_dim", [(1, 2, 12), (127, 2, 12), (128, 1, 12), (4097, 2, 3), (1000, 1, 27), (70000, 2, 12)])
+def test_hip_matches_the_oracle_on_other_sizes(hip_lib, M, K, sh_dim):
+    """Ragged row counts (the kernel works in trips of 128 rows, 32 per wave), other K / SH sizes, some gradients absent."""
+    from lara_amd import coarse
+    torch.manual_seed(M + K)
+    dec = _decoder(None, K, sh_dim)
+    x = (torch.randn(1, M, 80) * 1.1).cuda().requires_grad_(True)
+    res = coarse.forward_coarse(dec, x, -2.0, -5.0)
+    gouts = [torch.randn_like(r) for r in res]
+    use = [True, sh_dim != 3, True, M != 127, True]                       # leave some outputs without a gradient
+    sum((r * g).sum() for r, g, u in zip(res, gouts, use) if u).backward()
+    xc = x.detach().cpu().reshape(-1, 80).requires_grad_(True)
+    ps = [p.detach().cpu().clone().requires_grad_(True) for p in dec.mlp_coarse.parameters()]
+    want = coarsedec_ref.forward_coarse(xc, *ps, K, sh_dim, -2.0, -5.0)
+    sum((r * g.cpu().reshape(r.shape)).sum() for r, g, u in zip(want, gouts, use) if u).backward()
+    torch.cuda.synchronize()
+    for r, w, n in zip(res, want, NAMES):
+        if w.numel():
+            _close(r.detach().cpu().numpy(), w.detach().numpy(), 2e-2, n)
+    _close(x.grad.cpu().numpy(), xc.grad.numpy(), 2e-2, "dx")
+    for p, q in zip(dec.mlp_coarse.parameters(), ps):
+        _close(p.grad.cpu().numpy(), q.grad.numpy(), 2e-2 if M > 200 else 6e-2, "param grad")
+
+
+@pytest.mark.gpu
+def test_hip_is_repeatable_and_empty_input_is_fine(hip_lib):
+    from lara_amd import coarse
+    fx = np.load(FX)
+    dec = _decoder(fx)
+
+    def run(x):
+        for p in dec.parameters():
+            p.grad = None
+        x = x.clone().requires_grad_(True)
+        res = coarse.forward_coarse(dec, x, -2.0, -5.0)
+        sum(r.sum() * (i + 1) for i, r in enumerate(res)).backward()
+        torch.cuda.synchronize()
+        return [r.detach().clone() for r in res], x.grad.clone(), [p.grad.clone() for p in dec.mlp_coarse.parameters()]
+    x = torch.randn(1, 40000, 80, device="cuda:0")
+    a, b = run(x), run(x)
+    for u, v in zip(a[0] + [a[1]] + a[2], b[0] + [b[1]] + b[2]):
+        assert torch.equal(u, v)                                          # no floating-point atomics anywhere
+    res, dx, gp = run(torch.zeros(1, 0, 80, device="cuda:0"))
+    assert all(r.shape[1] == 0 for r in res) and dx.numel() == 0 and all(float(g.abs().max()) == 0.0 for g in gp)
