@@ -42,6 +42,20 @@ int lara_point_feats_backward(int32_t n, int32_t V, int32_t h, int32_t w, const 
                               const float *depth, const float *g_out, float *d_points, float *d_image,
                               float *d_acc_map, float *d_depth, void *workspace, void *stream);
 
+/* The same with the three render-derived maps in the SIDE-BY-SIDE layout of the multi-view renderer
+ * (`lara_surface_maps_forward_views`: image [h, row_views*w, 3], acc_map [h, row_views*w], depth [h, row_views*w, 1] --
+ * what network.py:527 builds with torch.cat(dim=1)); the sampler reads views 0 .. V-1 of the `row_views` in a row
+ * (network.py:499: the first n_views_sel).  No slicing / stacking copy in front, and the backward accumulates straight
+ * into gradient maps of the full side-by-side shape (views >= V receive nothing).  row_views = 0: the [V,h,w,c] layout. */
+int lara_point_feats_forward_concat(int32_t n, int32_t V, int32_t row_views, int32_t h, int32_t w, const float *points,
+                                    const float *w2cs, const float *ixts, const float *img_ref, const float *image,
+                                    const float *acc_map, const float *depth, float *out, void *workspace, void *stream);
+
+int lara_point_feats_backward_concat(int32_t n, int32_t V, int32_t row_views, int32_t h, int32_t w, const float *points,
+                                     const float *w2cs, const float *ixts, const float *img_ref, const float *image,
+                                     const float *acc_map, const float *depth, const float *g_out, float *d_points,
+                                     float *d_image, float *d_acc_map, float *d_depth, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,23 @@ def make_cameras(c2w: torch.Tensor, width: int, height: int, fovx: float, fovy: 
                    wvt[i], PT, full[i], centers[i]) for i in range(c2w.shape[0])]
 
 
+def make_cameras_scenes(c2w: torch.Tensor, sizes, scalars, device=None) -> list:
+    """``make_cameras`` for every scene of a batch in ONE pass of batched linear algebra (one inverse, one product, one
+    padded copy for all B x V cameras instead of one set per scene: LaRa's loop builds them scene by scene,
+    network.py:476-492).  ``c2w``: [B,V,4,4]; ``sizes``: per scene (width, height); ``scalars``: per scene
+    (znear, zfar, fovx, fovy) as Python floats.  Returns a list (scene) of lists (view) of `Camera`."""
+    c2w = torch.as_tensor(c2w, dtype=torch.float32)
+    B, V = c2w.shape[:2]
+    device = device if device is not None else c2w.device
+    w2c = torch.linalg.inv_ex(c2w.reshape(B * V, 4, 4).double())[0].float()
+    wvt = w2c.transpose(1, 2).contiguous().to(device).view(B, V, 4, 4)
+    PT = torch.stack([projection_matrix(near, far, fx, fy).t() for near, far, fx, fy in scalars]).contiguous().to(device)
+    full = torch.matmul(wvt, PT[:, None]).float().contiguous()
+    centers = torch.nn.functional.pad(-c2w[..., :3, 3], (0, 1)).contiguous().to(device)[..., :3]
+    return [[Camera(int(sizes[b][0]), int(sizes[b][1]), float(scalars[b][2]), float(scalars[b][3]), float(scalars[b][0]),
+                    float(scalars[b][1]), wvt[b, i], PT[b], full[b, i], centers[b, i]) for i in range(V)] for b in range(B)]
+
+
 def turntable_c2w(n_views: int, elevation_deg: float = 0.0) -> torch.Tensor:
     """Canonical gobjaverse pose rotated about +z in steps of 2*pi/n (tools/gen_video_path.py:23-37).
 

@@ -13,7 +13,15 @@ constexpr int PF_MAX_VIEWS = 8;
 struct PfP {
     int n, V, h, w;
     const float *points, *w2cs, *ixts, *img_ref, *image, *acc, *depth;
+    int vtot;   // 0: image / acc / depth are [V,h,w,c]; > 0: [h, vtot*w, c], the views side by side (`render_views(concat=True)`)
 };
+
+// pixel i = (v, y, x) of the packed stack -> its pixel index in the render-derived maps
+__device__ __forceinline__ size_t map_pixel(const PfP &p, const size_t i) {
+    if (p.vtot == 0) return i;
+    const size_t hw = (size_t)p.h * p.w, v = i / hw, pix = i - v * hw, y = pix / p.w, x = pix - y * p.w;
+    return (y * p.vtot + v) * p.w + x;
+}
 
 struct Tap {  // the four bilinear taps of a sample position; weight 0 and a safe index outside the image
     int idx[4];
@@ -46,21 +54,22 @@ __global__ void __launch_bounds__(256)
 pack_stack_kernel(const PfP p, float4 *__restrict__ packed) {
     const size_t hw = (size_t)p.h * p.w, i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)p.V * hw) return;
-    const size_t v = i / hw, pix = i - v * hw;
-    const float *im = p.image + i * 3;
+    const size_t v = i / hw, pix = i - v * hw, m = map_pixel(p, i);
+    const float *im = p.image + m * 3;
     packed[2 * i] = make_float4(p.img_ref[(v * 3 + 0) * hw + pix], p.img_ref[(v * 3 + 1) * hw + pix],
                                 p.img_ref[(v * 3 + 2) * hw + pix], im[0]);
-    packed[2 * i + 1] = make_float4(im[1], im[2], p.acc[i], p.depth[i]);
+    packed[2 * i + 1] = make_float4(im[1], im[2], p.acc[m], p.depth[m]);
 }
 
 __global__ void __launch_bounds__(256)
-unpack_grad_kernel(const float4 *__restrict__ dpacked, const size_t n, float *d_image, float *d_acc, float *d_depth) {
+unpack_grad_kernel(const PfP p, const float4 *__restrict__ dpacked, const size_t n, float *d_image, float *d_acc, float *d_depth) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float4 a = dpacked[2 * i], b = dpacked[2 * i + 1];
-    if (d_image) { d_image[3 * i] += a.w; d_image[3 * i + 1] += b.x; d_image[3 * i + 2] += b.y; }
-    if (d_acc) d_acc[i] += b.z;
-    if (d_depth) d_depth[i] += b.w;
+    const size_t m = map_pixel(p, i);
+    if (d_image) { d_image[3 * m] += a.w; d_image[3 * m + 1] += b.x; d_image[3 * m + 2] += b.y; }
+    if (d_acc) d_acc[m] += b.z;
+    if (d_depth) d_depth[m] += b.w;
 }
 
 // the 8 channels of view v at pixel index `pix`
@@ -222,11 +231,18 @@ int64_t lara_point_feats_workspace_bytes(int32_t V, int32_t h, int32_t w) {
 int lara_point_feats_forward(int32_t n, int32_t V, int32_t h, int32_t w, const float *points, const float *w2cs,
                              const float *ixts, const float *img_ref, const float *image, const float *acc_map,
                              const float *depth, float *out, void *workspace, void *stream) {
+    return lara_point_feats_forward_concat(n, V, 0, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth, out, workspace, stream);
+}
+
+int lara_point_feats_forward_concat(int32_t n, int32_t V, int32_t row_views, int32_t h, int32_t w, const float *points,
+                                    const float *w2cs, const float *ixts, const float *img_ref, const float *image,
+                                    const float *acc_map, const float *depth, float *out, void *workspace, void *stream) {
+    if (row_views < 0 || (row_views > 0 && row_views < V)) return LARA2DGS_E_INVALID;
     if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)V * h * w * 8 >= (1ll << 31)) return LARA2DGS_E_INVALID;  // 32-bit offsets into the stack
     if (n == 0) return LARA2DGS_OK;
     if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !out || !workspace) return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const PfP p{n, V, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth};
+    const PfP p{n, V, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth, row_views};
     float4 *packed = (float4 *)workspace;
     {
         L2D_PROF("point_feats_pack", s);
@@ -247,12 +263,21 @@ int lara_point_feats_backward(int32_t n, int32_t V, int32_t h, int32_t w, const 
                               const float *ixts, const float *img_ref, const float *image, const float *acc_map,
                               const float *depth, const float *g_out, float *d_points, float *d_image,
                               float *d_acc_map, float *d_depth, void *workspace, void *stream) {
+    return lara_point_feats_backward_concat(n, V, 0, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth, g_out, d_points,
+                                            d_image, d_acc_map, d_depth, workspace, stream);
+}
+
+int lara_point_feats_backward_concat(int32_t n, int32_t V, int32_t row_views, int32_t h, int32_t w, const float *points,
+                                     const float *w2cs, const float *ixts, const float *img_ref, const float *image,
+                                     const float *acc_map, const float *depth, const float *g_out, float *d_points,
+                                     float *d_image, float *d_acc_map, float *d_depth, void *workspace, void *stream) {
+    if (row_views < 0 || (row_views > 0 && row_views < V)) return LARA2DGS_E_INVALID;
     if (n < 0 || V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)V * h * w * 8 >= (1ll << 31)) return LARA2DGS_E_INVALID;  // 32-bit offsets into the stack
     if (n == 0) return LARA2DGS_OK;
     if (!points || !w2cs || !ixts || !img_ref || !image || !acc_map || !depth || !g_out || !d_points || !workspace)
         return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const PfP p{n, V, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth};
+    const PfP p{n, V, h, w, points, w2cs, ixts, img_ref, image, acc_map, depth, row_views};
     const size_t npix = (size_t)V * h * w;
     float4 *packed = (float4 *)workspace;
     const bool maps = d_image || d_acc_map || d_depth;
@@ -269,7 +294,7 @@ int lara_point_feats_backward(int32_t n, int32_t V, int32_t h, int32_t w, const 
         else if (V <= 4) launch_bwd<4>(p, packed, g_out, d_points, dpacked, s);
         else launch_bwd<8>(p, packed, g_out, d_points, dpacked, s);
         if (maps)
-            hipLaunchKernelGGL(unpack_grad_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const float4 *)dpacked, npix,
+            hipLaunchKernelGGL(unpack_grad_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, p, (const float4 *)dpacked, npix,
                                d_image, d_acc_map, d_depth);
     }
     L2D_CHECK_LAUNCH();

@@ -35,6 +35,10 @@ def _lib():
         lib.lara_point_feats_forward.argtypes = [i32, i32, i32, i32] + [vp] * 10
         lib.lara_point_feats_backward.restype = ctypes.c_int
         lib.lara_point_feats_backward.argtypes = [i32, i32, i32, i32] + [vp] * 14
+        lib.lara_point_feats_forward_concat.restype = ctypes.c_int
+        lib.lara_point_feats_forward_concat.argtypes = [i32, i32, i32, i32, i32] + [vp] * 10
+        lib.lara_point_feats_backward_concat.restype = ctypes.c_int
+        lib.lara_point_feats_backward_concat.argtypes = [i32, i32, i32, i32, i32] + [vp] * 14
         lib.lara_point_feats_workspace_bytes.restype = ctypes.c_int64
         lib.lara_point_feats_workspace_bytes.argtypes = [i32, i32, i32]
         lib.lara_fine_decoder_forward.restype = ctypes.c_int
@@ -60,24 +64,30 @@ def _workspace(device, V, h, w):
 
 class _PointFeats(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points, w2cs, ixts, img_ref, image, acc_map, depth):
+    def forward(ctx, points, w2cs, ixts, img_ref, image, acc_map, depth, row_views):
         if not points.is_cuda:
             raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
         f = lambda t: t.detach().float().contiguous()
         points, w2cs, ixts, img_ref, image, acc_map, depth = map(f, (points, w2cs, ixts, img_ref, image, acc_map, depth))
         n, V, h, w = points.shape[0], img_ref.shape[0], img_ref.shape[2], img_ref.shape[3]
-        if (points.shape != (n, 3) or w2cs.shape != (V, 4, 4) or ixts.shape != (V, 3, 3) or img_ref.shape != (V, 3, h, w)
-                or image.shape != (V, h, w, 3) or acc_map.shape != (V, h, w) or depth.shape != (V, h, w, 1)):
-            raise RuntimeError("expected points [n,3], w2cs [V,4,4], ixts [V,3,3], img_ref [V,3,h,w], image [V,h,w,3], "
-                               "acc_map [V,h,w], depth [V,h,w,1]")
+        if points.shape != (n, 3) or w2cs.shape != (V, 4, 4) or ixts.shape != (V, 3, 3) or img_ref.shape != (V, 3, h, w):
+            raise RuntimeError("expected points [n,3], w2cs [V,4,4], ixts [V,3,3], img_ref [V,3,h,w]")
+        if row_views:      # the maps of `row_views` >= V views side by side
+            R = int(row_views)
+            if R < V or image.shape != (h, R * w, 3) or acc_map.numel() != h * R * w or depth.shape != (h, R * w, 1):
+                raise RuntimeError("expected points [n,3], ... and image [h,R*w,3], acc_map [h,R*w], depth [h,R*w,1] with R = row_views >= V")
+        elif image.shape != (V, h, w, 3) or acc_map.shape != (V, h, w) or depth.shape != (V, h, w, 1):
+            raise RuntimeError("expected points [n,3], w2cs [V,4,4], ixts [V,3,3], img_ref [V,3,h,w], image [V,h,w,3], acc_map [V,h,w], depth [V,h,w,1]")
         out = torch.empty(V, 8, n, dtype=torch.float32, device=points.device)
         ws = _workspace(points.device, V, h, w)
         with torch.cuda.device(points.device):
-            _check(_lib().lara_point_feats_forward(n, V, h, w, points.data_ptr(), w2cs.data_ptr(), ixts.data_ptr(),
-                                                   img_ref.data_ptr(), image.data_ptr(), acc_map.data_ptr(), depth.data_ptr(),
-                                                   out.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(points.device).cuda_stream),
+            _check(_lib().lara_point_feats_forward_concat(n, V, int(row_views or 0), h, w, points.data_ptr(), w2cs.data_ptr(),
+                                                          ixts.data_ptr(), img_ref.data_ptr(), image.data_ptr(), acc_map.data_ptr(),
+                                                          depth.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                                          torch.cuda.current_stream(points.device).cuda_stream),
                    "lara_point_feats_forward")
         ctx.save_for_backward(points, w2cs, ixts, img_ref, image, acc_map, depth)
+        ctx.row_views = int(row_views or 0)
         return out
 
     @staticmethod
@@ -93,12 +103,13 @@ class _PointFeats(torch.autograd.Function):
         ptr = lambda t: None if t is None else t.data_ptr()
         ws = _workspace(points.device, V, h, w)
         with torch.cuda.device(points.device):
-            _check(_lib().lara_point_feats_backward(n, V, h, w, points.data_ptr(), w2cs.data_ptr(), ixts.data_ptr(),
-                                                    img_ref.data_ptr(), image.data_ptr(), acc_map.data_ptr(), depth.data_ptr(),
-                                                    g_out.data_ptr(), d_points.data_ptr(), ptr(d_image), ptr(d_acc), ptr(d_depth),
-                                                    ws.data_ptr(), torch.cuda.current_stream(points.device).cuda_stream),
+            _check(_lib().lara_point_feats_backward_concat(n, V, ctx.row_views, h, w, points.data_ptr(), w2cs.data_ptr(),
+                                                           ixts.data_ptr(), img_ref.data_ptr(), image.data_ptr(), acc_map.data_ptr(),
+                                                           depth.data_ptr(), g_out.data_ptr(), d_points.data_ptr(), ptr(d_image),
+                                                           ptr(d_acc), ptr(d_depth), ws.data_ptr(),
+                                                           torch.cuda.current_stream(points.device).cuda_stream),
                    "lara_point_feats_backward")
-        return d_points if need[0] else None, None, None, None, d_image, d_acc, d_depth
+        return d_points if need[0] else None, None, None, None, d_image, d_acc, d_depth, None
 
 
 class _TakeRows(torch.autograd.Function):
@@ -124,9 +135,12 @@ def take_rows(x, idx):
     return _TakeRows.apply(x, idx)
 
 
-def sample_point_feats(points, w2cs, ixts, img_ref, image, acc_map, depth):
-    """points [n,3] -> [V, 8, n]: channels 0-2 the input image, 3-5 the coarse render, 6 acc_map, 7 |depth - z|."""
-    return _PointFeats.apply(points, w2cs, ixts, img_ref, image, acc_map, depth)
+def sample_point_feats(points, w2cs, ixts, img_ref, image, acc_map, depth, row_views=0):
+    """points [n,3] -> [V, 8, n]: channels 0-2 the input image, 3-5 the coarse render, 6 acc_map, 7 |depth - z|.
+    `row_views` = R > 0: image / acc_map / depth are `Renderer.render_views(concat=True)`'s maps of R >= V views side by
+    side ([h, R*w, c]) and the sampler reads the first V of them in place -- no `[:, :V]` slice + stack in front, no
+    zero-padded slice gradient behind (network.py:499 stacks the first n_views_sel renders for exactly this call)."""
+    return _PointFeats.apply(points, w2cs, ixts, img_ref, image, acc_map, depth, row_views)
 
 
 def get_point_feats(self, idx, img_ref, renderings, n_views_sel, batch, points, mask):

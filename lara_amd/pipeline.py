@@ -231,7 +231,8 @@ class LaRaPipeline(nn.Module):
         sides = self._streams[:n_streams] if n_streams > 1 else [None] * B
         on = lambda s: torch.cuda.stream(s) if s is not None else contextlib.nullcontext()
 
-        cams_of = [self.scene_cameras(batch, i, scalars) for i in range(B)]
+        sizes = [(int(batch["meta"]["tar_w"][i]), int(batch["meta"]["tar_h"][i])) for i in range(B)]
+        cams_of = cameras.make_cameras_scenes(batch["tar_c2w"], sizes, scalars, device=batch["tar_c2w"].device)   # every MiniCam of the batch
         self._mark("start")
         g = make_gaussians()
         # the input images as [B, n_sel, 3, H, W] (network.py:437-438, :469): what the sampler reads as `img_ref`
@@ -270,11 +271,10 @@ class LaRaPipeline(nn.Module):
                     co = per_scene[i]
                     H, VW = co["acc_map"].shape
                     V, W = len(cams_of[i]), VW // len(cams_of[i])
-                    # the first n_sel views of the side-by-side maps as [n_sel, H, W, C] (network.py:499: `torch.stack`)
-                    sel = lambda t: t.view(H, V, W, -1)[:, :n_sel].permute(1, 0, 2, 3)
                     centers_f = take_rows(sc["centers"][i], idx[i])
+                    # the sampler reads the first n_sel views of the side-by-side maps in place (network.py:499 stacks them)
                     pf = sample_point_feats(centers_f, batch["tar_w2c"][i, :n_sel], batch["tar_ixt"][i, :n_sel], inps[i],
-                                            sel(co["image"]), sel(co["acc_map"]).squeeze(-1), sel(co["depth"]))
+                                            co["image"], co["acc_map"], co["depth"], row_views=V)
                     vox = torch.div(idx[i], self.K, rounding_mode="floor")
                     sh_res = forward_fine(self.decoder, _TakeVoxelRows.apply(sc["vol"][i], vox), torch.einsum("lcb->blc", pf), folded)
                     shs_f = sh_res.view(-1, *g["shs"].shape[-2:]) + take_rows(sc["shs"][i], idx[i])

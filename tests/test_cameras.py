@@ -99,3 +99,21 @@ def test_reference_renderer_builds_the_same_settings_through_the_shim():
         for k in [k for k in sys.modules if k == "lightning" or k.startswith("lightning.")]:
             del sys.modules[k]
         sys.modules.update(saved_mods)
+
+
+def test_cameras_of_a_whole_batch_equal_the_per_scene_cameras():
+    """`make_cameras_scenes` (one batched pass for the B x V cameras of a batch) against `make_cameras` per scene."""
+    import torch
+    from lara_amd import cameras
+    c2w = torch.stack([cameras.turntable_c2w(8), cameras.turntable_c2w(8, 20.0)])
+    scalars = [(1.1, 2.7, 0.75, 0.7), (0.9, 2.5, 0.6, 0.65)]
+    sizes = [(512, 512), (256, 128)]
+    got = cameras.make_cameras_scenes(c2w, sizes, scalars)
+    for b in range(2):
+        want = cameras.make_cameras(c2w[b], sizes[b][0], sizes[b][1], scalars[b][2], scalars[b][3], scalars[b][0], scalars[b][1])
+        assert len(got[b]) == len(want) == 8
+        for x, y in zip(got[b], want):
+            for k in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center"):
+                assert torch.equal(getattr(x, k), getattr(y, k)), k
+            assert (x.image_width, x.image_height, x.FoVx, x.FoVy, x.znear, x.zfar) == \
+                   (y.image_width, y.image_height, y.FoVx, y.FoVy, y.znear, y.zfar)
