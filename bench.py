@@ -1083,7 +1083,8 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     from lara_amd import rasterizer
     from lara_amd.batch import synthetic_batch
     from lara_amd.encoder_train import VolTransformer
-    from lara_amd.pipeline import CoarseFineDecoder, LaRaPipeline, lara_loss
+    from lara_amd.pipeline import CoarseFineDecoder, LaRaPipeline
+    from lara_amd.loss import lara_loss      # the fused restatement of loss.py (same values as pipeline.lara_loss: tests/test_pipeline.py)
     rasterizer.load_library()
     if args.views < 4 and not args.no_fine:
         raise SystemExit("bench.py --step pipeline: the fine stage samples the 4 input views (configs/base.yaml: n_views 4); --views >= 4 or --no-fine")
@@ -1150,7 +1151,7 @@ def ddp_single_rank_leg(info, args, device):
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
     from lara_amd import dp
-    from lara_amd.pipeline import lara_loss
+    from lara_amd.loss import lara_loss
     pipe, batch, feat_vol, _ = info["pipeline"]
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -1193,7 +1194,7 @@ def pipeline_breakdown(info, args):
     `LaRaPipeline.forward`) + the whole backward; (b) the library's kernels of one whole step grouped by stage (HIP events
     around every launch, serialised); (c) the fine subset's size and D."""
     from lara_amd import rasterizer
-    from lara_amd.pipeline import lara_loss
+    from lara_amd.loss import lara_loss
     pipe, batch, feat_vol, full_step = info["pipeline"]
     prev_streams = pipe.n_streams
     pipe.n_streams = 1

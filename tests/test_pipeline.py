@@ -76,6 +76,26 @@ def test_loss_matches_the_reference_minus_ms_ssim(it, with_fine):
         np.testing.assert_allclose(got, fx[f"{tag}.d_{k}"], rtol=1e-5, atol=1e-9, err_msg=k)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("it", [500, 2000])
+@pytest.mark.parametrize("with_fine", [True, False])
+def test_fused_loss_matches_the_reference_minus_ms_ssim(hip_lib, it, with_fine):
+    """`lara_amd.loss.lara_loss` (one HIP kernel per direction) against the same fixture of the reference's `Losses.forward`."""
+    from lara_amd.loss import lara_loss
+    fx = np.load(FX)
+    batch = {"tar_rgb": torch.from_numpy(fx["loss.in.tar_rgb"]).cuda()}
+    o = {k[len("loss.in."):]: torch.from_numpy(fx[k]).cuda().requires_grad_(True) for k in fx.files
+         if k.startswith("loss.in.") and k != "loss.in.tar_rgb" and (with_fine or not k.endswith("_fine"))}
+    loss, stats = lara_loss(batch, o, it)
+    loss.backward()
+    tag = f"loss.{it}.{'fine' if with_fine else 'coarse'}"
+    assert float(loss) == pytest.approx(float(fx[tag]), rel=2e-6)
+    assert set(stats) == {"mse"} | ({"mse_fine"} if with_fine else set()) | ({"distortion", "normal"} if it > 1000 else set())
+    for k, v in o.items():
+        got = v.grad.cpu().numpy() if v.grad is not None else np.zeros(v.shape, np.float32)
+        np.testing.assert_allclose(got, fx[f"{tag}.d_{k}"], rtol=1e-5, atol=1e-9, err_msg=k)
+
+
 def test_voxel_row_gather_is_the_expand_and_mask_of_the_reference():
     from lara_amd.pipeline import _TakeVoxelRows
     g = torch.Generator().manual_seed(2)
