@@ -29,7 +29,7 @@ from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class _View(ctypes.Structure):
