@@ -339,16 +339,28 @@ def mesh_eval_leg(args, device):
 def measure_roofline(scenes, settings, gc, ga, args):
     """Per-kernel HIP-event times over one step; returns (roofline dict, per-kernel table, D)."""
     from lara_amd import rasterizer
+    # An event pair around a launch also measures the host: the start event runs at once and the device then waits for the
+    # kernel to be enqueued.  One profiled step first (its first launches pay one-off host work: up to tens of ms were seen
+    # on one launch), then the measured one; a launch that still sits beyond 3x its kernel's median is a host stall, not a
+    # kernel time, and is left out of the average (`host_stalls` counts them; rocprofv3's averages, which only see the
+    # device, are the cross-check: profiles/<tag>_kernel_stats.csv).
     rasterizer.profile_enable(True)
+    step(scenes, settings, gc, ga)
+    torch.cuda.synchronize()
+    rasterizer.profile_collect()
     step(scenes, settings, gc, ga)
     torch.cuda.synchronize()
     rec = rasterizer.profile_collect()
     rasterizer.profile_enable(False)
-    agg = {}
+    by_name = {}
     for name, ms in rec:
-        a = agg.setdefault(name, [0, 0.0])
-        a[0] += 1
-        a[1] += ms
+        by_name.setdefault(name, []).append(ms)
+    agg, stalls = {}, 0
+    for name, v in by_name.items():
+        med = sorted(v)[len(v) // 2]
+        kept = [x for x in v if x <= 3.0 * med]
+        stalls += len(v) - len(kept)
+        agg[name] = [len(kept), sum(kept)]
     # D (pairs per frame) of one representative view
     from lara_amd import synthetic
     act = synthetic.activate({k: v.detach() for k, v in scenes[0].items()})
@@ -408,7 +420,7 @@ def measure_roofline(scenes, settings, gc, ga, args):
             # useful FMA lane-operations / issued VALU lane-slots: filled in by the cpu_baseline leg, whose oracle counts the
             # (pixel, splat) pairs the frame really blends (`blended_pairs`); issued = SQ_INSTS_VALU x 64 lanes (committed PMC)
             "valu_useful_frac": None, "valu_insts_per_launch": insts, "valu_insts_source": insts_src,
-            "avg_launch_us": round(t["avg_us"], 2), "alg_bytes_per_launch": t["alg_bytes"],
+            "avg_launch_us": round(t["avg_us"], 2), "host_stalls_left_out": stalls, "alg_bytes_per_launch": t["alg_bytes"],
             "pairs_per_frame_D": D, "measured_copy_GBs": round(copy_GBs, 1),
             "whole_frame": {"alg_bytes": frame_bytes, "kernel_us": round(frame_us, 1),
                             "achieved": round(frame_bytes / frame_us / 1e3, 1),

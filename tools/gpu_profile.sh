@@ -28,6 +28,12 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     -d $OUT/prof_${TAG}_pmc2 -o pmc -- \
     python $REPO/bench.py --steps 1 --warmup 0 --scenes 1 --step raster --raster-api loop --streams 1 --no-fine --no-cpu-baseline --no-roofline $EXTRA > $OUT/prof_${TAG}_pmc2.log 2>&1
+# (c) the same counters over the MULTI-VIEW launches (one scene, 8 views, every kernel once over the cameras, one stream):
+#     what the batched launch does to the forward's idle issue slots
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+    -d $OUT/prof_${TAG}_vpmc -o pmc -- \
+    python $REPO/bench.py --steps 1 --warmup 0 --scenes 1 --step raster --raster-api views --streams 1 --no-fine --no-cpu-baseline --no-roofline $EXTRA > $OUT/prof_${TAG}_vpmc.log 2>&1
+find $OUT/prof_${TAG}_vpmc -type f -size +8M -delete
 # keep only what is small enough to travel back
 find $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_stats_train $OUT/prof_${TAG}_stats_pipe1 $OUT/prof_${TAG}_pmc $OUT/prof_${TAG}_pmc2 -type f -size +8M -delete
 find $OUT/prof_${TAG}_stats $OUT/prof_${TAG}_pmc $OUT/prof_${TAG}_pmc2 -type f | head -50

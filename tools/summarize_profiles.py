@@ -41,6 +41,14 @@ if agg:
         for k, d in agg.items():
             n = max(cnt[(k, c)] for c in cols)
             f.write(f"{k},{n}," + ",".join(str(int(d.get(c, 0) / max(cnt[(k, c)], 1))) for c in cols) + "\n")
+agg, cnt = pmc_table(os.path.join(out, f"prof_{tag}_vpmc", "**", "*counter_collection.csv"))      # the multi-view launches
+if agg:
+    cols = sorted({c for d in agg.values() for c in d})
+    with open(os.path.join(prof, f"{tag}_views_pmc_summary.csv"), "w") as f:
+        f.write("kernel,launches," + ",".join(cols) + "\n")
+        for k, d in agg.items():
+            n = max(cnt[(k, c)] for c in cols)
+            f.write(f"{k},{n}," + ",".join(str(int(d.get(c, 0) / max(cnt[(k, c)], 1))) for c in cols) + "\n")
 traffic = {}
 for c, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     agg, cnt = pmc_table(os.path.join(out, f"traffic_{tag}_{c}", "**", "*counter_collection.csv"))
