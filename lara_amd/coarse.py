@@ -104,6 +104,8 @@ class _CoarseDecoder(torch.autograd.Function):
 def supported(decoder) -> bool:
     """The sizes the kernels are built for: Linear(80,80) ReLU Linear(80,80) ReLU Linear(80, K (10 + sh_dim) <= 48)."""
     seq = getattr(decoder, "mlp_coarse", None)
+    if any(not hasattr(decoder, a) for a in ("K", "sh_dim", "opacity_dim", "scaling_dim", "rotation_dim")):
+        return False
     if seq is None or len(seq) != 5 or not all(isinstance(seq[i], nn.Linear) for i in (0, 2, 4)):
         return False
     if not all(isinstance(seq[i], nn.ReLU) for i in (1, 3)) or any(seq[i].bias is None for i in (0, 2, 4)):

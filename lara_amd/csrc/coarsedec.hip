@@ -11,8 +11,13 @@
 // matrices are written, straight from / to the operand layout.
 // A wave carries two column blocks (32 voxel rows) per trip so that a weight fragment read from LDS feeds two MFMAs; a
 // workgroup (4 waves) takes 128 rows per trip and stays resident (weights are staged into LDS once per workgroup).
-// 65 MFMAs per 16 rows forward, 130 backward: ~15 / 30 us of matrix-core time per 10^6 rows -- the kernels run at the speed
-// of their HBM streams (forward 320 + 88 K bytes per row, backward 320 + 88 K in, 320 + 896 out).
+// Outputs (forward) and output gradients (backward) travel through a per-wave LDS tile in the five tensors' own layout, 16
+// bytes per lane; the backward's products with W^T read the same row-major LDS image through ds_read_b64_tr_b16; the factor
+// matrices of the parameter gradients leave as bf16 rows, the activations with a column of ones (bias gradients ride along
+// in the weight-gradient products of lara_gemm_tn_bf16).
+// 65 MFMAs per 16 rows forward, 130 backward (~50 / ~100 us of matrix-core time per 10^6 rows at this instruction's rate);
+// HBM: forward 320 + 88 K bytes per row, backward 320 + 88 K in, 320 + 1008 out.  Measured 150 / 584 us per 10^6 rows
+// (3.5 / 3.1 TB/s): a trip's load, MFMA and store phases do not overlap inside a wave.
 #include "common.h"
 #include "../../include/lara_coarsedec.h"
 
@@ -156,7 +161,6 @@ coarse_fwd_kernel(const CdP p) {
     __shared__ __attribute__((aligned(16))) unsigned short W1s[CD_F * CD_LDW], W2s[CD_F * CD_LDW], W3s[CD_O * CD_LDW];
     __shared__ __attribute__((aligned(16))) float bs[CD_NB];
     __shared__ __attribute__((aligned(16))) float tiles[4 * CD_TILE];
-    __shared__ float *s_out[5];
     __shared__ int s_width[5], s_toff[5];
     __shared__ signed char s_tensor[CD_O], s_col[CD_O], s_act[CD_O];
     stage_matrix<CD_F>(p.w1, CD_F, W1s, CD_LDW, false);
@@ -168,7 +172,7 @@ coarse_fwd_kernel(const CdP p) {
     if (threadIdx.x < CD_O) {
         s_tensor[threadIdx.x] = p.tensor[threadIdx.x]; s_col[threadIdx.x] = p.col[threadIdx.x]; s_act[threadIdx.x] = p.act[threadIdx.x];
     }
-    if (threadIdx.x < 5) { s_out[threadIdx.x] = p.out[threadIdx.x]; s_width[threadIdx.x] = p.width[threadIdx.x]; s_toff[threadIdx.x] = p.toff[threadIdx.x]; }
+    if (threadIdx.x < 5) { s_width[threadIdx.x] = p.width[threadIdx.x]; s_toff[threadIdx.x] = p.toff[threadIdx.x]; }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, q4 = lane >> 4;
     const int trips = (p.M + CD_PTS - 1) / CD_PTS;
@@ -238,7 +242,6 @@ coarse_bwd_kernel(const CdP p) {
     __shared__ __attribute__((aligned(16))) unsigned short W1s[CD_F * CD_LDW], W2s[CD_F * CD_LDW], W3s[CD_O * CD_LDW];
     __shared__ __attribute__((aligned(16))) float bs[2 * CD_F];
     __shared__ __attribute__((aligned(16))) float tiles[8 * CD_TILE];
-    __shared__ const float *s_dout[5];
     __shared__ int s_width[5], s_toff[5];
     __shared__ signed char s_tensor[CD_O], s_col[CD_O], s_act[CD_O];
     stage_matrix<CD_F>(p.w1, CD_F, W1s, CD_LDW, false);
@@ -249,7 +252,7 @@ coarse_bwd_kernel(const CdP p) {
     if (threadIdx.x < CD_O) {
         s_tensor[threadIdx.x] = p.tensor[threadIdx.x]; s_col[threadIdx.x] = p.col[threadIdx.x]; s_act[threadIdx.x] = p.act[threadIdx.x];
     }
-    if (threadIdx.x < 5) { s_dout[threadIdx.x] = p.dout[threadIdx.x]; s_width[threadIdx.x] = p.width[threadIdx.x]; s_toff[threadIdx.x] = p.toff[threadIdx.x]; }
+    if (threadIdx.x < 5) { s_width[threadIdx.x] = p.width[threadIdx.x]; s_toff[threadIdx.x] = p.toff[threadIdx.x]; }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c16 = lane & 15, q4 = lane >> 4;
     const int trips = (p.M + CD_PTS - 1) / CD_PTS;
