@@ -696,6 +696,11 @@ def point_feats_leg(device, args):
             "torch_sequence_us": round(res[False], 1), "fused_us": round(res[True], 1)}
 
 
+def _leg(name):
+    """Progress line on stderr: a leg that dies (device fault, time-out) is then named in the log."""
+    print(f"[bench] {name}", file=sys.stderr, flush=True)
+
+
 def coarse_decoder_leg(device, scenes):
     """`Decoder.forward_coarse` (network.py:259-278) on the batch's scenes x 64^3 voxel rows, forward + backward with gradients
     to the volume features and the six parameters: the torch sequence under bf16 autocast arithmetic (`pipeline.decode_coarse`:
@@ -1465,9 +1470,11 @@ def main():
     }
     solo = rank == 0 and world == 1 and not plumbing
     if solo and args.step == "pipeline" and not args.no_roofline:
+        _leg("stages")
         out["stages"] = pipeline_breakdown(info, args)
     if solo and args.step == "pipeline" and not args.no_roofline and not args.no_side_legs:
         try:
+            _leg("ddp_single_rank_rccl")
             out["ddp_single_rank_rccl"] = ddp_single_rank_leg(info, args, device)
         except Exception as e:      # (a box without a usable RCCL: say so instead of losing the line)
             out["ddp_single_rank_rccl"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -1475,6 +1482,7 @@ def main():
         # no decoder / sampler / forward_fine / loss, the fine subset not thinned
         a2 = argparse.Namespace(**{**vars(args), "step": "train"})
         step2, info2 = make_training_step(a2, device, rank, world, plumbing)
+        _leg("independent_tensors_step")
         for _ in range(3):
             step2()
         torch.cuda.synchronize()
@@ -1506,31 +1514,39 @@ def main():
         coarse = args.scenes * args.views
         # the raster alone, coarse views only: round 1's headline definition (BENCH_r01.json `value`)
         api = args.raster_api
+        _leg("raster_only")
         out["raster_only"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams, api=api), coarse),
                                   workload=f"raster fwd+bwd only, {args.scenes} scenes x {args.views} coarse views, {args.streams} HIP streams, api={api}")
         if fine_idx is not None:
+            _leg("raster_only_with_fine")
             out["raster_only_with_fine"] = dict(timed(lambda: step(scenes, settings, gc, ga, args.streams, fine_idx, api=api), 2 * coarse),
                                                 workload="raster fwd+bwd only, coarse + fine views (the raster part of the headline step)",
                                                 fine_subset_fraction=round(float(sum(i.numel() for i in fine_idx)) / (P * len(fine_idx)), 4))
         # the multi-view call on ONE caller stream (the library's side streams only)
+        _leg("views_api_one_stream")
         out["views_api_one_stream"] = timed(lambda: step(scenes, settings, gc, ga, 1, api="views"), coarse)
         # one call per view, as the reference's loop issues them: two scene streams (round 1's headline) and one stream
+        _leg("reference_loop")
         out["reference_loop"] = {"two_streams": timed(lambda: step(scenes, settings, gc, ga, 2, api="loop"), coarse),
                                  "with_fine_two_streams": (timed(lambda: step(scenes, settings, gc, ga, 2, fine_idx, api="loop"), 2 * coarse)
                                                            if fine_idx is not None else None)}
+        _leg("single_stream")
         out["single_stream"] = timed(lambda: step(scenes, settings, gc, ga, 1, api="loop"), coarse)
         # opt-in, not in the reference: surfels with opacity < 1/255 (never drawn) culled in the preprocess; same
         # images to an ulp, same gradients (tests/test_raster_parity_gpu.py); nothing to cull at LaRa's initialisation,
         # most of the volume in a trained-like scene
         prev = rasterizer.set_cull_transparent(True)
         try:
+            _leg("cull_transparent_opt_in")
             out["cull_transparent_opt_in"] = timed(lambda: step(scenes, settings, gc, ga, args.streams, api=api), coarse)
         finally:
             rasterizer.set_cull_transparent(prev)
+        _leg("forward_only")
         out["forward_only"] = forward_only_leg(scenes, settings, args)
         if "LARA2DGS_VIEW_STREAMS" not in os.environ:
             rasterizer.set_view_lanes(None)     # the one-stream side legs below: the library's default (two lanes)
         if not args.no_side_legs:
+            _leg("mesh_eval")
             out["mesh_eval"] = mesh_eval_leg(args, device)
     if rank == 0 and not plumbing and not args.no_roofline:
         scenes, settings, gc, ga, fine_idx = info["raster_state"]
@@ -1542,16 +1558,26 @@ def main():
         del full_step
         info.clear()
         torch.cuda.empty_cache()
+        _leg("attention")
         out["attention"] = attention_leg(device, args.scenes)
+        _leg("encoder")
         out["encoder"] = encoder_leg(device, args.scenes)
+        _leg("encoder_train")
         out["encoder_train"] = encoder_train_leg(device, args.scenes)
+        _leg("rays")
         out["rays"] = rays_leg(device, args.scenes, args.views, args.res)
+        _leg("render_img")
         out["render_img"] = render_img_leg(device, args)
+        _leg("point_feats")
         out["point_feats"] = point_feats_leg(device, args)
+        _leg("coarse_decoder")
         out["coarse_decoder"] = coarse_decoder_leg(device, args.scenes)
+        _leg("fine_decoder")
         out["fine_decoder"] = fine_decoder_leg(device)
+        _leg("fine_stage")
         out["fine_stage"] = fine_stage_leg(device, args)
     if solo and not args.no_cpu_baseline:
+        _leg("cpu_baseline")
         out["cpu_baseline"] = cpu_baseline(args)
         out["cpu_baseline"]["encoder"] = cpu_encoder_baseline()
         roof = out.get("roofline")
