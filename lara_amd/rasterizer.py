@@ -165,22 +165,46 @@ _scratch = {}   # (device index, stream id) -> uint8 tensor
 _pending = []   # [(event, pinned header, capacity)] of forwards not yet checked for overflow
 
 
-def _poison(buf: torch.Tensor) -> torch.Tensor:
-    """LARA2DGS_POISON_BUFFERS=1 (tests / debugging): fill a freshly obtained state or scratch buffer with 0xFF bytes (NaN as
-    floats, 4 G as counts) before the library sees it -- a kernel that reads a field before it is written then fails
-    loudly instead of living off whatever the caching allocator left in the block."""
-    if os.environ.get("LARA2DGS_POISON_BUFFERS") == "1":
-        buf.fill_(255)
-    return buf
+_GUARD = 1 << 16   # poison mode: guard bytes on either side of a state / scratch buffer
+_guards = []       # poison mode: [(whole allocation, payload bytes)] handed out since the last check_poison_guards()
+
+
+def _poison_mode() -> bool:
+    return os.environ.get("LARA2DGS_POISON_BUFFERS") == "1"
+
+
+def _alloc_bytes(n: int, device: torch.device) -> torch.Tensor:
+    """A state / scratch buffer.  LARA2DGS_POISON_BUFFERS=1 (tests / debugging): the buffer sits between two 64 KB guard
+    zones and everything is filled with 0xFF bytes (NaN as floats, 4 G as counts) before the library sees it -- a kernel that
+    reads a field before it is written, or beyond either end, then fails loudly instead of living off whatever the caching
+    allocator left around, and `check_poison_guards()` finds a write beyond either end."""
+    if not _poison_mode():
+        return torch.empty(n, dtype=torch.uint8, device=device)
+    whole = torch.empty(n + 2 * _GUARD, dtype=torch.uint8, device=device)
+    whole.fill_(255)
+    _guards.append((whole, n))
+    return whole[_GUARD:_GUARD + n]
+
+
+def check_poison_guards() -> list:
+    """Poison mode: the payload sizes of the buffers handed out since the last call whose guard zones no longer read 0xFF
+    (i.e. some kernel wrote outside the buffer); synchronises the device."""
+    torch.cuda.synchronize()
+    bad = [n for whole, n in _guards
+           if not bool((whole[:_GUARD] == 255).all()) or not bool((whole[_GUARD + n:] == 255).all())]
+    _guards.clear()
+    return bad
 
 
 def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
+    if _poison_mode():      # a fresh, guarded, 0xFF-filled buffer per call (the backward must not live off the forward's either)
+        return _alloc_bytes(nbytes, device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _scratch[key] = buf
-    return _poison(buf)
+    return buf
 
 
 def _raise_overflow(hdr, cap):
@@ -324,7 +348,7 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
         color = torch.empty((3, H, W), dtype=torch.float32, device=device)
         allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
         radii = torch.empty((P,), dtype=torch.int32, device=device)
-        state = _poison(torch.empty((lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap),), dtype=torch.uint8, device=device))
+        state = _alloc_bytes(lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap), device)
         scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap))
         rc = lib.lara2dgs_forward(ctypes.byref(view), _ptr(means3D_c), _ptr(sh_c), _ptr(col_c),
                                   _ptr(opa_c), _ptr(sc_c), _ptr(rot_c), _ptr(tm_c),
@@ -487,7 +511,7 @@ class _RasterizeViews(torch.autograd.Function):
             radii = torch.empty((n, P), dtype=torch.int32, device=device)
             sb = (lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
             qb = (lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
-            state = _poison(torch.empty((n * sb,), dtype=torch.uint8, device=device))
+            state = _alloc_bytes(n * sb, device)
             # a scratch buffer per VIEW: the library then preprocesses all cameras in one launch (the surfels' inputs are
             # read once); with fewer it falls back to one preprocess launch per view on the lanes
             # (LARA2DGS_VIEWS_BATCH_PREPROCESS=0 keeps one scratch per lane: the memory-lean path)

@@ -20,3 +20,13 @@ def hip_lib():
     if not os.path.exists(rasterizer.LIB_PATH):
         g.build()
     return rasterizer.load_library()
+
+
+@pytest.fixture(autouse=True)
+def _poison_guards_survive(request):
+    """With LARA2DGS_POISON_BUFFERS=1 in the environment of the whole run (a debugging mode: every state / scratch buffer of
+    the rasteriser 0xFF-filled between guard zones), every GPU test also asserts that no kernel wrote outside a buffer."""
+    yield
+    if os.environ.get("LARA2DGS_POISON_BUFFERS") == "1" and request.node.get_closest_marker("gpu") is not None:
+        from lara_amd import rasterizer
+        assert rasterizer.check_poison_guards() == [], "a kernel wrote beyond the end of a state / scratch buffer"

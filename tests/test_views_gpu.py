@@ -298,7 +298,8 @@ def test_render_views_matches_render_img_loop():
 def test_state_and_scratch_contents_do_not_matter(monkeypatch):
     """LARA2DGS_POISON_BUFFERS=1 fills every state / scratch buffer with 0xFF before the library sees it (the caching
     allocator otherwise hands back blocks that still hold a previous call's, valid-looking, contents): same bits forward
-    and backward, per-view operator and multi-view call -- no kernel reads a field before it is written."""
+    and backward, per-view operator and multi-view call -- no kernel reads a field before it is written; the buffers then also
+    sit between 0xFF guard zones, which must survive (no write outside a buffer; a read outside would see poison)."""
     from lara_amd import GaussianRasterizer, rasterize_gaussians_views
     act, cams = small_scene(grid=12, size=96, n_views=5, seed=8)
     settings = [raster_settings(c, [1.0, 0.5, 0.0], device=DEV) for c in cams]
@@ -316,8 +317,10 @@ def test_state_and_scratch_contents_do_not_matter(monkeypatch):
         return [c.detach().clone(), a.detach().clone(), r.clone(), c1.detach().clone(), r1.clone()] + \
                [v.grad.clone() for v in inp.values()] + [v.grad.clone() for v in one.values()]
 
+    from lara_amd import rasterizer
     clean = run()
     monkeypatch.setenv("LARA2DGS_POISON_BUFFERS", "1")
     poisoned = run()
+    assert rasterizer.check_poison_guards() == []       # ... and none writes beyond either end of a buffer
     for x, y in zip(clean, poisoned):
         assert torch.equal(x, y)
