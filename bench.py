@@ -390,7 +390,9 @@ def measure_roofline(scenes, settings, gc, ga, args):
     # summaries are committed under profiles/ and READ here -- they are not measured in this run and say so.
     traffic, traffic_src, valu, valu_src, insts, insts_src = None, None, None, None, None, None
     if args.grid == 64 and args.res == 512:
-        tagged = (lambda f: "trained" in os.path.basename(f)) if args.regime == "trained" else (lambda f: "trained" not in os.path.basename(f))
+        # (same regime, and the per-view launches: `<tag>_views_pmc_summary.csv` holds the 8-view launches of a multi-view call)
+        same = (lambda f: "trained" in os.path.basename(f)) if args.regime == "trained" else (lambda f: "trained" not in os.path.basename(f))
+        tagged = lambda f: same(f) and "_views_" not in os.path.basename(f)
         traffic, traffic_src = _newest_profile("traffic_r*.json", lambda f: json.load(open(f))["bytes_per_launch"][dom]["total"], tagged)
         valu, valu_src = _newest_profile("r*pmc_summary.csv", lambda f: _valu_issue_frac(f, dom), tagged)
         insts, insts_src = _newest_profile("r*pmc_summary.csv", lambda f: _pmc_value(f, dom, "SQ_INSTS_VALU"), tagged)
