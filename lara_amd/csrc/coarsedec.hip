@@ -39,7 +39,7 @@ constexpr int CD_LDW = 84;    // bf16 elements per LDS row of an 80-wide matrix 
 constexpr int CD_PTS = 128;   // voxel rows per workgroup trip
 constexpr int CD_NB = 208;    // bias entries: 80 + 80 + 48
 constexpr int CD_FA = 88;     // row width of the activation factor matrices: 80 features, a column of ones, 7 of zeros
-constexpr int CD_TILE = 16 * CD_O + 16 * 8;   // floats of a wave's IO tile: 16 rows of the five tensors (+ the backward's copy of `offset`)
+constexpr int CD_TILE = 16 * CD_O + 16 * 12;  // floats of a wave's IO tile: 16 rows of the five tensors + the backward's copy of `offset` (16 x 3K floats, K <= 4 since 10 K <= CD_O)
 constexpr int CD_WG_FWD = 1024, CD_WG_BWD = 512;
 
 struct CdP {
@@ -387,6 +387,7 @@ coarse_bwd_kernel(const CdP p) {
 int fill_map(CdP &p, const int K, const int sh_dim) {
     const int per = 10 + sh_dim;
     if (K < 1 || sh_dim < 0 || K * per > CD_O) return LARA2DGS_E_INVALID;
+    static_assert(CD_TILE - 16 * CD_O >= 16 * 3 * (CD_O / 10), "the backward's copy of `offset` (16 x 3K floats) must fit the tile's tail for every K with 10 K <= CD_O");
     p.n_par = K * per;
     const int widths[5] = {3, sh_dim, 2, 4, 1};   // output tensors: offset, sh, scaling, rotation, opacity
     for (int t = 0, o = 0; t < 5; t++) { p.width[t] = K * widths[t]; p.toff[t] = o; o += 16 * p.width[t]; }

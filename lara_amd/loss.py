@@ -1,8 +1,11 @@
-"""The pixel terms of LaRa's training loss on MI355X: lightning/loss.py:17-60 (without the MS-SSIM term: pytorch_msssim is
-absent from this image) over the stacked outputs of ``Network.forward``, as one HIP kernel per direction
-(``lara_loss_terms_forward`` / ``_backward``, include/lara_loss.h) instead of ~25 elementwise and reduction kernels forward
-and ~30 backward.  ``lara_loss(batch, output, it)`` has the signature and return value of ``lara_amd.pipeline.lara_loss``
-(itself the restatement of ``Losses.forward``): (loss, scalar_stats).  Opt-in; no CPU path: tensors must live on the GPU.
+"""LaRa's training loss on MI355X (lightning/loss.py:17-60) over the stacked outputs of ``Network.forward``: the pixel terms
+(colour MSE, distortion, normal consistency) as one HIP kernel per direction (``lara_loss_terms_forward`` / ``_backward``,
+include/lara_loss.h) instead of ~25 elementwise and reduction kernels forward and ~30 backward, plus the reference's
+``0.5 * (1 - MS_SSIM)`` term and its psnr / ssim statistics (loss.py:36-45) through ``ms_ssim`` below -- plain torch
+operators (the package the reference imports, `pytorch_msssim`, is absent from this image and un-pinned in the reference;
+``ms_ssim`` restates its published algorithm and is tested against an independent float64 restatement, tests/test_loss_cpu.py:
+parity with the package itself is unpinned).  ``lara_loss(batch, output, it)`` has the signature and return value of
+``Losses.forward``: (loss, scalar_stats).  The fused pixel terms have no CPU path: tensors must live on the GPU.
 """
 from __future__ import annotations
 
@@ -93,8 +96,83 @@ class _LossTerms(torch.autograd.Function):
         return None, d_image, d_fine, d_dist, d_rn, d_dn, None
 
 
-def lara_loss(batch, output, it=10000):
-    """lightning/loss.py:17-60 without MS-SSIM, fused: same arguments and return value as ``lara_amd.pipeline.lara_loss``."""
+MS_SSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+_win_cache = {}
+
+
+def _gauss_window(device, size=11, sigma=1.5):
+    key = (str(device), size, sigma)
+    if key not in _win_cache:
+        c = torch.arange(size, dtype=torch.float32) - size // 2
+        g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+        _win_cache[key] = (g / g.sum()).to(device)
+    return _win_cache[key]
+
+
+def _blur(x, win):
+    """Separable 'valid' Gaussian filter of every channel plane of x [N,C,H,W]: along H, then along W."""
+    C, k = x.shape[1], win.numel()
+    x = torch.nn.functional.conv2d(x, win.view(1, 1, k, 1).expand(C, 1, k, 1), groups=C)
+    return torch.nn.functional.conv2d(x, win.view(1, 1, 1, k).expand(C, 1, 1, k), groups=C)
+
+
+def _ssim_cs(X, Y, win, data_range=1.0, K=(0.01, 0.03)):
+    """Per-(image, channel) means of the SSIM map and of its contrast-structure factor."""
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    N = X.shape[0]
+    f = _blur(torch.cat([X, Y, X * X, Y * Y, X * Y]), win)      # the five filters of an SSIM level as one pass
+    mu1, mu2, xx, yy, xy = (f[i * N:(i + 1) * N] for i in range(5))
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    cs_map = (2 * (xy - mu12) + C2) / ((xx - mu1_sq) + (yy - mu2_sq) + C2)
+    ssim_map = ((2 * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
+    return ssim_map.flatten(2).mean(-1), cs_map.flatten(2).mean(-1)
+
+
+def ms_ssim(X, Y, data_range=1.0, win_size=11, win_sigma=1.5, weights=MS_SSIM_WEIGHTS):
+    """Multi-scale SSIM of two image batches [N,C,H,W] as `pytorch_msssim.MS_SSIM(data_range=1.0, size_average=True,
+    channel=3)` computes it (lightning/loss.py:15, :42): five scales (2 x 2 average pooling in between, odd sides
+    padded), 11-tap sigma-1.5 Gaussian windows without padding, K = (0.01, 0.03), the contrast-structure means of the
+    first four scales and the SSIM mean of the last clamped at zero, raised to the five published weights, multiplied, and
+    averaged over images and channels.  fp32 (the reference calls it under ``autocast(enabled=False)``)."""
+    if X.shape != Y.shape or X.dim() != 4:
+        raise ValueError("ms_ssim: two image batches [N,C,H,W] of the same shape expected")
+    if min(X.shape[-2:]) <= (win_size - 1) * 2 ** 4:
+        raise ValueError(f"ms_ssim: the smaller image side must exceed {(win_size - 1) * 2 ** 4} (four 2x downsamplings)")
+    if X.dtype != torch.float64 or Y.dtype != torch.float64:       # (float64 stays float64: the tests' finite differences)
+        X, Y = X.float(), Y.float()
+    win = _gauss_window(X.device, win_size, win_sigma).to(X.dtype)
+    w = torch.tensor(weights, dtype=X.dtype, device=X.device)
+    vals = []
+    for i in range(len(weights)):
+        s, cs = _ssim_cs(X, Y, win, data_range)
+        if i < len(weights) - 1:
+            vals.append(torch.relu(cs))
+            pad = [d % 2 for d in X.shape[2:]]
+            X = torch.nn.functional.avg_pool2d(X, kernel_size=2, padding=pad)
+            Y = torch.nn.functional.avg_pool2d(Y, kernel_size=2, padding=pad)
+    vals.append(torch.relu(s))
+    return torch.prod(torch.stack(vals, 0) ** w.view(-1, 1, 1), dim=0).mean()
+
+
+def ms_ssim_terms(batch, output, prexes=("", "_fine")):
+    """loss.py:36-45 for the images present: ({prex: 0.5 * (1 - MS_SSIM)}, {psnr / ssim statistics})."""
+    B, V, H, W = batch["tar_rgb"].shape[:-1]
+    tar = batch["tar_rgb"].permute(0, 2, 1, 3, 4).reshape(B, H, V * W, 3).permute(0, 3, 1, 2).float()
+    terms, stats = {}, {}
+    for prex in prexes:
+        if f"image{prex}" not in output or (prex == "_fine" and "acc_map_fine" not in output):
+            continue
+        img = output[f"image{prex}"].permute(0, 3, 1, 2).float()
+        with torch.autocast(device_type=img.device.type, enabled=False):
+            val = ms_ssim(img, tar)
+        terms[prex] = 0.5 * (1 - val)
+        stats[f"ssim{prex}"] = val.detach()
+    return terms, stats
+
+
+def lara_loss(batch, output, it=10000, ms_ssim=True):
+    """lightning/loss.py:17-60: same arguments and return value as ``Losses.forward``; the pixel terms fused, the MS-SSIM
+    term (``ms_ssim=False`` leaves it and the ssim statistics out) through torch operators."""
     if "image" not in output:
         return 0, {}
     fine = output.get("image_fine") if "acc_map_fine" in output else None                  # loss.py:31
@@ -107,9 +185,14 @@ def lara_loss(batch, output, it=10000):
         _weights[key] = torch.tensor([1.0, 1.0 if fine is not None else 0.0, 1000.0 if reg else 0.0, 0.2 if reg else 0.0], device=terms.device)
     loss = torch.dot(terms, _weights[key])
     t = terms.detach()
-    stats = {"mse": t[0]}
+    stats = {"mse": t[0], "psnr": -10.0 * torch.log10(t[0])}                                # loss.py:36-39
     if fine is not None:
-        stats["mse_fine"] = t[1]
+        stats["mse_fine"], stats["psnr_fine"] = t[1], -10.0 * torch.log10(t[1])
     if reg:
         stats["distortion"], stats["normal"] = t[2], t[3]
+    if ms_ssim:
+        extra, st = ms_ssim_terms(batch, output, ("", "_fine") if fine is not None else ("",))
+        for v in extra.values():
+            loss = loss + v                                                                  # loss.py:45
+        stats.update(st)
     return loss, stats

@@ -127,6 +127,33 @@ def check_mask(mask, training, generator=None):
     return out
 
 
+def hand_over(obj, stream):
+    """Tell the caching allocator that `stream` reads the tensor(s) in `obj` (a tensor, a Camera-like object with tensor
+    attributes, or a nested list / tuple / dict of those) although another stream allocated them.
+
+    The allocator hands a freed block back to the stream that ALLOCATED it at once, on the host's clock.  A tensor made
+    on the caller's stream and read by a scene stream -- the decoder's outputs, the subset indices, the cameras -- is
+    freed when its last Python / autograd reference goes, typically in the middle of the backward, while the scene
+    stream's kernels that read it are still queued; the next allocation on the caller's stream may get the same bytes
+    and overwrite them under the reader (that is what hung the device in round 3, with subset
+    INDICES as the overwritten tensor).  `record_stream` makes the free wait for the reader."""
+    if stream is None or obj is None:
+        return
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            hand_over(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            hand_over(v, stream)
+    elif hasattr(obj, "__dict__"):
+        for v in vars(obj).values():
+            if torch.is_tensor(v):
+                hand_over(v, stream)
+
+
 class _TakeVoxelRows(torch.autograd.Function):
     """``x.unsqueeze(1).expand(-1, K, -1)[mask.view(-1, K)]`` (network.py:509): row idx // K of x for every kept
     Gaussian.  Backward: at most K rows add into one voxel; for K <= 2 the sum of two floats does not depend on the
@@ -245,6 +272,8 @@ class LaRaPipeline(nn.Module):
         for s in sides:
             if s is not None:
                 s.wait_stream(cur)
+                # made on the caller's stream, read (and saved for the backward) on the scene streams
+                hand_over((g, inps, cams_of), s)
 
         # per-scene tensors: one unbind per tensor (its backward is one stack; `x[i]` per use would cost a zero-filled
         # [B,P,C] buffer and an accumulation for every use)
@@ -265,8 +294,10 @@ class LaRaPipeline(nn.Module):
             for s in sides:
                 if s is not None:
                     s.wait_stream(cur)
+                    hand_over((masks, folded), s)
             for i in range(B):                                                  # network.py:502-525
                 s = sides[i % len(sides)]
+                hand_over(idx[i], s)
                 with on(s):
                     co = per_scene[i]
                     H, VW = co["acc_map"].shape
@@ -285,9 +316,11 @@ class LaRaPipeline(nn.Module):
                         bg_colors=batch["bg_color"][i], prex="_fine", concat=True))
                     self._mark("fine views")
         outs = per_scene                                                        # network.py:527: already [H, V*W, C] per key
-        for s in sides:
+        for i, s in enumerate(sides):
             if s is not None:
                 cur.wait_stream(s)
+        if sides[0] is not None:
+            hand_over(per_scene, cur)       # made on the scene streams, read by the stack below on the caller's
         out = {k: torch.stack([o[k] for o in outs]) for k in outs[0]}           # network.py:529
         self._mark("outputs")
         return out
@@ -300,19 +333,28 @@ class LaRaPipeline(nn.Module):
             cur.wait_stream(s)
 
 
-def lara_loss(batch, output, it=10000):
-    """lightning/loss.py:17-60 without the MS-SSIM term (pytorch_msssim is absent from this image): colour MSE for the
-    coarse and the fine images, and after iteration 1000 the coarse pass's distortion (x 1000) and normal-consistency
-    (x 0.2) terms.  Returns (loss, scalar_stats)."""
+def lara_loss(batch, output, it=10000, ms_ssim=True):
+    """lightning/loss.py:17-60 as plain torch: colour MSE and ``0.5 * (1 - MS_SSIM)`` (``lara_amd.loss.ms_ssim``: the
+    restatement of the absent `pytorch_msssim` package; ``ms_ssim=False`` leaves the term out) for the coarse and the fine
+    images, and after iteration 1000 the coarse pass's distortion (x 1000) and normal-consistency (x 0.2) terms.  Returns
+    (loss, scalar_stats) with the reference's keys (mse, psnr, ssim, distortion, normal; `_fine` variants)."""
+    from .loss import ms_ssim_terms
     B, V, H, W = batch["tar_rgb"].shape[:-1]
     tar = batch["tar_rgb"].permute(0, 2, 1, 3, 4).reshape(B, H, V * W, 3)
     loss, stats = 0, {}
     for prex in ("", "_fine"):
         if f"image{prex}" not in output:
             continue
+        if prex == "_fine" and "acc_map_fine" not in output:                    # loss.py:31
+            continue
         mse = ((output[f"image{prex}"] - tar) ** 2).mean()
         loss = loss + mse
         stats[f"mse{prex}"] = mse.detach()
+        stats[f"psnr{prex}"] = -10.0 * torch.log10(mse.detach())               # loss.py:36-39
+        if ms_ssim:
+            extra, st = ms_ssim_terms(batch, output, (prex,))
+            loss = loss + extra[prex]                                           # loss.py:41-45
+            stats.update(st)
         if f"rend_dist{prex}" in output and it > 1000 and prex != "_fine":
             dist = output[f"rend_dist{prex}"].mean()
             err = ((1 - (output[f"rend_normal{prex}"] * output[f"depth_normal{prex}"]).sum(dim=-1))

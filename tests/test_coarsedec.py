@@ -104,9 +104,11 @@ def test_hip_matches_the_reference_fixture(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,sh_dim", [(1, 2, 12), (127, 2, 12), (128, 1, 12), (4097, 2, 3), (1000, 1, 27), (70000, 2, 12)])
+@pytest.mark.parametrize("M,K,sh_dim", [(1, 2, 12), (127, 2, 12), (128, 1, 12), (4097, 2, 3), (1000, 1, 27), (70000, 2, 12),
+                                         (777, 3, 3), (300, 3, 6)])
 def test_hip_matches_the_oracle_on_other_sizes(hip_lib, M, K, sh_dim):
-    """Ragged row counts (the kernel works in trips of 128 rows, 32 per wave), other K / SH sizes, some gradients absent."""
+    """Ragged row counts (the kernel works in trips of 128 rows, 32 per wave), other K / SH sizes (K = 3: the backward's
+    copy of `offset` is 16 x 3K floats per wave tile -- ADVICE r3: it used to be sized for K <= 2), some gradients absent."""
     from lara_amd import coarse
     torch.manual_seed(M + K)
     dec = _decoder(None, K, sh_dim)

@@ -101,7 +101,7 @@ def _rccl_worker(port, out):
         def grads(model):
             for p in pipe.parameters():
                 p.grad = None
-            loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=True), 2000)
+            loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=True), 2000, ms_ssim=False)
             loss.backward()
             pipe.join_streams()
             torch.cuda.synchronize()

@@ -1,0 +1,132 @@
+"""The configuration the headline times (BASELINE.json configs[2]: P = 524 288 surfels, 8 views, 512 x 512, 4 scenes on two
+scene streams), held to the same bars as the small cases:
+
+* the multi-view launch (`blockIdx.z` = view, 8 x 282 MB of state at a stride -- the 64-bit strides, the capacity carving
+  of `ckpt` / `pair_mask` and the one-launch `preprocess_bwd_views` fold only meet their real sizes here) against the
+  per-view operator: outputs and summed gradients bit for bit, one view against the CPU oracle;
+* `LaRaPipeline` (lightning/network.py:473-527) with two scene streams against one stream over 50 training steps whose
+  fine subsets change size every step.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import oracle_view, raster_settings, run_oracle, to_numpy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_multi_view_launch_at_benchmark_size_equals_the_per_view_operator_and_the_oracle(hip_lib):
+    from lara_amd import GaussianRasterizer, cameras, rasterize_gaussians_views, rasterizer, synthetic
+    from tests.test_raster_parity_gpu import _check_forward
+    P, n, S = 524288, 8, 512
+    act = synthetic.activate(synthetic.make_scene(grid=64, K=2, seed=0))
+    assert act["means3D"].shape[0] == P
+    cams = cameras.make_cameras(cameras.turntable_c2w(n), S, S, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8)
+    bgs = [(1.0, 1.0, 1.0)] * 4 + [(0.0, 0.0, 0.0), (0.5, 0.5, 0.5), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)]   # gobjverse.py:103-106
+    settings = [raster_settings(c, bg, device=DEV) for c, bg in zip(cams, bgs)]
+    g = torch.Generator().manual_seed(5)
+    dc = torch.randn(n, 3, S, S, generator=g).to(DEV)
+    da = (torch.randn(n, 7, S, S, generator=g) * 0.1).to(DEV)
+    leaves = lambda: {k: v.to(DEV).clone().requires_grad_(True) for k, v in act.items()}
+
+    inp = leaves()
+    color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+    node = color.grad_fn
+    state, sb, cap = node.saved_tensors[7], node.sb, node.cap
+    ((color * dc).sum() + (allmap * da).sum()).backward()
+    torch.cuda.synchronize()
+
+    want = None
+    for i, rs in enumerate(settings):
+        li = leaves()
+        c, r, a = GaussianRasterizer(rs)(means3D=li["means3D"], means2D=None, shs=li["shs"], opacities=li["opacities"],
+                                         scales=li["scales"], rotations=li["rotations"])
+        ((c * dc[i]).sum() + (a * da[i]).sum()).backward()
+        assert torch.equal(color[i].detach(), c.detach()), f"view {i}: colour"
+        assert torch.equal(allmap[i].detach(), a.detach()), f"view {i}: allmap"
+        assert torch.equal(radii[i], r), f"view {i}: radii"
+        gi = {k: v.grad for k, v in li.items()}
+        want = gi if want is None else {k: want[k] + gi[k] for k in gi}            # view order, as the library folds them
+    for k in want:
+        assert torch.equal(inp[k].grad, want[k]), f"grad {k}: max diff {(inp[k].grad - want[k]).abs().max().item():.3e}"
+
+    # view 5 (grey background, a novel view) of the multi-view launch against the oracle, the integer surface included
+    v = 5
+    views = rasterizer.state_views(state.view(n, sb)[v], P, S, S, cap)
+    r = {"views": views, "radii": radii[v], "color": color[v].detach(), "allmap": allmap[v].detach()}
+    D = _check_forward(r, run_oracle(oracle_view(cams[v], bgs[v]), to_numpy(act)), S, S)
+    assert 1_000_000 < D < 3_000_000
+    rasterizer.check_pending(block=True)
+
+
+def _full_size_pipeline(dev, layers=2):
+    from lara_amd.batch import synthetic_batch
+    from lara_amd.encoder_train import VolTransformer
+    from lara_amd.pipeline import CoarseFineDecoder, LaRaPipeline
+    torch.manual_seed(0)
+    enc = VolTransformer(256, 800, [16], 32, 64, 80, layers, 16)
+    pipe = LaRaPipeline(enc, CoarseFineDecoder(), grid_reso=32, n_streams=2).to(dev)
+    pipe.fine_mask = "reference"
+    pipe.train()
+    batch = synthetic_batch(batch_size=4, n_views=8, H=512, W=512, n_input=4, seed=7, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    batch["tar_rgb"] = torch.rand(batch["tar_rgb"].shape, generator=g).to(dev)
+    feat_vol = torch.randn(4, 4, 800, 16, 16, 16, generator=g).to(dev).requires_grad_(True)
+    return pipe, batch, feat_vol
+
+
+def test_pipeline_at_benchmark_size_two_scene_streams_equal_one_over_50_steps(hip_lib):
+    """4 scenes x (8 coarse + 8 fine) views at P = 524 288 / 512^2, `_check_mask` thinning the fine subsets at random so
+    that their sizes (and with them every buffer size of the fine pass) change with every step; step k with two scene
+    streams must give the outputs of step k on one stream bit for bit and the same gradients (the sampler's image
+    gradient adds with float atomics: 1e-5 of max there, everything else the same bits)."""
+    from lara_amd import rasterizer
+    from lara_amd.loss import lara_loss
+    dev = torch.device(DEV)
+    pipe, batch, feat_vol = _full_size_pipeline(dev)
+    params = [p for p in pipe.parameters() if p.requires_grad]
+    sizes_seen = set()
+    orig = pipe.gs_render.render_views
+
+    def spy(cams, rays, centers, *a, **k):
+        sizes_seen.add(int(centers.shape[0]))
+        return orig(cams, rays, centers, *a, **k)
+    pipe.gs_render.render_views = spy
+
+    def run(step, n_streams):
+        pipe.n_streams = n_streams
+        torch.manual_seed(1000 + step)               # the same random thinning in both runs
+        for p in params:
+            p.grad = None
+        feat_vol.grad = None
+        out = pipe(batch, feat_vol, with_fine=True)
+        loss, _ = lara_loss(batch, out, 2000)
+        loss.backward()
+        pipe.join_streams()
+        keep = {k: out[k].detach() for k in ("image", "image_fine", "acc_map", "rend_dist", "depth_fine")}
+        grads = [p.grad for p in params] + [feat_vol.grad]
+        return keep, float(loss), grads
+
+    worst = 0.0
+    for step in range(50):
+        o2, l2, g2 = run(step, 2)
+        o1, l1, g1 = run(step, 1)
+        for k in o1:
+            assert torch.equal(o1[k], o2[k]), f"step {step}: output {k} differs between one and two scene streams"
+        assert l1 == l2, (step, l1, l2)
+        for a, b in zip(g1, g2):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.isfinite(b).all()
+                d = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-30)
+                worst = max(worst, d)
+                assert d <= 1e-4, (step, d)
+    torch.cuda.synchronize()
+    rasterizer.check_pending(block=True)
+    # the fine subsets really changed size: P for the coarse pass + a different count per (step, scene)
+    assert 524288 in sizes_seen and len(sizes_seen) > 100, len(sizes_seen)
+    print(f"two-stream vs one-stream over 50 full-size steps: outputs bit-identical, worst gradient difference {worst:.2e} of max; "
+          f"{len(sizes_seen) - 1} distinct fine-subset sizes")
