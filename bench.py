@@ -80,6 +80,10 @@ def parse():
                          "opt-in, SURVEY.md section 8f-2); loop: one GaussianRasterizer call per view, as the reference's loop issues them")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent scenes of a step are spread over (1 = the reference's sequential loop)")
+    ap.add_argument("--ms-ssim", action="store_true",
+                    help="add the reference's 0.5 (1 - MS_SSIM) term (loss.py:41-45) to the timed step's loss: lara_amd.loss.ms_ssim, plain "
+                         "torch operators (outside SURVEY.md section 8; the package the reference imports is absent).  Default: the "
+                         "step is timed WITHOUT it (the workload string says so) and `step_with_ms_ssim` reports the step with it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the side objects (attention, encoder, rays, ...)")
@@ -1137,14 +1141,20 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     params = [p for p in pipe.parameters() if p.requires_grad]
     with_fine = not args.no_fine
 
-    def full_step():
+    poison = os.environ.get("LARA2DGS_POISON_BUFFERS") == "1"
+
+    def full_step(ms_ssim=args.ms_ssim):
         out = model(batch, feat_vol, with_fine=with_fine)
-        loss, _ = lara_loss(batch, out, 2000)       # past iteration 1000: distortion + normal terms are on (loss.py:48)
+        loss, _ = lara_loss(batch, out, 2000, ms_ssim=ms_ssim)       # past iteration 1000: distortion + normal terms are on (loss.py:48)
         loss.backward()
         pipe.join_streams()
         for p in params:
             p.grad = None
         feat_vol.grad = None
+        if poison:      # debugging mode: every state / scratch buffer 0xFF-filled between guard zones; checked (and released) per step
+            bad = rasterizer.check_poison_guards()
+            if bad:
+                raise SystemExit(f"bench.py: a kernel wrote beyond the end of a state / scratch buffer (payload sizes {bad})")
 
     def after_first_step():
         if info["grad_allreduce"] is not None:
@@ -1183,7 +1193,7 @@ def ddp_single_rank_leg(info, args, device):
         params = [p for p in pipe.parameters() if p.requires_grad]
 
         def one():
-            loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=not args.no_fine), 2000)
+            loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=not args.no_fine), 2000, ms_ssim=False)
             loss.backward()
             pipe.join_streams()
             for p in params:
@@ -1226,7 +1236,7 @@ def pipeline_breakdown(info, args):
         torch.cuda.synchronize()
         pipe.stage_events = []
         out = pipe(batch, feat_vol, with_fine=not args.no_fine)
-        loss, _ = lara_loss(batch, out, 2000)
+        loss, _ = lara_loss(batch, out, 2000, ms_ssim=False)
         e_l = torch.cuda.Event(enable_timing=True); e_l.record()
         loss.backward()
         pipe.join_streams()
@@ -1447,7 +1457,7 @@ def main():
         "data": "synthetic" if not plumbing else "PLUMBING SELF-TEST (no GPU work; not a measurement)",
         "config": {
             "workload": (
-                (f"configs[2]: the whole data-dependent LaRa training step (lightning/network.py:455-532 + loss.py minus MS-SSIM), per GPU "
+                (f"configs[2]: the whole data-dependent LaRa training step (lightning/network.py:455-532 + loss.py {'WITH its MS-SSIM term (torch operators)' if args.ms_ssim else 'minus MS-SSIM'}), per GPU "
                  f"{args.scenes} scenes: VolTransformer ({enc['layers']} layers, {enc['parameters'] / 1e6:.2f} M parameters) -> coarse decoder MLP "
                  f"-> {args.views} coarse views/scene -> " + ("" if args.no_fine else f"_check_mask ({args.fine_mask}) -> point sampler on 4 input views -> "
                  f"forward_fine -> {args.views} fine views/scene -> ") + f"loss -> ONE backward through all of it; @{args.res}x{args.res}, P={P} "
@@ -1474,6 +1484,23 @@ def main():
     if solo and args.step == "pipeline" and not args.no_roofline:
         _leg("stages")
         out["stages"] = pipeline_breakdown(info, args)
+    if solo and args.step == "pipeline" and not args.no_side_legs and not args.ms_ssim and args.res > 160:
+        # the same step with the reference's 0.5 (1 - MS_SSIM) term in the loss (loss.py:41-45): plain torch operators (outside
+        # SURVEY.md section 8; `pytorch_msssim` itself is absent), so the like-for-like figure sits beside `value`
+        _leg("step_with_ms_ssim")
+        fs = info["pipeline"][3]
+        for _ in range(2):
+            fs(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fs(True)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        out["step_with_ms_ssim"] = {"value": round(frames_per_step * args.steps / d1, 3), "unit": "frames/s",
+                                    "ms_per_step": round(1e3 * d1 / args.steps, 3),
+                                    "what": "the headline step + 0.5 (1 - MS_SSIM) for the coarse and the fine image (lara_amd.loss.ms_ssim: "
+                                            "torch matmul / pooling operators, fp32, no HIP kernel of this repo)"}
     if solo and args.step == "pipeline" and not args.no_roofline and not args.no_side_legs:
         try:
             _leg("ddp_single_rank_rccl")

@@ -109,11 +109,36 @@ def _gauss_window(device, size=11, sigma=1.5):
     return _win_cache[key]
 
 
-def _blur(x, win):
-    """Separable 'valid' Gaussian filter of every channel plane of x [N,C,H,W]: along H, then along W."""
-    C, k = x.shape[1], win.numel()
-    x = torch.nn.functional.conv2d(x, win.view(1, 1, k, 1).expand(C, 1, k, 1), groups=C)
-    return torch.nn.functional.conv2d(x, win.view(1, 1, 1, k).expand(C, 1, 1, k), groups=C)
+_band_cache = {}
+
+
+def _band(win, n_in, n_out, device, dtype):
+    """[n_in, n_out] matrix B with B[j + i, j] = win[i]: x @ B = the 'valid' correlation of x's last dimension with win."""
+    key = (str(device), dtype, win.numel(), n_in, n_out, float(win[0]))
+    if key not in _band_cache:
+        k = win.numel()
+        B = torch.zeros(n_in, n_out, dtype=dtype, device=device)
+        j = torch.arange(n_out, device=device)
+        for i in range(k):
+            B[j + i, j] = win[i].to(dtype)
+        _band_cache[key] = B
+    return _band_cache[key]
+
+
+def _blur(x, win, block=128):
+    """Separable 'valid' Gaussian filter of every channel plane of x [N,C,H,W], along H then along W, as two matrix
+    products with banded matrices (the filter along H as one [H-k+1, H] band from the left; along W in blocks of `block`
+    outputs with a k-1 halo, so that the band stays 138 wide whatever W is).  Same sums as the two depthwise
+    convolutions `pytorch_msssim` issues; on this ROCm build a grouped `conv2d` over [60, 512, 4096] planes takes tens of
+    milliseconds, the two products a fraction of one."""
+    k = win.numel()
+    H, W = x.shape[-2:]
+    x = torch.matmul(_band(win, H, H - k + 1, x.device, x.dtype).t(), x)            # along H
+    n_out = W - k + 1
+    nb = -(-n_out // block)
+    xp = torch.nn.functional.pad(x, (0, nb * block + k - 1 - W))
+    y = torch.matmul(xp.unfold(-1, block + k - 1, block), _band(win, block + k - 1, block, x.device, x.dtype))
+    return y.flatten(-2)[..., :n_out]
 
 
 def _ssim_cs(X, Y, win, data_range=1.0, K=(0.01, 0.03)):

@@ -71,7 +71,7 @@ def accumulation_allocates_on_consumer_stream(carved: bool, n: int = 1 << 20) ->
     x = torch.randn(2, n, device=dev, requires_grad=True)
     a, b = x.unbind(0)                                 # UnbindBackward lives on the caller's stream
     seen = {}
-    a.register_hook(lambda g: seen.setdefault("ptr", g.data_ptr()))
+    a.register_hook(lambda g: seen.update(ptr=g.data_ptr()))
     side.wait_stream(cur)
     with torch.cuda.stream(side):                      # two consumers of `a` on the side stream: their gradients meet in a's slot
         p, q = _TwoGrads.apply(a, b, carved)           # (in the pipeline: the subset gather and the coarse views' rasteriser node)

@@ -1,0 +1,83 @@
+// traffic_calib.hip -- known-byte-count kernels in the access patterns this library uses, to calibrate rocprofv3's
+// FETCH_SIZE / WRITE_SIZE on gfx950 (MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of a 16 B/lane streaming
+// read; other widths and WRITE_SIZE uncalibrated).  Every buffer is far larger than the 256 MiB Infinity Cache and is
+// touched exactly once per launch, so the bytes that must cross the HBM interface are known:
+//   stream4 / stream16   coalesced 4 B / 16 B per lane, read N and write N
+//   rec80_seq            thread i reads record i = five float4 at an 80-byte stride (preprocess_fwd's output pattern read back)
+//   rec80_gather         thread i reads idx[i] (4 B, coalesced) and then the 80-byte record idx[i] with five float4 loads:
+//                        the composite kernels' staging pattern.  idx is a permutation: every record, hence every 128-byte
+//                        line of the record array, is needed exactly once per launch -- but a record straddles a line
+//                        boundary 3 times in 8, so lines are requested 1.375 times on average unless the second request hits in L2
+//   line128_gather       idx[i] -> a 128-byte aligned, 128-byte record (eight float4): one full line per record, no ambiguity
+// build: hipcc --offload-arch=gfx950 -O2 tools/ubench/traffic_calib.hip -o tools/ubench/traffic_calib
+// run:   rocprofv3 --kernel-trace --pmc FETCH_SIZE -- tools/ubench/traffic_calib     (and again with WRITE_SIZE)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+__global__ void stream4(const float *__restrict__ in, float *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + 1.0f;
+}
+__global__ void stream16(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float4 v = in[i]; v.x += 1.0f; out[i] = v; }
+}
+__global__ void rec80_seq(const float4 *__restrict__ rec, float *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 *r = rec + i * 5;
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
+    out[i] = a.x + b.y + c.z + d.w + e.x;
+}
+__global__ void rec80_gather(const uint32_t *__restrict__ idx, const float4 *__restrict__ rec, float *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 *r = rec + (size_t)idx[i] * 5;
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
+    out[i] = a.x + b.y + c.z + d.w + e.x;
+}
+__global__ void line128_gather(const uint32_t *__restrict__ idx, const float4 *__restrict__ rec, float *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 *r = rec + (size_t)idx[i] * 8;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += r[k].x;
+    out[i] = s;
+}
+// idx[i] = (i * A + B) mod n with A odd and n a power of two: a permutation with no locality
+__global__ void fill_perm(uint32_t *idx, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (uint32_t)((i * 2654435761ull + 12345ull) & (n - 1));
+}
+__global__ void fill_f(float *p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (float)(i & 1023) * 1e-3f;
+}
+
+int main() {
+    const size_t N = (size_t)1 << 24;                 // 16.8 M threads / records
+    float *big, *out; uint32_t *idx;
+    if (hipMalloc(&big, N * 128) != hipSuccess || hipMalloc(&out, N * 16) != hipSuccess || hipMalloc(&idx, N * 4) != hipSuccess) return 1;
+    const unsigned blk = 256;
+    auto grid = [&](size_t n) { return dim3((unsigned)((n + blk - 1) / blk)); };
+    hipLaunchKernelGGL(fill_f, grid(N * 32), dim3(blk), 0, 0, big, N * 32);
+    hipLaunchKernelGGL(fill_perm, grid(N), dim3(blk), 0, 0, idx, N);
+    (void)hipDeviceSynchronize();
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(stream4, grid(N * 16), dim3(blk), 0, 0, big, big + N * 16, N * 16);                          // 1 GiB in, 1 GiB out
+        hipLaunchKernelGGL(stream16, grid(N * 4), dim3(blk), 0, 0, (const float4 *)big, (float4 *)(big + N * 16), N * 4); // 1 GiB in, 1 GiB out
+        hipLaunchKernelGGL(rec80_seq, grid(N), dim3(blk), 0, 0, (const float4 *)big, out, N);
+        hipLaunchKernelGGL(rec80_gather, grid(N), dim3(blk), 0, 0, idx, (const float4 *)big, out, N);
+        hipLaunchKernelGGL(line128_gather, grid(N), dim3(blk), 0, 0, idx, (const float4 *)big, out, N);
+    }
+    (void)hipDeviceSynchronize();
+    printf("{\"N\": %zu, \"known_bytes\": {"
+           "\"stream4\": {\"read\": %zu, \"write\": %zu}, \"stream16\": {\"read\": %zu, \"write\": %zu}, "
+           "\"rec80_seq\": {\"read\": %zu, \"write\": %zu}, "
+           "\"rec80_gather\": {\"read\": %zu, \"read_if_straddling_lines_fetched_twice\": %zu, \"write\": %zu}, "
+           "\"line128_gather\": {\"read\": %zu, \"write\": %zu}}}\n",
+           N, N * 64, N * 64, N * 64, N * 64, N * 80, N * 4, N * 84, N * 4 + (size_t)(N * 80 * 1.375), N * 4, N * 132, N * 4);
+    return 0;
+}
