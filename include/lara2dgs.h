@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LARA2DGS_ABI_VERSION 7
+#define LARA2DGS_ABI_VERSION 8
 
 #define LARA2DGS_OK 0
 #define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
@@ -96,6 +96,8 @@ typedef struct lara2dgs_state_layout {
     int64_t pair_mask;   /* uint64[capacity]: per list position, the forward's candidate mask of the entry over the tile's
                           * 8x8 grid of 2x2 pixel blocks (bit gy*8+gx); the backward reads it instead of scan-converting
                           * the surfel's footprint a second time */
+    int64_t tile_maxc;   /* uint32[tiles]: the largest last-contributor position over the tile's pixels, written by the forward
+                          * composite: a backward work item (tile, segment) beyond it exits on its first load */
     int64_t total;
 } lara2dgs_state_layout;
 

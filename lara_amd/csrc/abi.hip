@@ -103,6 +103,7 @@ StateView carve_state(const ViewDev &v, void *state) {
     s.bwd_items = (uint2 *)(b + L.bwd_items);
     s.ckpt = (float *)(b + L.ckpt);
     s.pair_mask = (uint2 *)(b + L.pair_mask);
+    s.tile_maxc = (uint32_t *)(b + L.tile_maxc);
     return s;
 }
 

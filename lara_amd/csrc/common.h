@@ -65,6 +65,7 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     uint2 *bwd_items;     // [cap/L2D_SEG+1] (tile, segment) of every full segment
     float *ckpt;          // [cap/L2D_SEG+1][L2D_CKPT_F][256] per-pixel prefix sums at segment boundaries
     uint2 *pair_mask;     // [cap] per list position: the forward's 64-bit candidate mask (lo, hi) of the entry
+    uint32_t *tile_maxc;  // [tiles] max over the tile's pixels of the last contributor (list position + 1), from the forward
 };
 
 struct ScratchView {
@@ -108,6 +109,7 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->bwd_items = o;   o = align_up(o + nseg * 8, 256);
     L->ckpt = o;        o = align_up(o + l2d_ckpt_slots(cap) * L2D_CKPT_F * 256 * 4, 256);
     L->pair_mask = o;   o = align_up(o + cap * 8, 256);
+    L->tile_maxc = o;   o = align_up(o + tiles * 4, 256);
     L->total = o;
 }
 

@@ -305,7 +305,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
-                     float *__restrict__ ckpt, uint2 *__restrict__ pair_mask,
+                     float *__restrict__ ckpt, uint2 *__restrict__ pair_mask, uint32_t *__restrict__ tile_maxc,
                      float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs,
                      const ViewBatch vb) {
     {   // this workgroup's view (blockIdx.z; a single-view launch has strides 0)
@@ -314,6 +314,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         geom = l2d_view_ptr(geom, sst); tile_order = l2d_view_ptr(tile_order, sst); cullbox = l2d_view_ptr(cullbox, sst);
         final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
         seg_cnt = l2d_view_ptr(seg_cnt, sst); ckpt = l2d_view_ptr(ckpt, sst); pair_mask = l2d_view_ptr(pair_mask, sst);
+        tile_maxc = l2d_view_ptr(tile_maxc, sst);
         slabs = l2d_view_ptr(slabs, vb.scratch_stride);
         out_color = l2d_view_ptr(out_color, vb.n ? 3 * HWb : 0); out_allmap = l2d_view_ptr(out_allmap, vb.n ? 7 * HWb : 0);
         if (vb.n) v.bg = vb.bg[blockIdx.z];
@@ -322,6 +323,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     static_assert(L2D_SEG % FWD_CHUNK == 0, "segment boundaries must fall on round boundaries");
     __shared__ float4 rec[REC4 * CHUNK];
     __shared__ unsigned long long qmask[4][16][CHUNK / 64];  // per wave, per quad: candidate words of the round
+    __shared__ uint32_t s_tmax;                               // largest last contributor over the tile's pixels
     const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -492,6 +494,16 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         return;
     }
 
+    {   // the backward's work items of this tile end at the deepest contributor of any of its pixels: one word per tile
+        if (threadIdx.x == 0) s_tmax = 0u;
+        __syncthreads();
+        uint32_t m = px.last_contributor;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if (lane == 0) atomicMax(&s_tmax, m);
+        __syncthreads();
+        if (threadIdx.x == 0) tile_maxc[tile] = s_tmax;
+    }
     if (inside) {
         final_T[pix] = T;
         final_T[pix + HW] = px.M1;
@@ -527,10 +539,11 @@ __global__ void __launch_bounds__(256)
 composite_fwd_combine_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                              const uint32_t *__restrict__ tile_order, float *__restrict__ final_T,
                              uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ seg_base,
-                             const uint32_t *__restrict__ seg_cnt, float *__restrict__ ckpt, float *__restrict__ out_color,
-                             float *__restrict__ out_allmap, float *__restrict__ slabs, const ViewBatch vb) {
+                             const uint32_t *__restrict__ seg_cnt, float *__restrict__ ckpt, uint32_t *__restrict__ tile_maxc,
+                             float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs, const ViewBatch vb) {
     {
         const long long sst = vb.state_stride, HWb = (long long)v.H * v.W * 4;
+        tile_maxc = l2d_view_ptr(tile_maxc, sst);
         header = l2d_view_ptr(header, sst); ranges = l2d_view_ptr(ranges, sst); tile_order = l2d_view_ptr(tile_order, sst);
         final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
         seg_cnt = l2d_view_ptr(seg_cnt, sst); ckpt = l2d_view_ptr(ckpt, sst); slabs = l2d_view_ptr(slabs, vb.scratch_stride);
@@ -573,6 +586,14 @@ composite_fwd_combine_kernel(ViewDev v, const uint32_t *__restrict__ header, con
         if (lc) last = lc;
         done = sl[FS_DONE * 256] != 0.f;
     }
+    {
+        __shared__ uint32_t s_tmax;
+        if (threadIdx.x == 0) s_tmax = 0u;
+        __syncthreads();
+        atomicMax(&s_tmax, last);
+        __syncthreads();
+        if (threadIdx.x == 0) tile_maxc[tile] = s_tmax;
+    }
     if (!inside) return;
     final_T[pix] = T; final_T[pix + HW] = M1; final_T[pix + 2 * HW] = M2;
     final_T[pix + 3 * HW] = C0; final_T[pix + 4 * HW] = C1; final_T[pix + 5 * HW] = C2;
@@ -602,25 +623,62 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_full(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
 }
-// step 1 (xor 1): lane keeps the 11 values of its own parity; step 2 (xor 2): keeps every second of
-// those.  Result: r[i] = quad sum of g[4i + (lane&3)], i = 0..4; r[5] = quad sum of g[20 + (lane&1)]
-// (valid in lanes with bit 1 clear).
-__device__ __forceinline__ void quad_reduce_scatter(const float g[22], float r[6], const int lane) {
+// The quad's 2x2 pixels are lanes 0..3 = (x, y) in {(0,0), (1,0), (0,1), (1,1)} of the block.  22 sums over the four lanes
+// land 5-6 per lane (slot float 4 i + lane&3 = r[i]; r[5] in lanes 0, 1 only):
+//
+//   rows 0-2 (one per component c of dp = dL/dp):  lane 0: S_c = sum dp_c    lane 1: sum lx dp_c    lane 2: sum ly dp_c
+//                                                  lane 3: sum q_c  (q = three more values: here dz sx, dz sy, dz)
+//   The pixel offsets are lx = bx + x, ly = by + y, so sum lx dp = bx S + (dp1 + dp3), sum ly dp = by S + (dp2 + dp3): partial
+//   sums the butterfly forms anyway.  After step 1 (xor 1) every lane holds its row's t = dp + dp', q-row sum tq; step 2
+//   exchanges  mine = a1 t + a2 dp + a3 tq  against the partner's  send = b1 t + b2 dp + b3 tq  with per-LANE constants
+//     lane 0: mine = t            send = by t            -> t0 + t2                     = S
+//     lane 2: mine = (by+1) t     send = t               -> by t0 + (by+1) t2           = sum ly dp
+//     lane 1: mine = bx t + dp    send = tq              -> bx (t0 + t2) + dp1 + dp3    = sum lx dp
+//     lane 3: mine = tq           send = bx t + dp       -> tq0 + tq2                   = sum q
+//   i.e. 3 DPP adds + 6 full-rate multiply-adds for four sums, against 3.1 DPP adds + 5.8 (half-rate) selects + the two
+//   lx / ly products in the plain reduce-scatter.  (Every input is an exact zero on a lane that does not contribute and finite
+//   elsewhere, so the zero coefficients are harmless.)
+//   rows 3-5: the plain reduce-scatter of the other ten values h: r[3] = sum h[lane&3], r[4] = sum h[4 + lane&3],
+//   r[5] = sum h[8 + lane&1].
+struct QuadCoef { float a1, a2, a3, b1, b2, b3; };
+__device__ __forceinline__ QuadCoef quad_coef(const int lane, const float lx, const float ly) {
+    QuadCoef k;
+    const int l = lane & 3;
+    k.a1 = l == 0 ? 1.f : (l == 1 ? lx - 1.f : (l == 2 ? ly : 0.f));
+    k.a2 = l == 1 ? 1.f : 0.f;
+    k.a3 = l == 3 ? 1.f : 0.f;
+    k.b1 = l == 0 ? ly : (l == 2 ? 1.f : (l == 3 ? lx - 1.f : 0.f));
+    k.b2 = l == 3 ? 1.f : 0.f;
+    k.b3 = l == 1 ? 1.f : 0.f;
+    return k;
+}
+__device__ __forceinline__ void quad_reduce_scatter(const float dp[3], const float q[3], const float h[10], const QuadCoef &k,
+                                                    float r[6], const int lane) {
     const bool b0 = lane & 1, b1 = lane & 2;
-    float v1[11];
 #pragma unroll
-    for (int i = 0; i < 11; i++) {
-        const float mine = b0 ? g[2 * i + 1] : g[2 * i];
-        const float send = b0 ? g[2 * i] : g[2 * i + 1];
-        v1[i] = mine + dpp_full<0xB1>(send);  // quad_perm [1,0,3,2]
+    for (int c = 0; c < 3; c++) {
+        float d = dp[c];
+        asm volatile("" : "+v"(d));      // (left alone, the compiler re-associates dp + dpp(dp) into v_mov 0 + v_mov_dpp + v_fmac)
+        const float t = d + dpp_full<0xB1>(d);           // quad_perm [1,0,3,2]
+        const float tq = q[c] + dpp_full<0xB1>(q[c]);
+        const float mine = k.a1 * t + (k.a2 * d + k.a3 * tq);
+        const float send = k.b1 * t + (k.b2 * d + k.b3 * tq);
+        r[c] = mine + dpp_full<0x4E>(send);              // quad_perm [2,3,0,1]
     }
+    float v1[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
+        const float mine = b0 ? h[2 * i + 1] : h[2 * i];
+        const float send = b0 ? h[2 * i] : h[2 * i + 1];
+        v1[i] = mine + dpp_full<0xB1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
         const float mine = b1 ? v1[2 * i + 1] : v1[2 * i];
         const float send = b1 ? v1[2 * i] : v1[2 * i + 1];
-        r[i] = mine + dpp_full<0x4E>(send);  // quad_perm [2,3,0,1]
+        r[3 + i] = mine + dpp_full<0x4E>(send);
     }
-    r[5] = v1[10] + dpp_full<0x4E>(v1[10]);
+    r[5] = v1[4] + dpp_full<0x4E>(v1[4]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -657,7 +715,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
                      const uint32_t *__restrict__ bwd_order,
                      const uint2 *__restrict__ bwd_items, const float *__restrict__ ckpt,
-                     const uint2 *__restrict__ pair_mask,
+                     const uint2 *__restrict__ pair_mask, const uint32_t *__restrict__ tile_maxc,
                      const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                      const uint32_t *__restrict__ pair_pos,
                      float4 *__restrict__ pair_grad, uint8_t *__restrict__ pair_valid, const ViewBatch vb) {
@@ -668,6 +726,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
         seg_cnt = l2d_view_ptr(seg_cnt, sst); bwd_order = l2d_view_ptr(bwd_order, sst); bwd_items = l2d_view_ptr(bwd_items, sst);
         ckpt = l2d_view_ptr(ckpt, sst); pair_mask = l2d_view_ptr(pair_mask, sst); pair_pos = l2d_view_ptr(pair_pos, sst);
+        tile_maxc = l2d_view_ptr(tile_maxc, sst);
         pair_grad = l2d_view_ptr(pair_grad, qst); pair_valid = l2d_view_ptr(pair_valid, qst);
         dL_dcolor = l2d_view_ptr(dL_dcolor, vb.n ? 3 * HWb : 0); dL_dallmap = l2d_view_ptr(dL_dallmap, vb.n ? 7 * HWb : 0);
         if (vb.n) v.bg = vb.bg[blockIdx.z];
@@ -679,7 +738,6 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __shared__ unsigned long long s_live[SLAB_CHUNK];  // an entry's candidate blocks whose quad still walks it
     __shared__ uint32_t s_ql[64];            // per 2x2 block: last contributor over its four pixels
     __shared__ uint32_t s_id[WIN];
-    __shared__ uint32_t s_maxc;
     __shared__ int s_nfit;
     __shared__ uint32_t s_total;
     if (header[1]) return;
@@ -702,6 +760,14 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     } else {
         return;
     }
+    // The tile only needs entries [0, max over its pixels of last_contributor): the forward left that maximum in tile_maxc, so a
+    // work item beyond it (most of them once surfaces are opaque) leaves here, before any per-pixel load or barrier.
+    const uint2 range = ranges[tile];
+    const int seg_lo = seg * L2D_SEG;      // the last segment runs to the end of the list (all of it for a tile that is not segmented)
+    const int seg_hi = seg == (int)seg_cnt[tile] ? (int)(range.y - range.x) : seg_lo + L2D_SEG;
+    const int total = min((int)tile_maxc[tile], seg_hi);
+    const int lo = seg_lo;
+    if (total <= lo) return;
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int grp = lane >> 2;
@@ -713,10 +779,6 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const size_t pix = inside ? (size_t)pyi * v.W + pxi : 0;
     const float lx = (float)lxi, ly = (float)lyi;
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
-    const uint2 range = ranges[tile];
-    // the last segment runs to the end of the list (all of it for a tile that is not segmented)
-    const int seg_lo = seg * L2D_SEG;
-    const int seg_hi = seg == (int)seg_cnt[tile] ? (int)(range.y - range.x) : seg_lo + L2D_SEG;
 
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
@@ -741,22 +803,15 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     float accum_g = 0.f, last_g = 0.f, last_alpha = 0.f;
     float last_dL_dT = 0.f;
 
-    // the tile only needs entries [0, max over pixels of last_contributor)
-    if (tid == 0) s_maxc = 0;
-    __syncthreads();
-    atomicMax(&s_maxc, last_contributor);
-    __syncthreads();
-    const int total = min((int)s_maxc, seg_hi);
-    const int lo = seg_lo;
     // bits of the 8x8 block mask that precede this lane's 2x2 block (slab slot ranking)
     const int my_blk = (lyi >> 1) * 8 + (lxi >> 1);
     const uint32_t below_lo = my_blk >= 32 ? 0xffffffffu : (1u << my_blk) - 1u;
     const uint32_t below_hi = my_blk >= 32 ? (1u << (my_blk - 32)) - 1u : 0u;
+    const QuadCoef qcoef = quad_coef(lane, lx, ly);
     uint32_t quad_last = last_contributor;  // max over the 2x2 block
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0xB1, 0xf, 0xf, false));
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0x4E, 0xf, 0xf, false));
     if ((lane & 3) == 0) s_ql[my_blk] = quad_last;  // read by wave 0 after the first window's barrier
-    if (total <= lo) return;
 
     // A pixel whose walk began above this segment resumes from the forward's checkpoint at seg_hi:
     // with F the running sum of f_k * w_k over entries < seg_hi and T_b the transmittance there,
@@ -898,7 +953,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     Hit h;
                     float Tw[3], opa;
                     const bool active = eval_rec(ent, lx, ly, h, Tw, opa) && has && contributor < last_contributor;
-                    if (__ballot(active) == 0ull || (v.dbg & 16u)) continue;
+                    // (no shortcut for a trip without a single active lane: it would be taken by a few per cent of the trips and
+                    // costs every trip five register copies to keep the state both paths update -- 397 -> 388 us at init)
                     // From here on all lanes run (the quad sums below need uniform control flow): inactive
                     // lanes keep their state and contribute exact zeros.
                     const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
@@ -939,36 +995,29 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     last_g = gval;
                     last_alpha = alpha;
                     last_dL_dT = dLdT_new;
-                    // this pixel's 22 coefficient-space partials (zeros when inactive) ...
+                    // this pixel's coefficient-space partials (zeros when inactive) ...
                     // An inactive lane's sx, sy, rz may be inf / NaN (pz = 0); every product they enter has a factor
                     // that IS zero there (dz, qG, dpx, dpy, rz3), and v_mul_legacy_f32 (0 * anything = 0) keeps the
                     // zero -- three selects fewer than zeroing sx, sy, rz themselves.  Active lanes: same products.
                     const float ww = w, da = active ? dL_dalpha : 0.f, dz = active ? dL_dz : 0.f;   // (w = 0 when inactive)
                     const float sx = h.sx, sy = h.sy;
                     const float rz3 = (active && h.use3d) ? h.rz : 0.f;     // the 3-D branch's 1/pz, else 0
-                    float g[22];
-                    g[18] = ww * dpix[0]; g[19] = ww * dpix[1]; g[20] = ww * dpix[2];
-                    g[14] = ww * dnrm[0]; g[15] = ww * dnrm[1]; g[16] = ww * dnrm[2];
                     // depth = s . Tw.xy + Tw.z (the published backward uses this form in both branches)
-                    g[9] = mul_legacy(dz, sx); g[10] = mul_legacy(dz, sy); g[11] = dz;
+                    const float qv[3] = {mul_legacy(dz, sx), mul_legacy(dz, sy), dz};
                     const float qG = opa * da * h.G;  // dL/dG * G  (G is finite on every lane)
                     const float dL_dsx = dz * Tw[0] - mul_legacy(qG, sx);
                     const float dL_dsy = dz * Tw[1] - mul_legacy(qG, sy);
                     const float dpx = dL_dsx * rz3, dpy = dL_dsy * rz3;
-                    const float dpz = -(mul_legacy(dpx, sx) + mul_legacy(dpy, sy));
-                    g[0] = dpx; g[1] = dpy; g[2] = dpz;
-                    g[3] = lx * dpx; g[4] = lx * dpy; g[5] = lx * dpz;
-                    g[6] = ly * dpx; g[7] = ly * dpy; g[8] = ly * dpz;
+                    const float dpv[3] = {dpx, dpy, -(mul_legacy(dpx, sx) + mul_legacy(dpy, sy))};
                     const float qG2 = h.use3d ? 0.f : -FILTER_INV_SQUARE * qG;   // the low-pass branch's share
-                    g[12] = qG2 * h.ddx;
-                    g[13] = qG2 * h.ddy;
-                    g[17] = h.G * da;
-                    g[21] = ww;  // > 0 marks a block that contributed
-                    // ... summed over the quad's 2x2 pixels with a DPP reduce-scatter (each lane ends up
-                    // with 5-6 of the 22 sums) and parked in the (entry, block) slot: plain stores, one
-                    // writer per slot
+                    // hv: centre (2), normal (3), opacity, colour (3), sum of weights (> 0 marks a block that contributed)
+                    const float hv[10] = {qG2 * h.ddx, qG2 * h.ddy, ww * dnrm[0], ww * dnrm[1], ww * dnrm[2], h.G * da,
+                                          ww * dpix[0], ww * dpix[1], ww * dpix[2], ww};
+                    // ... summed over the quad's 2x2 pixels with a DPP reduce-scatter (each lane ends up with 5-6 of the 22
+                    // sums; the pixel-offset moments of dL/dp come out of the butterfly's own partial sums) and parked in the
+                    // (entry, block) slot: plain stores, one writer per slot
                     float r[6];
-                    quad_reduce_scatter(g, r, lane);
+                    quad_reduce_scatter(dpv, qv, hv, qcoef, r, lane);
                     // (pin the sums here: left alone, the compiler sinks the second step's adds into the `if (has)` below,
                     // away from their DPP operand fetches, and pays a v_mov 0 + v_mov_dpp + v_add per value instead of one
                     // v_add_f32_dpp)
@@ -1020,7 +1069,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     const float Tu[3] = {g0.x, g0.y, g0.z}, Tv[3] = {g0.w, g1.x, g1.y}, Tw[3] = {g1.z, g1.w, g2.x};
                     const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
                     const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
-                    const float a[3] = {g[0], g[1], g[2]}, b[3] = {g[3], g[4], g[5]}, cc[3] = {g[6], g[7], g[8]};
+                    // slot rows 0-2 = per component of dL/dp: (sum, sum lx, sum ly, q) -- see quad_reduce_scatter
+                    const float a[3] = {g[0], g[4], g[8]}, b[3] = {g[1], g[5], g[9]}, cc[3] = {g[2], g[6], g[10]};
+                    const float qd[3] = {g[3], g[7], g[11]};       // sums of dz sx, dz sy, dz
                     // A = k0 x l0, B = Tw x l0, C = k0 x Tw ; for y = u x v: dL/du = v x dL/dy, dL/dv = dL/dy x u
                     float t1[3], t2[3], dk0[3], dl0[3], dTw[3];
                     cross3(l0, a, t1); cross3(Tw, cc, t2);
@@ -1028,7 +1079,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     cross3(a, k0, t1); cross3(b, Tw, t2);
                     for (int i = 0; i < 3; i++) dl0[i] = t1[i] + t2[i];
                     cross3(l0, b, t1); cross3(cc, k0, t2);
-                    for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + g[9 + i];
+                    for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + qd[i];
                     // one 80-byte gradient row per touched (tile, surfel) pair, written exactly once, at the pair's
                     // SURFEL-MAJOR index (pair_pos[p], recorded by the sort): a surfel's rows are contiguous and
                     // preprocess_bwd streams them; a byte per pair marks the rows that exist
@@ -1062,14 +1113,17 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     }
 }
 
-// reduce-scatter self-test: in [64][22] (lane major) -> out [16 quads][22] quad sums
+// reduce-scatter self-test: in [64][16] (lane major: dp 3, q 3, h 10) -> out [16 quads][24] = the quad's slot; the lanes'
+// pixel offsets are those of wave 0 of a workgroup
 __global__ void __launch_bounds__(64)
 selftest_butterfly_kernel(const float *__restrict__ in, float *__restrict__ out) {
-    const int lane = threadIdx.x, q4 = lane & 3;
-    float g[22], r[6];
-    for (int k = 0; k < 22; k++) g[k] = in[lane * 22 + k];
-    quad_reduce_scatter(g, r, lane);
-    float *dst = out + (lane >> 2) * 22 + q4;
+    const int lane = threadIdx.x, q4 = lane & 3, grp = lane >> 2;
+    const float lx = (float)((grp & 3) * 2 + (lane & 1)), ly = (float)((grp >> 2) * 2 + ((lane >> 1) & 1));
+    float dp[3], q[3], h[10], r[6];
+    for (int k = 0; k < 3; k++) { dp[k] = in[lane * 16 + k]; q[k] = in[lane * 16 + 3 + k]; }
+    for (int k = 0; k < 10; k++) h[k] = in[lane * 16 + 6 + k];
+    quad_reduce_scatter(dp, q, h, quad_coef(lane, lx, ly), r, lane);
+    float *dst = out + (lane >> 2) * 24 + q4;
     for (int i = 0; i < 5; i++) dst[4 * i] = r[i];
     if (q4 < 2) dst[20] = r[5];
 }
@@ -1083,7 +1137,7 @@ int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *
     if (vbp) vb = *vbp;
     const unsigned nz = vbp ? (unsigned)vb.n : 1u;    // blockIdx.z = view (st / sc / out_* are view 0's)
 #define FWD_ARGS v, st.header, st.ranges, st.point_list, (const float4 *)st.geom, st.tile_order, (const float4 *)st.cullbox, \
-                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, out_color, out_allmap, slabs, vb
+                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, st.tile_maxc, out_color, out_allmap, slabs, vb
     {
         // Depth-segment split of the long lists: OPT-IN (lara2dgs_set_forward_split / LARA2DGS_FWD_SPLIT=1), off by default
         // because it measured SLOWER: at LaRa's init statistics the four launches take 123 (prepass) + 142 (segment walks) + 14
@@ -1098,7 +1152,7 @@ int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *
             hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(v.tiles, 8, nz), dim3(256), 0, s, FWD_ARGS);
             hipLaunchKernelGGL(composite_fwd_kernel<2>, dim3(v.tiles, 8, nz), dim3(256), 0, s, FWD_ARGS);
             hipLaunchKernelGGL(composite_fwd_combine_kernel, dim3(v.tiles, 1, nz), dim3(256), 0, s, v, st.header, st.ranges, st.tile_order,
-                               st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, out_color, out_allmap, slabs, vb);
+                               st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.tile_maxc, out_color, out_allmap, slabs, vb);
         }
         hipLaunchKernelGGL(composite_fwd_kernel<0>, dim3(v.tiles, 1, nz), dim3(256), 0, s, FWD_ARGS);
     }
@@ -1119,7 +1173,7 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
         hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid, 1, vbp ? (unsigned)vb.n : 1u), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
                            (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.bwd_order,
-                           st.bwd_items, st.ckpt, st.pair_mask, dL_dcolor, dL_dallmap, st.pair_pos, sc.pair_grad,
+                           st.bwd_items, st.ckpt, st.pair_mask, st.tile_maxc, dL_dcolor, dL_dallmap, st.pair_pos, sc.pair_grad,
                            (uint8_t *)sc.pair_valid, vb);
     }
     L2D_CHECK_LAUNCH();

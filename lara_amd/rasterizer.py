@@ -28,8 +28,9 @@ import torch
 from torch import nn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 7
+# (LARA2DGS_LIB: another build of the same library -- kernel A/B experiments, tools/build_variant.sh; never a CPU path)
+LIB_PATH = os.environ.get("LARA2DGS_LIB") or os.path.join(_HERE, "liblara2dgs.so")
+ABI_VERSION = 8
 
 
 class _View(ctypes.Structure):
@@ -52,7 +53,7 @@ class GradLayout(ctypes.Structure):
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "pair_base", "pair_pos", "final_T", "n_contrib",
-                 "seg_base", "seg_cnt", "bwd_order", "bwd_items", "ckpt", "pair_mask", "total")]
+                 "seg_base", "seg_cnt", "bwd_order", "bwd_items", "ckpt", "pair_mask", "tile_maxc", "total")]
 
 
 _lib = None
@@ -699,6 +700,7 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
         bwd_order=sec(L.bwd_order, tiles * 4, torch.int32, (tiles,)),
         bwd_items=sec(L.bwd_items, (cap // 512 + 1) * 8, torch.int32, (cap // 512 + 1, 2)),
         pair_mask=sec(L.pair_mask, cap * 8, torch.int64, (cap,)),
+        tile_maxc=sec(L.tile_maxc, tiles * 4, torch.int32, (tiles,)),
     )
 
 

@@ -105,7 +105,7 @@ def explain_contrib_mismatches(ref, n_contrib_hip, W, tol_alpha=1e-3, tol_T=5e-3
     pixels NOT explained that way, and the worst margins among the explained."""
     bad = np.argwhere((n_contrib_hip[0] != ref.n_contrib[0]) | (n_contrib_hip[1] != ref.n_contrib[1]))
     out = {"mismatching_pixels": int(len(bad)), "unexplained": 0, "worst_alpha_margin": 0.0, "worst_T_margin": 0.0,
-           "by_alpha_flip": 0, "by_T_flip": 0}
+           "by_alpha_flip": 0, "by_T_flip": 0, "unexplained_detail": []}
     for py, px in bad[:limit]:
         w = pixel_walk(ref, int(px), int(py), W)
         ok = True
@@ -116,13 +116,18 @@ def explain_contrib_mismatches(ref, n_contrib_hip, W, tol_alpha=1e-3, tol_T=5e-3
             lo0, hi = max(min(a, b) - 1, 0), max(a, b)
             ma = float(w["alpha"][lo0:hi].min()) if hi > lo0 else np.inf
             mt = float(np.minimum(w["stop"][lo0:hi], w["median"][lo0:hi] if ch == 1 else np.inf).min()) if hi > lo0 else np.inf
+            # (T at list position n is a product of n factors, each off by a few ulp between the two implementations: the T
+            # thresholds get 1e-6 per position on top of the one-alpha-flip allowance -- 3e-3 at the 3000th entry of a
+            # full-size list, nothing at the tens of entries of the small cases)
             if ma <= tol_alpha:
                 out["by_alpha_flip"] += 1
                 out["worst_alpha_margin"] = max(out["worst_alpha_margin"], ma)
-            elif mt <= tol_T:
+            elif mt <= tol_T + 1e-6 * hi:
                 out["by_T_flip"] += 1
                 out["worst_T_margin"] = max(out["worst_T_margin"], mt)
             else:
                 ok = False
+                out["unexplained_detail"].append({"px": int(px), "py": int(py), "channel": ch, "hip": a, "oracle": b,
+                                                  "min_alpha_margin": ma, "min_T_margin": mt})
         out["unexplained"] += 0 if ok else 1
     return out

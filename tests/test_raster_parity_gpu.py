@@ -534,16 +534,28 @@ def test_full_size_gradients_within_the_oracles_own_conditioning(hip_lib):
 
 
 def test_quad_reduce_scatter_selftest(hip_lib):
-    """The 22-value DPP quad reduce-scatter of the backward composite against plain sums."""
+    """The DPP quad reduce-scatter of the backward composite against plain sums: per 2x2 block and component of dL/dp the
+    sum, its two pixel-offset moments (formed from the butterfly's partial sums) and a fourth value; ten more plain sums."""
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(64, 22, generator=g, dtype=torch.float32)
-    out = torch.zeros(16 * 22, device=DEV)
+    x = torch.randn(64, 16, generator=g, dtype=torch.float32)
+    out = torch.zeros(16 * 24, device=DEV)
     rc = hip_lib.lara2dgs_selftest(0, x.to(DEV).data_ptr(), out.data_ptr(), None)
     assert rc == 0
     torch.cuda.synchronize()
-    got = out.cpu().numpy().reshape(16, 22)
-    ref = x.double().reshape(16, 4, 22).sum(1).numpy()
-    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    got = out.cpu().numpy().reshape(16, 24)
+    xd = x.double().numpy().reshape(16, 4, 16)
+    lane = np.arange(64).reshape(16, 4)
+    quad = lane >> 2
+    lx = ((quad & 3) * 2 + (lane & 1)).astype(np.float64)
+    ly = ((quad >> 2) * 2 + ((lane >> 1) & 1)).astype(np.float64)
+    ref = np.zeros((16, 24))
+    for c in range(3):
+        ref[:, 4 * c + 0] = xd[:, :, c].sum(1)
+        ref[:, 4 * c + 1] = (lx * xd[:, :, c]).sum(1)
+        ref[:, 4 * c + 2] = (ly * xd[:, :, c]).sum(1)
+        ref[:, 4 * c + 3] = xd[:, :, 3 + c].sum(1)
+    ref[:, 12:22] = xd[:, :, 6:16].sum(1)
+    np.testing.assert_allclose(got[:, :22], ref[:, :22], rtol=1e-5, atol=2e-5)
 
 
 def test_opt_in_culling_of_transparent_surfels_changes_no_pixel(hip_lib):

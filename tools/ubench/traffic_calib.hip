@@ -7,8 +7,11 @@
 //   rec80_gather         thread i reads idx[i] (4 B, coalesced) and then the 80-byte record idx[i] with five float4 loads:
 //                        the composite kernels' staging pattern.  idx is a permutation: every record, hence every 128-byte
 //                        line of the record array, is needed exactly once per launch -- but a record straddles a line
-//                        boundary 3 times in 8, so lines are requested 1.375 times on average unless the second request hits in L2
+//                        boundary 4 times in 8, so 1.5 lines are requested per record on average unless the second request hits in L2
 //   line128_gather       idx[i] -> a 128-byte aligned, 128-byte record (eight float4): one full line per record, no ambiguity
+// and the same patterns at the composite kernels' REAL sizes, which fit the Infinity Cache and were written by the kernel in
+// front (stream16_small: 64 MB in / out; rec80_gather_small: 1.5 M references into 524 288 records = 42 MB, every record
+// referenced ~3 times like a surfel in the tile lists) -- whether the counter sees cache-resident data the same way
 // build: hipcc --offload-arch=gfx950 -O2 tools/ubench/traffic_calib.hip -o tools/ubench/traffic_calib
 // run:   rocprofv3 --kernel-trace --pmc FETCH_SIZE -- tools/ubench/traffic_calib     (and again with WRITE_SIZE)
 #include <hip/hip_runtime.h>
@@ -46,6 +49,17 @@ __global__ void line128_gather(const uint32_t *__restrict__ idx, const float4 *_
     for (int k = 0; k < 8; k++) s += r[k].x;
     out[i] = s;
 }
+__global__ void stream16_small(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float4 v = in[i]; v.x += 1.0f; out[i] = v; }
+}
+__global__ void rec80_gather_small(const uint32_t *__restrict__ idx, const float4 *__restrict__ rec, float *__restrict__ out, size_t n, uint32_t mask) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 *r = rec + (size_t)(idx[i] & mask) * 5;
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
+    out[i] = a.x + b.y + c.z + d.w + e.x;
+}
 // idx[i] = (i * A + B) mod n with A odd and n a power of two: a permutation with no locality
 __global__ void fill_perm(uint32_t *idx, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,12 +86,23 @@ int main() {
         hipLaunchKernelGGL(rec80_gather, grid(N), dim3(blk), 0, 0, idx, (const float4 *)big, out, N);
         hipLaunchKernelGGL(line128_gather, grid(N), dim3(blk), 0, 0, idx, (const float4 *)big, out, N);
     }
+    // cache-resident sizes: the producer (fill_f over the same 64 MB / 42 MB) runs right in front of every measured launch
+    const size_t NS = (size_t)1 << 22, NR = (size_t)1 << 19, NG = 1536 * 1024;
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(fill_f, grid(NS * 4), dim3(blk), 0, 0, big, NS * 4);
+        hipLaunchKernelGGL(stream16_small, grid(NS), dim3(blk), 0, 0, (const float4 *)big, (float4 *)(big + N * 16), NS);   // 64 MiB in, 64 MiB out
+        hipLaunchKernelGGL(fill_f, grid(NR * 20), dim3(blk), 0, 0, big, NR * 20);
+        hipLaunchKernelGGL(rec80_gather_small, grid(NG), dim3(blk), 0, 0, idx, (const float4 *)big, out, NG, (uint32_t)(NR - 1));
+    }
     (void)hipDeviceSynchronize();
     printf("{\"N\": %zu, \"known_bytes\": {"
            "\"stream4\": {\"read\": %zu, \"write\": %zu}, \"stream16\": {\"read\": %zu, \"write\": %zu}, "
            "\"rec80_seq\": {\"read\": %zu, \"write\": %zu}, "
            "\"rec80_gather\": {\"read\": %zu, \"read_if_straddling_lines_fetched_twice\": %zu, \"write\": %zu}, "
-           "\"line128_gather\": {\"read\": %zu, \"write\": %zu}}}\n",
-           N, N * 64, N * 64, N * 64, N * 64, N * 80, N * 4, N * 84, N * 4 + (size_t)(N * 80 * 1.375), N * 4, N * 132, N * 4);
+           "\"line128_gather\": {\"read\": %zu, \"write\": %zu}, "
+           "\"stream16_small\": {\"read\": %zu, \"write\": %zu}, "
+           "\"rec80_gather_small\": {\"read_unique\": %zu, \"read_referenced\": %zu, \"write\": %zu}}}\n",
+           N, N * 64, N * 64, N * 64, N * 64, N * 80, N * 4, N * 84, N * 4 + (size_t)(N * 80 * 1.5), N * 4, N * 132, N * 4,
+           NS * 16, NS * 16, NR * 80 + NG * 4, NG * 84, NG * 4);
     return 0;
 }
