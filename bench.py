@@ -1501,6 +1501,59 @@ def main():
                                     "ms_per_step": round(1e3 * d1 / args.steps, 3),
                                     "what": "the headline step + 0.5 (1 - MS_SSIM) for the coarse and the fine image (lara_amd.loss.ms_ssim: "
                                             "torch matmul / pooling operators, fp32, no HIP kernel of this repo)"}
+    if solo and args.step == "pipeline" and not args.no_side_legs:
+        # The same step as an UNMODIFIED LaRa issues it around the drop-in rasteriser (lara_amd.reference_style: one
+        # GaussianRasterizer call per view on one stream, render_img's post-processing / get_point_feats / forward_fine / the coarse
+        # MLP / the loss as plain torch operators, `x[mask]` indexing).  The encoder stays this package's HIP VolTransformer in both.
+        from lara_amd import reference_style
+        from lara_amd.pipeline import lara_loss as torch_loss
+        _leg("drop_in_step")
+        pipe_, batch_, fv_, _fs = info["pipeline"]
+        pars_ = [p for p in pipe_.parameters() if p.requires_grad]
+
+        def drop_in():
+            o = reference_style.network_forward(pipe_, batch_, fv_, with_fine=not args.no_fine)
+            l, _ = torch_loss(batch_, o, 2000, ms_ssim=False)
+            l.backward()
+            for p in pars_:
+                p.grad = None
+            fv_.grad = None
+        for _ in range(2):
+            drop_in()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(2, args.steps // 2)):
+            drop_in()
+        torch.cuda.synchronize()
+        d1 = (time.perf_counter() - t1) / max(2, args.steps // 2)
+        out["drop_in_step"] = {"value": round(frames_per_step / d1, 3), "unit": "frames/s", "ms_per_step": round(1e3 * d1, 3),
+                               "what": "the headline's step as train_lightning.py issues it UNCHANGED around the shim: per-view GaussianRasterizer "
+                                       "calls on one stream, reference-style torch operators for render_img's post-processing, the coarse MLP, "
+                                       "get_point_feats, forward_fine, x[mask] and the loss (lara_amd.reference_style); same HIP VolTransformer"}
+        del drop_in
+        torch.cuda.empty_cache()
+        # SURVEY 8d's second regime for the whole step: the same network with its opacity logits biased to an opaque thin shell
+        # in empty space (pixels saturate after tens of surfels; the fine pass renders the shell only)
+        _leg("trained_like_step")
+        pipe_.opacity_bias = pipe_.trained_like_opacity_bias()
+        try:
+            fs = info["pipeline"][3]
+            for _ in range(2):
+                fs()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                fs()
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t1) / args.steps
+            with torch.no_grad():
+                kept = float((torch.sigmoid(pipe_.gaussians(fv_)["opacity"]) > 0.005).float().mean())
+            out["trained_like_step"] = {"value": round(frames_per_step / d1, 3), "unit": "frames/s", "ms_per_step": round(1e3 * d1, 3),
+                                        "fine_subset_fraction": round(kept, 4),
+                                        "what": "the headline step with the decoder's opacity logits biased to SURVEY 8d's trained-like shell "
+                                                "(opaque |r - 0.35| < 0.02, empty elsewhere): the composite kernels' early-terminating regime"}
+        finally:
+            pipe_.opacity_bias = None
     if solo and args.step == "pipeline" and not args.no_roofline and not args.no_side_legs:
         try:
             _leg("ddp_single_rank_rccl")

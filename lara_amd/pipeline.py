@@ -197,6 +197,7 @@ class LaRaPipeline(nn.Module):
         self.fused_coarse = True          # False: `decode_coarse` (torch operators) instead of lara_amd.coarse
         self.fine_mask = "reference"      # "reference": _check_mask as the reference applies it; "plain": opacity > 0.005 only
         self.stage_events = None          # set to a list to collect (stage, start event, end event) per call
+        self.opacity_bias = None          # benchmarks only: a [1,P,1] logit bias (see `trained_like_opacity_bias`)
 
     # -- stages --------------------------------------------------------------------------------------------------
     def gaussians(self, feat_vol):
@@ -209,12 +210,22 @@ class LaRaPipeline(nn.Module):
             offset, shs, scaling, rotation, opacity = coarse.forward_coarse(self.decoder, vol, self.opacity_shift, self.scaling_shift)
         else:
             offset, shs, scaling, rotation, opacity = decode_coarse(self.decoder, vol, self.opacity_shift, self.scaling_shift, autocast)
+        if self.opacity_bias is not None:
+            opacity = opacity + self.opacity_bias
         half_cell = 0.5 * self.scene_size / self.n_offset_groups                # network.py:425-429
         B = offset.shape[0]
         centers = self.group_centers.unsqueeze(-2).expand(B, -1, self.K, -1).reshape(offset.shape) + offset * half_cell
         masks = torch.sigmoid(opacity.detach()).squeeze(-1) > 0.005
         return {"centers": centers, "shs": shs, "scaling": scaling, "rotation": rotation, "opacity": opacity,
                 "masks": masks, "vol": vol.view(B, -1, vol.shape[-1])}
+
+    def trained_like_opacity_bias(self):
+        """SURVEY.md section 8d's second regime for the WHOLE step: a logit bias that makes the random-init network emit an opaque
+        thin shell (|r - 0.35| < 0.02: +4 - shift, i.e. opacity ~ 0.98) in empty space (-6 - shift elsewhere), as
+        `synthetic.make_scene(regime="trained")` does for the raster-only scenes.  Assign the result to `opacity_bias`."""
+        r = self.group_centers.norm(dim=-1, keepdim=True)                                   # [1, voxels, 1]
+        bias = torch.where((r - 0.35).abs() < 0.02, 4.0 - self.opacity_shift, -6.0 - self.opacity_shift)
+        return bias.unsqueeze(-2).expand(-1, -1, self.K, -1).reshape(1, -1, 1).contiguous()
 
     @staticmethod
     def host_scalars(batch):

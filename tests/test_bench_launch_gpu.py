@@ -32,3 +32,18 @@ def test_bench_gpus_2_real_step_over_gloo(hip_lib):
     assert ar["backend"] == "gloo" and ar["buckets"] and sum(ar["buckets"]) == ar["bytes_per_step"]
     assert ar["bytes_per_step"] > 4 * 5_000_000                        # two GroupAttBlocks + pos_embed + tail + decoder, fp32
     assert out["value"] > 0
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="two RCCL ranks want two GPUs (the round's box has one)")
+def test_bench_gpus_2_real_step_over_rccl(hip_lib):
+    """`python bench.py --gpus 2` as the driver launches it on a multi-GPU node: backend nccl (= RCCL), one rank per device."""
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LARA_BENCH_PLUMBING", "LARA_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes", "1",
+           "--views", "4", "--grid", "16", "--res", "128", "--encoder-layers", "2", "--no-cpu-baseline", "--no-roofline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["grad_allreduce"]["backend"] == "nccl"
+    assert out["config"]["frames_per_step"] == 2 * 1 * 4 * 2 and out["value"] > 0

@@ -12,35 +12,40 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _model():
+def _model(dev="cuda:0"):
     from lara_amd.encoder_train import VolTransformer
     torch.manual_seed(3)
     return VolTransformer(embed_dim=256, image_feat_dim=800, n_groups=[2], vol_low_res=4, vol_high_res=8, out_dim=80,
-                          num_layers=2, num_heads=16).to("cuda:0")
+                          num_layers=2, num_heads=16).to(dev)
 
 
-def _inputs(rank):
+def _inputs(rank, dev="cuda:0"):
     g = torch.Generator().manual_seed(100 + rank)
-    return (torch.randn(1, 4, 800, 2, 2, 2, generator=g).to("cuda:0"), torch.randn(1, 8, 8, 8, 80, generator=g).to("cuda:0"))
+    return (torch.randn(1, 4, 800, 2, 2, 2, generator=g).to(dev), torch.randn(1, 8, 8, 8, 80, generator=g).to(dev))
 
 
-def _worker(rank, world, port, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, out, backend="gloo"):
+    """`backend="gloo"`: both ranks share cuda:0; `backend="nccl"` (= RCCL): rank r owns cuda:r."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         from lara_amd import encoder_train
-        torch.cuda.set_device(0)
         # small buckets, so that the two blocks' parameters land in different ones
-        ddp = torch.nn.parallel.DistributedDataParallel(_model(), find_unused_parameters=True, bucket_cap_mb=1)
+        ddp = torch.nn.parallel.DistributedDataParallel(_model(dev), device_ids=[dev.index] if backend == "nccl" else None,
+                                                        find_unused_parameters=True, bucket_cap_mb=1)
         log = encoder_train._block_bwd_log = []
 
         def hook(state, bucket):      # called by the reducer the moment a bucket is full: this is where its all-reduce is enqueued
             log.append(("allreduce_enqueued", bucket.index()))
             return default_hooks.allreduce_hook(state, bucket)
         ddp.register_comm_hook(None, hook)
-        feats, dout = _inputs(rank)
+        feats, dout = _inputs(rank, dev)
         (ddp(feats) * dout).sum().backward()
         torch.cuda.synchronize()
         out.put((rank, {n: p.grad.cpu().numpy() for n, p in ddp.module.named_parameters()}, list(log)))   # (by value: this process exits)
@@ -49,10 +54,22 @@ def _worker(rank, world, port, out):
 
 
 def test_hip_backward_feeds_torch_ddp(hip_lib):
+    _two_rank_ddp("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks want two GPUs (the round's box has one; the driver's 8-GPU node runs this)")
+def test_hip_backward_feeds_torch_ddp_over_two_rccl_ranks(hip_lib):
+    """The same assertions with backend nccl (= RCCL over xGMI), one rank per GPU: identical post-all-reduce gradients on
+    both ranks, equal to the mean of the local ones, and the first bucket's all-reduce enqueued before the last block's
+    backward.  Skipped on a one-GPU box: no two-rank RCCL run has happened in this environment."""
+    _two_rank_ddp("nccl")
+
+
+def _two_rank_ddp(backend):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (11 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = [out.get(timeout=600) for _ in range(2)]

@@ -280,3 +280,38 @@ def test_pipeline_reproduces_the_references_own_network_forward(hip_lib, n_strea
         assert np.quantile(err, 0.999) <= typical * scale, (k, float(np.quantile(err, 0.999)))
     mse = float(((out["image_fine"].cpu().numpy() - want["image_fine"]) ** 2).mean())
     assert 10 * np.log10(1.0 / max(mse, 1e-30)) >= 70.0
+
+
+@pytest.mark.gpu
+def test_reference_style_network_forward_matches_the_fused_pipeline(hip_lib):
+    """`lara_amd.reference_style.network_forward` -- the reference's own sequence of torch operators around the drop-in
+    rasteriser (what bench.py times as `drop_in_step`) -- against the opt-in pipeline on the same parameters: the coarse maps to
+    fp32 rounding (same rasteriser kernels, post-processing as torch operators instead of the fused kernel), the fine maps to the
+    bf16 rounding of `Decoder.forward_fine` under autocast (the fused fine decoder runs its products in fp32)."""
+    from lara_amd import reference_style
+    dev = torch.device("cuda:0")
+    pipe, batch, feat_vol = _small_problem(dev)
+    pipe.fine_mask = "plain"
+    with torch.no_grad():
+        a = pipe(batch, feat_vol, with_fine=True)
+        pipe.join_streams()
+        b = reference_style.network_forward(pipe, batch, feat_vol, with_fine=True)
+    torch.cuda.synchronize()
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].shape == b[k].shape, k
+        err = float((a[k] - b[k]).abs().max())
+        scale = max(1.0, float(b[k].abs().max()))
+        if k.endswith("_fine"):
+            assert err <= 5e-2 * scale and float((a[k] - b[k]).abs().mean()) <= 2e-3 * scale, (k, err)
+        elif k.startswith("depth_normal"):      # normalised cross products of finite differences: ill-conditioned where depth ~ 0
+            assert float((a[k] - b[k]).abs().mean()) <= 1e-4, (k, err)
+        else:
+            assert err <= 2e-5 * scale, (k, err)
+    # and it is differentiable end to end (the bench runs its backward)
+    out = reference_style.network_forward(pipe, batch, feat_vol, with_fine=True)
+    from lara_amd.pipeline import lara_loss
+    loss, _ = lara_loss(batch, out, 2000, ms_ssim=False)
+    loss.backward()
+    assert feat_vol.grad is not None and torch.isfinite(feat_vol.grad).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pipe.parameters() if p.requires_grad)
