@@ -20,7 +20,16 @@
 #include "group_attn.h"
 #include "../../include/lara_groupattn.h"
 
+#include <atomic>
+namespace {
+// 0: five launches (LayerNorm, Q, K|V, attention, output projection); 1 / 2: the K|V projection + ONE wave-private kernel for
+// the rest (group_attn_fused_kernel / group_attn_fused2_kernel).  LARA_GA_FUSED at load, lara_groupattn_set_fused at run time.
+std::atomic<int> g_ga_fused{[] { const char *e = getenv("LARA_GA_FUSED"); return e ? atoi(e) : 0; }()};
+}
+
 extern "C" {
+
+int lara_groupattn_set_fused(int32_t mode) { return g_ga_fused.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
 
 int64_t lara_groupattn_workspace_bytes(int32_t G) {
     if (G < 0) return LARA2DGS_E_INVALID;
@@ -42,7 +51,7 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
         // wave-private kernel (group_attn_fused_kernel).  Same results; measured 237 us against the 190 us of the four
         // launches it replaces at 4 scenes -- a wave's serial chain (LayerNorm, 16 L2 round trips for the weight
         // tiles, attention, epilogue) at 1.5 waves per SIMD is latency-bound.  DESIGN.md section 3.3.
-        static const bool fused = getenv("LARA_GA_FUSED") && atoi(getenv("LARA_GA_FUSED")) != 0;
+        const int fused = g_ga_fused.load();
         if (fused) {
             unsigned short *kvf = (unsigned short *)workspace + (size_t)G * 8 * 256 * 2;
             {
@@ -55,8 +64,11 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
             {
                 L2D_PROF("ga_fused", s);
                 const int units = (G + 3) / 4;
-                hipLaunchKernelGGL(group_attn_fused_kernel, dim3((units + 1) / 2), dim3(128), 0, s, x, ln_weight, ln_bias, eps,
-                                   wq, kvf, wo, y, G);
+                if (fused == 2)
+                    hipLaunchKernelGGL(group_attn_fused2_kernel, dim3(units), dim3(64), 0, s, x, ln_weight, ln_bias, eps, wq, kvf, wo, y, G);
+                else
+                    hipLaunchKernelGGL(group_attn_fused_kernel, dim3((units + 1) / 2), dim3(128), 0, s, x, ln_weight, ln_bias, eps,
+                                       wq, kvf, wo, y, G);
             }
             L2D_CHECK_LAUNCH();
             return LARA2DGS_OK;

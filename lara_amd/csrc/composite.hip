@@ -353,6 +353,9 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const int total = (int)(range.y - range.x);
     const bool split = total > FWD_SPLIT && (v.dbg & 128u);      // flag 128: lara2dgs_set_forward_split (opt-in, see launch_composite_fwd)
     if ((MODE == 0) == split) return;
+    // (tried in round 4: s_setprio for the waves of the long lists, so that a single-view launch -- which lasts as long as its
+    // longest list, 5.3 k entries against a mean of 1.5 k -- gets that list done sooner.  No effect, 260.5 vs 261 us: the long
+    // list's workgroup is not held back by its co-residents' issue slots but by its own per-round chain of gathers and barriers.)
     const int segf = MODE == 0 ? total : fwd_seg_len(total);
     const int lo = MODE == 0 ? 0 : (int)blockIdx.y * segf, hi = min(total, lo + segf);   // this workgroup's entries [lo, hi)
     if (lo >= hi && MODE != 0) return;
@@ -704,10 +707,17 @@ __device__ __forceinline__ void quad_reduce_scatter(const float dp[3], const flo
 // the wave instructions, and it keeps the backward free of floating-point atomics.
 constexpr int SLAB_WIN = 128;     // list entries staged per window (one per thread)
 constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
-constexpr int SLAB_POOL = 384;    // (entry, 2x2 block) slots per round
+#ifndef L2D_SLAB_POOL
+#define L2D_SLAB_POOL 384
+#endif
+constexpr int SLAB_POOL = L2D_SLAB_POOL;    // (entry, 2x2 block) slots per round (tools/build_variant.sh -DL2D_SLAB_POOL=n for A/B runs)
 constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padded to 96 bytes (48 KB in all)
 
+#ifdef L2D_BWD_WAVES       // waves per SIMD the register allocation aims at (tools/build_variant.sh -DL2D_BWD_WAVES=n for A/B runs)
+__global__ void __launch_bounds__(256, L2D_BWD_WAVES)
+#else
 __global__ void __launch_bounds__(256)
+#endif
 composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
                      const uint32_t *__restrict__ tile_order, const float4 *__restrict__ cullbox,

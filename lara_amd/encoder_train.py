@@ -442,6 +442,10 @@ class _BlockFn(torch.autograd.Function):
             sw.dkv_all = torch.empty(sw.cond_bf.shape[0] * sw.cond_bf.shape[1], lddkv, dtype=torch.bfloat16, device=dev)
         gd = sw.accumulators(l)
         dw = _fill(_BlockGrads(), gd, _GRAD_FIELDS)
+        # `g` is overwritten in place with the gradient for the block's input and handed on.  That is safe because every
+        # edge this node sits on is INTERNAL to `_forward_per_block` (the token tensors between `_StartFn`, the blocks and
+        # `_HeadFn` never reach the caller, so no hook or `retain_grad` can hold one), and both producers of `g` -- the next
+        # block and `_HeadFn.backward` -- hand over a buffer nobody else reads.
         g = g.float()
         if not g.is_contiguous():
             g = g.contiguous()
@@ -456,7 +460,7 @@ class _BlockFn(torch.autograd.Function):
                                                 ctypes.byref(dw), chained, sw.dkv_all.data_ptr() + l * 1024, lddkv, ws.data_ptr(),
                                                 _stream(dev)), "lara_groupblock_backward")
         _ws_owner[dev.index] = (id(sw), l)
-        ctx.act = None
+        ctx.act = None      # released now, not with the graph; a second backward over a retained graph recomputes them (act = NULL)
         return (g, None, None, gd["ln1_w"], gd["ln1_b"], gd["wq"], gd["wkv"][:256], gd["wkv"][256:], gd["wo"], gd["ln2_w"], gd["ln2_b"],
                 gd["w1"], gd["b1"], gd["w2"], gd["b2"], gd["ln3_w"], gd["ln3_b"],
                 gd["wconv"].view(256, 3, 3, 3, 256).permute(0, 4, 1, 2, 3))
@@ -500,6 +504,9 @@ class _HeadFn(torch.autograd.Function):
                                                    d_nb.data_ptr(), d_wd.data_ptr(), d_b8.data_ptr(), hws.data_ptr(),
                                                    _stream(dev)), "lara_voltrans_head_backward")
         _ws_owner.pop(dev.index, None)      # a new sweep starts: block L - 1 is not chained to anything
+        # ... and with fresh gradient accumulators: `_CondFn.backward` releases them at the END of a sweep only when the image
+        # features want a gradient; a second backward over a retained graph must not add into the first one's sums
+        sw.flat = sw.dkv_all = None
         return (g, d_nw, d_nb, d_wd.view(2, 2, 2, out_dim, 256).permute(4, 3, 0, 1, 2), d_b8.view(8, out_dim).sum(0), None, None, None)
 
 

@@ -248,7 +248,16 @@ class LaRaPipeline(nn.Module):
             self.stage_events.append((name, e))
 
     # -- the step ------------------------------------------------------------------------------------------------
-    def forward(self, batch, feat_vol, with_fine=True):
+    def forward(self, batch, feat_vol, with_fine=True, n_views_sel=None):
+        """`n_views_sel`: the number of INPUT views, which the reference draws at random in {2, 3, 4} when
+        ``cfg.train.use_rand_views`` is set (network.py:437-441).  The fused sampler / fine decoder and the encoder's K|V layout
+        are built for ``self.n_views`` (4: configs/base.yaml); any other count is rejected here rather than mis-indexed --
+        run such a step through ``lara_amd.reference_style.network_forward``-style torch operators instead."""
+        if n_views_sel is not None and int(n_views_sel) != self.n_views:
+            raise NotImplementedError(f"lara_amd.pipeline: built for {self.n_views} input views (configs/base.yaml n_views); got n_views_sel="
+                                      f"{n_views_sel} (cfg.train.use_rand_views): not supported by the fused fine stage")
+        if feat_vol.dim() == 6 and feat_vol.shape[1] != self.n_views:
+            raise NotImplementedError(f"lara_amd.pipeline: the image-feature volume holds {feat_vol.shape[1]} views, the pipeline is built for {self.n_views}")
         return self._step(batch, lambda: self.gaussians(feat_vol), feat_vol.device, feat_vol.shape[0], with_fine)
 
     def forward_from_volume(self, batch, volume_feat_up, with_fine=True, autocast=True):

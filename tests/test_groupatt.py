@@ -92,9 +92,10 @@ def test_ragged_group_count_and_larger_batch(hip_lib):
 
 
 @pytest.mark.gpu
-def test_fused_wave_private_kernel_is_parity_green(hip_lib):
-    """The experiment knob LARA_GA_FUSED=1 (one wave-private kernel for LayerNorm, Q projection, attention, output
-    projection + residual) is read once per process: run the same checks in a child."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_wave_private_kernel_is_parity_green(hip_lib, mode):
+    """LARA_GA_FUSED=1 / 2 (one wave-private kernel for LayerNorm, Q projection, attention, output projection + residual,
+    first and second cut), read at load: run the same checks in a child."""
     import subprocess
     import sys
     code = (
@@ -110,6 +111,6 @@ def test_fused_wave_private_kernel_is_parity_green(hip_lib):
         "    d = (y - ref).abs()\n"
         "    assert float(d.max()) <= 4e-2 and float(d.mean()) <= 4e-3, (G, float(d.max()), float(d.mean()))\n"
         "print('fused ok')\n" % (HERE, os.path.dirname(HERE)))
-    env = dict(os.environ, LARA_GA_FUSED="1")
+    env = dict(os.environ, LARA_GA_FUSED=str(mode))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fused ok" in out.stdout, out.stdout + out.stderr

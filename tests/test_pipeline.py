@@ -315,3 +315,13 @@ def test_reference_style_network_forward_matches_the_fused_pipeline(hip_lib):
     loss.backward()
     assert feat_vol.grad is not None and torch.isfinite(feat_vol.grad).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pipe.parameters() if p.requires_grad)
+
+
+def test_pipeline_rejects_a_random_number_of_input_views():
+    """`cfg.train.use_rand_views` (network.py:437-441) draws 2-4 input views; the fused fine stage is built for 4 and says so."""
+    from lara_amd.pipeline import CoarseFineDecoder, LaRaPipeline
+    pipe = LaRaPipeline(torch.nn.Identity(), CoarseFineDecoder(), grid_reso=4, n_offset_groups=4, n_views=4)
+    with pytest.raises(NotImplementedError):
+        pipe({}, torch.zeros(1, 4, 800, 2, 2, 2), n_views_sel=3)
+    with pytest.raises(NotImplementedError):
+        pipe({}, torch.zeros(1, 3, 800, 2, 2, 2))
