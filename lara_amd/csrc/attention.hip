@@ -23,8 +23,9 @@
 #include <atomic>
 namespace {
 // 0: five launches (LayerNorm, Q, K|V, attention, output projection); 1 / 2: the K|V projection + ONE wave-private kernel for
-// the rest (group_attn_fused_kernel / group_attn_fused2_kernel).  LARA_GA_FUSED at load, lara_groupattn_set_fused at run time.
-std::atomic<int> g_ga_fused{[] { const char *e = getenv("LARA_GA_FUSED"); return e ? atoi(e) : 0; }()};
+// the rest (group_attn_fused_kernel / group_attn_fused2_kernel).  LARA_GA_FUSED at load (default 2: 216 us per layer at 4 scenes
+// against 286 for the five launches and 302 for the first cut), lara_groupattn_set_fused at run time.
+std::atomic<int> g_ga_fused{[] { const char *e = getenv("LARA_GA_FUSED"); const int m = e ? atoi(e) : 2; return m < 0 ? 0 : (m > 2 ? 2 : m); }()};
 }
 
 extern "C" {
@@ -33,8 +34,8 @@ int lara_groupattn_set_fused(int32_t mode) { return g_ga_fused.exchange(mode < 0
 
 int64_t lara_groupattn_workspace_bytes(int32_t G) {
     if (G < 0) return LARA2DGS_E_INVALID;
-    // xn [G*8,256] + q [G*8,256] + kv [G*4,512] + o [G*8,256], bf16
-    return (int64_t)G * (8 * 256 * 3 + 4 * 512) * 2 + 1024;
+    // xn [G*8,256] + q [G*8,256] + kv [G*4,512] + o [G*8,256], bf16; + 256 KB in front for the fused path's packed weights
+    return (int64_t)G * (8 * 256 * 3 + 4 * 512) * 2 + 1024 + 262144;
 }
 
 int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const uint16_t *cond_bf16,
@@ -47,13 +48,14 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
         return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     {
-        // Experiment knob (default off): LayerNorm + Q projection + attention + output projection + residual as ONE
-        // wave-private kernel (group_attn_fused_kernel).  Same results; measured 237 us against the 190 us of the four
-        // launches it replaces at 4 scenes -- a wave's serial chain (LayerNorm, 16 L2 round trips for the weight
-        // tiles, attention, epilogue) at 1.5 waves per SIMD is latency-bound.  DESIGN.md section 3.3.
+        // LayerNorm + Q projection + attention + output projection + residual as ONE wave-private kernel behind the K|V
+        // projection: x read once (and once more for the residual), y written once; xn, Q and O never leave the CU.  The
+        // first cut (mode 1, round 2) lost to the four launches it replaces (237 vs 190 us); the second (mode 2, round 4: packed
+        // weight fragments, K|V's second half through registers at 24 KB of LDS per wave, epilogue bounced through LDS, hardware
+        // bf16 conversion) takes 141 us.  DESIGN.md section 3.3.
         const int fused = g_ga_fused.load();
         if (fused) {
-            unsigned short *kvf = (unsigned short *)workspace + (size_t)G * 8 * 256 * 2;
+            unsigned short *kvf = (unsigned short *)((char *)workspace + 262144) + (size_t)G * 8 * 256 * 2;
             {
                 L2D_PROF("ga_gemm_kv", s);
                 GemmP p{};
@@ -64,9 +66,14 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
             {
                 L2D_PROF("ga_fused", s);
                 const int units = (G + 3) / 4;
-                if (fused == 2)
-                    hipLaunchKernelGGL(group_attn_fused2_kernel, dim3(units), dim3(64), 0, s, x, ln_weight, ln_bias, eps, wq, kvf, wo, y, G);
-                else
+                if (fused == 2) {
+                    // the two 256 x 256 weights in fragment order (2 x 128 KB at the start of the workspace): two launches of 32
+                    // workgroups in front of the step
+                    unsigned short *wqp = (unsigned short *)workspace, *wop = wqp + 65536;
+                    hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, wq, wqp);
+                    hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, wo, wop);
+                    hipLaunchKernelGGL(group_attn_fused2_kernel, dim3(units), dim3(64), 0, s, x, ln_weight, ln_bias, eps, wqp, kvf, wop, y, G);
+                } else
                     hipLaunchKernelGGL(group_attn_fused_kernel, dim3((units + 1) / 2), dim3(128), 0, s, x, ln_weight, ln_bias, eps,
                                        wq, kvf, wo, y, G);
             }

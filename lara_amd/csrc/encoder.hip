@@ -76,8 +76,9 @@ int64_t lara_groupblock_workspace_bytes(int32_t scenes, int32_t R) {
     if (scenes < 0 || R <= 0 || (R & 1)) return LARA2DGS_E_INVALID;
     const int64_t M = (int64_t)scenes * R * R * R;
     // xn | q | o | kv (bf16 [M,256] each; q|o doubles as the MLP hidden [M,512]) + (mean, rstd) per row
-    // + one zeroed row (the convolution's padding voxels)
-    return M * 256 * 2 * 4 + M * 8 + 512 + 1024;
+    // + one zeroed row (the convolution's padding voxels); + 256 KB: the attention step's fused path keeps its packed weights
+    // in front of its regions (lara_groupattn_workspace_bytes)
+    return M * 256 * 2 * 4 + M * 8 + 512 + 1024 + 262144;
 }
 
 int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *x,

@@ -276,18 +276,31 @@ group_attn_fused_kernel(const float *x /* may alias y: the block runs in place *
 // ---- the same step, second cut (round 4): what made the kernel above latency-bound was not its occupancy alone but FOUR
 // exposed memory round trips per unit -- the LayerNorm's row loads four at a time, the K|V DMA waited for at the start of
 // each half of the heads, and the residual loaded inside every output tile's epilogue.  Here all 32 rows of x are requested in
-// two batches before any arithmetic, both halves of K|V start travelling before the Q projection (8 KB more LDS: one wave per
-// workgroup, 32 KB), and the residual is prefetched one tile ahead like the weight fragments.  In-place safe (x may alias y):
+// two batches before any arithmetic, the first half of K|V starts travelling before the Q projection and the second through
+// registers during the first half's attention, the weights are read in fragment order (pack_weight_frag_kernel: the row-major
+// fragments cost 64 L1 accesses per instruction and the first cut sat on the L1's access rate), and the residual is prefetched one
+// tile ahead like the weight fragments.  One wave per workgroup, 24 KB of LDS: six waves per CU.  In-place safe (x may alias y):
 // a wave reads all of its rows' x before the LayerNorm and re-reads a tile's residual before it stores that tile.
+// A [256, 256] bf16 weight (row = output feature, K contiguous) in the order group_attn_fused2_kernel's A-operand fragments are
+// read in: out[((nt * 16 + ks) * 64 + lane) * 8 + e] = W[nt * 32 + (lane & 31)][ks * 16 + 8 * (lane >> 5) + e].  Straight from
+// the row-major matrix a fragment instruction touches 32 rows x 32 bytes -- 64 separate L1 accesses, 23.6 k per wave and unit,
+// and the kernel sat on the L1's access rate (TCP_TOTAL_CACHE_ACCESSES 96.6 M per launch = 180 us of 222); packed, the same
+// instruction reads 1 KB of consecutive bytes.
+__global__ void __launch_bounds__(256) pack_weight_frag_kernel(const unsigned short *__restrict__ W, unsigned short *__restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk per thread: 8192 chunks
+    const int lane = t & 63, ks = (t >> 6) & 15, nt = t >> 10;
+    *(uint4 *)(out + (size_t)t * 8) = *(const uint4 *)(W + (size_t)(nt * 32 + (lane & 31)) * 256 + ks * 16 + 8 * (lane >> 5));
+}
+
 __global__ void __launch_bounds__(64)
 group_attn_fused2_kernel(const float *x /* may alias y: the block runs in place */, const float *__restrict__ gamma,
-                        const float *__restrict__ beta, const float eps, const unsigned short *__restrict__ Wq,
-                        const unsigned short *__restrict__ KV, const unsigned short *__restrict__ Wo, float *y, const int G) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[32768];
+                        const float *__restrict__ beta, const float eps, const unsigned short *__restrict__ Wq /* packed */,
+                        const unsigned short *__restrict__ KV, const unsigned short *__restrict__ Wo /* packed */, float *y, const int G) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[24576];
     const int lane = threadIdx.x & 63;
     const int unit = blockIdx.x, g0 = unit * 4;
     if (g0 >= G) return;
-    unsigned char *R = lds_all, *KVr = R + 16384;      // K|V: [half][K 4 KB | V 4 KB]
+    unsigned char *R = lds_all, *KVr = R + 16384;      // K|V of one half of the heads: K 4 KB | V 4 KB
     const int c16 = lane & 15, q4 = lane >> 4;
     const int q_rows = min(32, (G - g0) * 8), kv_rows = min(16, (G - g0) * 4);  // ragged last unit
     const int srow = lane >> 4, sphys = lane & 15;
@@ -308,10 +321,8 @@ group_attn_fused2_kernel(const float *x /* may alias y: the block runs in place 
                 const float mean = wave_total((v[i].x + v[i].y) + (v[i].z + v[i].w)) * (1.0f / 256.0f);
                 const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d4 = v[i].w - mean;
                 const float rstd = 1.0f / sqrtf(wave_total(a * a + b * b + c * c + d4 * d4) * (1.0f / 256.0f) + eps);
-                ushort4 o;
-                o.x = f2bf(a * rstd * gm.x + bt.x); o.y = f2bf(b * rstd * gm.y + bt.y);
-                o.z = f2bf(c * rstd * gm.z + bt.z); o.w = f2bf(d4 * rstd * gm.w + bt.w);
-                *(ushort4 *)(R + hh * 8192 + r * 256 + ((chunk ^ (r & 15)) << 4) + sub) = o;
+                *(uint2 *)(R + hh * 8192 + r * 256 + ((chunk ^ (r & 15)) << 4) + sub) =
+                    make_uint2(f2bf2(a * rstd * gm.x + bt.x, b * rstd * gm.y + bt.y), f2bf2(c * rstd * gm.z + bt.z, d4 * rstd * gm.w + bt.w));
             }
         }
     }
@@ -324,31 +335,31 @@ group_attn_fused2_kernel(const float *x /* may alias y: the block runs in place 
             bf[ks] = *(const bf16x8 *)(R + (f >> 7) * 8192 + frow * 256 + ((((f & 127) >> 3) ^ (frow & 15)) << 4));
         }
     };
-    // the unit's K|V rows (both halves of the heads) start travelling now; they are needed after the Q projection
+    // the unit's K|V rows of the first half of the heads start travelling now; they are needed after the Q projection.  (The
+    // second half follows through REGISTERS while the first is being consumed -- see the attention loop: 24 KB of LDS per wave
+    // = six waves per CU; with both halves resident it was 32 KB = four.)
 #pragma unroll
-    for (int hh = 0; hh < 2; hh++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = 4 * i + srow, chunk = sphys ^ (row & 15);
-            const unsigned short *src = KV + (size_t)(g0 * 4 + min(row, kv_rows - 1)) * 512 + hh * 128 + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(KVr + hh * 8192 + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 256),
-                                             (__attribute__((address_space(3))) void *)(KVr + hh * 8192 + 4096 + i * 1024), 16, 0, 0);
-        }
+    for (int i = 0; i < 4; i++) {
+        const int row = 4 * i + srow, chunk = sphys ^ (row & 15);
+        const unsigned short *src = KV + (size_t)(g0 * 4 + min(row, kv_rows - 1)) * 512 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(KVr + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 256),
+                                         (__attribute__((address_space(3))) void *)(KVr + 4096 + i * 1024), 16, 0, 0);
+    }
     bf16x8 bf[16], wf[16];
     load_rows(bf);
 #pragma unroll
-    for (int ks = 0; ks < 16; ks++) wf[ks] = *(const bf16x8 *)(Wq + (size_t)frow * 256 + fk + ks * 16);
+    for (int ks = 0; ks < 16; ks++) wf[ks] = *(const bf16x8 *)(Wq + ((size_t)ks * 64 + lane) * 8);
     // ---- 2. Q^T tiles: 8 tiles of 32 features; the accumulator's registers 4g..4g+3 are features
     //         n0 + 8g + 4 (lane >> 5) + (0..3) of row (lane & 31)
 #pragma unroll 1
     for (int nt = 0; nt < 8; nt++) {
         // the weight fragments of the NEXT tile are requested before this tile's MFMAs (a tile is one L2 round trip)
-        const unsigned short *wnext = Wq + (size_t)(min(nt + 1, 7) * 32 + frow) * 256 + fk;
+        const unsigned short *wnext = Wq + ((size_t)min(nt + 1, 7) * 1024 + lane) * 8;
         bf16x8 wn[16];
 #pragma unroll
-        for (int ks = 0; ks < 16; ks++) wn[ks] = *(const bf16x8 *)(wnext + ks * 16);
+        for (int ks = 0; ks < 16; ks++) wn[ks] = *(const bf16x8 *)(wnext + ks * 512);
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -357,18 +368,33 @@ group_attn_fused2_kernel(const float *x /* may alias y: the block runs in place 
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int f = nt * 32 + 8 * g + 4 * (lane >> 5);
-            ushort4 o;
-            o.x = f2bf(acc[4 * g]); o.y = f2bf(acc[4 * g + 1]); o.z = f2bf(acc[4 * g + 2]); o.w = f2bf(acc[4 * g + 3]);
-            *(ushort4 *)(R + (f >> 7) * 8192 + frow * 256 + ((((f & 127) >> 3) ^ (frow & 15)) << 4) + ((f & 7) << 1)) = o;
+            *(uint2 *)(R + (f >> 7) * 8192 + frow * 256 + ((((f & 127) >> 3) ^ (frow & 15)) << 4) + ((f & 7) << 1)) =
+                make_uint2(f2bf2(acc[4 * g], acc[4 * g + 1]), f2bf2(acc[4 * g + 2], acc[4 * g + 3]));
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ks++) wf[ks] = wn[ks];
     }
     // ---- 3. attention, half of the heads at a time (Q is in place; K|V rows come by LDS-DMA)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K|V have arrived long ago (wave-private region: no barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K|V (first half) have arrived long ago (wave-private region: no barrier)
+    uint4 pk[4], pv[4];                                  // the second half's K|V rows, in the DMA's lane order, on their way
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = 4 * i + srow, chunk = sphys ^ (row & 15);
+        const unsigned short *src = KV + (size_t)(g0 * 4 + min(row, kv_rows - 1)) * 512 + 128 + chunk * 8;
+        pk[i] = *(const uint4 *)src;
+        pv[i] = *(const uint4 *)(src + 256);
+    }
     for (int hh = 0; hh < 2; hh++) {
-        unsigned char *Qr = R + hh * 8192, *Kr = KVr + hh * 8192, *Vr = Kr + 4096;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned char *Qr = R + hh * 8192, *Kr = KVr, *Vr = KVr + 4096;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous half's LDS reads are retired
+        if (hh == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                *(uint4 *)(Kr + i * 1024 + lane * 16) = pk[i];
+                *(uint4 *)(Vr + i * 1024 + lane * 16) = pv[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll 2
         for (int hl = 0; hl < 8; hl++) {
             const int ck = 2 * hl + (q4 >> 1), sub = (q4 & 1) * 8;
@@ -391,15 +417,17 @@ group_attn_fused2_kernel(const float *x /* may alias y: the block runs in place 
                 const float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
                 const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx), e2 = __expf(s2 - mx), e3 = __expf(s3 - mx);
                 const float inv = valid ? 1.0f / (e0 + e1 + e2 + e3) : 0.f;
+                const uint2 pp = make_uint2(f2bf2(e0 * inv, e1 * inv), f2bf2(e2 * inv, e3 * inv));
                 s16x4 pf;
-                pf[0] = (short)f2bf(e0 * inv); pf[1] = (short)f2bf(e1 * inv);
-                pf[2] = (short)f2bf(e2 * inv); pf[3] = (short)f2bf(e3 * inv);
+                __builtin_memcpy(&pf, &pp, 8);
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
                 o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, vf, o, 0, 0, 0);
+                const unsigned o01 = f2bf2(o[0], o[1]), o23 = f2bf2(o[2], o[3]);
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int orow = 16 * t + 4 * q4 + rr;
-                    *(unsigned short *)(Qr + orow * 256 + ((cv ^ (orow & 15)) << 4) + vb) = f2bf(o[rr]);
+                    const unsigned w = rr < 2 ? o01 : o23;
+                    *(unsigned short *)(Qr + orow * 256 + ((cv ^ (orow & 15)) << 4) + vb) = (unsigned short)((rr & 1) ? (w >> 16) : w);
                 }
             }
         }
@@ -408,37 +436,44 @@ group_attn_fused2_kernel(const float *x /* may alias y: the block runs in place 
     // ---- 4. y^T = W_o O^T, + x, stored 16 bytes per lane
     load_rows(bf);
 #pragma unroll
-    for (int ks = 0; ks < 16; ks++) wf[ks] = *(const bf16x8 *)(Wo + (size_t)frow * 256 + fk + ks * 16);
-    const bool row_ok = frow < q_rows;
-    // the residual rows of a tile are requested one tile ahead, like the weight fragments (x is long gone from the caches)
-    const size_t xrow = (row0 + min(frow, q_rows - 1)) * 256 + 4 * (lane >> 5);
+    for (int ks = 0; ks < 16; ks++) wf[ks] = *(const bf16x8 *)(Wo + ((size_t)ks * 64 + lane) * 8);
+    // Epilogue through LDS: the accumulator gives a lane 4 consecutive features of ONE row per register group, i.e. a store (and
+    // the residual's load) instruction touches 32 rows x 2 pieces of 16 bytes -- 64 separate L1 accesses.  The tile (32 rows x 32
+    // features, fp32) is bounced through the row buffer, which step 4 no longer needs once `bf` is loaded: lane l then owns the
+    // 16-byte chunk (l & 7) of rows (l >> 3) + 8 p, p = 0..3 -- 128 contiguous bytes per row and 8 rows per instruction, for the
+    // residual's loads (requested one tile ahead, like the weight fragments) and for the stores.
+    float *T = (float *)R;                           // [32 rows][36 floats]: 144-byte rows spread the 16-byte writes over the banks
+    const int erow = lane >> 3, ec = (lane & 7) * 4;
     float4 xr[4], xn4[4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) xr[g] = *(const float4 *)(x + xrow + 8 * g);
+    for (int p4 = 0; p4 < 4; p4++) xr[p4] = *(const float4 *)(x + (row0 + min(erow + 8 * p4, q_rows - 1)) * 256 + ec);
 #pragma unroll 1
     for (int nt = 0; nt < 8; nt++) {
-        const unsigned short *wnext = Wo + (size_t)(min(nt + 1, 7) * 32 + frow) * 256 + fk;
+        const unsigned short *wnext = Wo + ((size_t)min(nt + 1, 7) * 1024 + lane) * 8;
         bf16x8 wn[16];
 #pragma unroll
-        for (int ks = 0; ks < 16; ks++) wn[ks] = *(const bf16x8 *)(wnext + ks * 16);
+        for (int ks = 0; ks < 16; ks++) wn[ks] = *(const bf16x8 *)(wnext + ks * 512);
 #pragma unroll
-        for (int g = 0; g < 4; g++) xn4[g] = *(const float4 *)(x + xrow + min(nt + 1, 7) * 32 + 8 * g);
+        for (int p4 = 0; p4 < 4; p4++) xn4[p4] = *(const float4 *)(x + (row0 + min(erow + 8 * p4, q_rows - 1)) * 256 + min(nt + 1, 7) * 32 + ec);
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[i] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 16; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bf[ks], acc, 0, 0, 0);
-        if (row_ok) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const size_t at = (row0 + frow) * 256 + nt * 32 + 8 * g + 4 * (lane >> 5);
-                *(float4 *)(y + at) = make_float4(acc[4 * g] + xr[g].x, acc[4 * g + 1] + xr[g].y, acc[4 * g + 2] + xr[g].z, acc[4 * g + 3] + xr[g].w);
-            }
+        for (int g = 0; g < 4; g++)
+            *(float4 *)(T + frow * 36 + 8 * g + 4 * (lane >> 5)) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+#pragma unroll
+        for (int p4 = 0; p4 < 4; p4++) {
+            const int row = erow + 8 * p4;
+            const float4 v = *(const float4 *)(T + row * 36 + ec);
+            if (row < q_rows)
+                *(float4 *)(y + (row0 + row) * 256 + nt * 32 + ec) = make_float4(v.x + xr[p4].x, v.y + xr[p4].y, v.z + xr[p4].z, v.w + xr[p4].w);
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ks++) wf[ks] = wn[ks];
 #pragma unroll
-        for (int g = 0; g < 4; g++) xr[g] = xn4[g];
+        for (int p4 = 0; p4 < 4; p4++) xr[p4] = xn4[p4];
     }
 }
 

@@ -10,11 +10,21 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// fp32 -> bf16, round to nearest even, on gfx950's v_cvt_pk_bf16_f32 (two values per instruction; the integer form
+// u += 0x7fff + ((u >> 16) & 1) >> 16 is three half-rate instructions per value, and a kernel that rounds hundreds of values per lane
+// -- the fused attention step: 512 -- spent 40 % of its vector instructions on it).  Same result for every finite input and inf.
+// (through the compiler's own conversion, not inline asm: an asm statement that reads an MFMA accumulator is invisible to the
+// hazard recognizer -- the first version did exactly that behind the attention's P.V product and produced NaNs)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned f2bf2(float lo, float hi) {   // bf16(lo) | bf16(hi) << 16
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    unsigned u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
 }
+__device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)f2bf2(f, f); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 // ---- LayerNorm(C = 256) + bf16 cast: one wave per token, 4 channels per lane ---------------------

@@ -92,10 +92,11 @@ def test_ragged_group_count_and_larger_batch(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [1, 2])
-def test_fused_wave_private_kernel_is_parity_green(hip_lib, mode):
-    """LARA_GA_FUSED=1 / 2 (one wave-private kernel for LayerNorm, Q projection, attention, output projection + residual,
-    first and second cut), read at load: run the same checks in a child."""
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_every_mode_of_the_attention_step_is_parity_green(hip_lib, mode):
+    """LARA_GA_FUSED = 0 (five launches), 1, 2 (the K|V projection + one wave-private kernel for LayerNorm, Q projection,
+    attention, output projection + residual: first and second cut; 2 is the default), read at load: run
+    the same checks in a child per mode."""
     import subprocess
     import sys
     code = (
