@@ -422,6 +422,8 @@ def measure_roofline(scenes, settings, gc, ga, args):
     roof = {"kernel": dom, "bound": "valu" if composite else "hbm", "achieved": round(t["alg_GBs"], 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(t["alg_GBs"] / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": traffic_src,
+            # the same fraction on the COUNTER bytes (calibrated: 2 x FETCH_SIZE + WRITE_SIZE) instead of the algorithmic model
+            "traffic_frac": (round(traffic / (t["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
             "valu_issue_frac": valu, "valu_issue_source": valu_src,
             # useful FMA lane-operations / issued VALU lane-slots: filled in by the cpu_baseline leg, whose oracle counts the
             # (pixel, splat) pairs the frame really blends (`blended_pairs`); issued = SQ_INSTS_VALU x 64 lanes (committed PMC)
