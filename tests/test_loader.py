@@ -93,3 +93,38 @@ def test_collate_builds_the_reference_rays_on_the_device():
                 want = fx[f"test4.{i}.{k}"]
                 got = batch[k][b].cpu().numpy()
                 assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), k
+
+
+def test_worker_side_collate_is_picklable_and_runs_in_dataloader_workers():
+    """`collate_cpu` (the half that may run inside DataLoader workers) is a module-level function, drops the two ray keys and
+    needs no GPU: it is driven here by a real DataLoader with two worker processes."""
+    import pickle
+    from lara_amd import dataset
+    pickle.dumps(dataset.collate_cpu)
+    fx = np.load(FX)
+    items = [_fixture_item(fx, "test4", i) for i in (0, int(fx["test4.len"]) - 1)]
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            return dict(items[i % 2], tar_rays=np.zeros((0,), np.float32), tar_rays_down=np.zeros((0,), np.float32))
+    loader = torch.utils.data.DataLoader(DS(), batch_size=2, num_workers=2, collate_fn=dataset.collate_cpu)
+    batches = list(loader)
+    assert len(batches) == 2
+    for b in batches:
+        assert "tar_rays" not in b and "tar_rays_down" not in b
+        assert b["tar_c2w"].shape == (2, 8, 4, 4) and not b["tar_c2w"].is_cuda
+
+
+@pytest.mark.gpu
+def test_on_device_finishes_cpu_collated_batches():
+    from lara_amd import dataset
+    fx = np.load(FX)
+    idx = (0, int(fx["test4.len"]) - 1)
+    items = [_fixture_item(fx, "test4", i) for i in idx]
+    got = list(dataset.on_device([dataset.collate_cpu(items)], "cuda"))[0]
+    want = dataset.collate_to_device(items)
+    for k in ("tar_rays", "tar_rays_down", "tar_c2w", "tar_rgb"):
+        assert got[k].is_cuda and torch.equal(got[k], want[k]), k
