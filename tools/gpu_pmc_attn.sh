@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 4, GPU call F: where the fused attention kernel's time goes (SQ wait / issue counters, VMEM and L1/L2 traffic).
+# Where the attention step's time goes: SQ wait / issue counters, VMEM instructions and L1 / L2 traffic of every kernel of
+# tools/attn_bench.py (modes in $MODES, default 2 = the fused kernel).  Prints the per-kernel means.
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
@@ -11,7 +12,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $SET -d $OUT/pmca_r04_$i -o pmc -- \
-      python $REPO/tools/attn_bench.py --reps 2 --modes 2 > $OUT/pmca_r04_$i.log 2>&1
+      python $REPO/tools/attn_bench.py --reps 2 --modes ${MODES:-2} > $OUT/pmca_r04_$i.log 2>&1
   echo "pass $i rc=$?"
 done
 find $OUT/pmca_r04_* -type f -size +8M -delete
