@@ -390,10 +390,19 @@ def measure_roofline(scenes, settings, gc, ga, args):
              for k, (n, t) in agg.items()}
     dom = max(table, key=lambda k: table[k]["avg_us"] * table[k]["launches"])
     t = table[dom]
-    # Counter-derived figures need rocprofv3 passes of their own (tools/gpu_traffic.sh, tools/gpu_pmc_bwd.sh); their
-    # summaries are committed under profiles/ and READ here -- they are not measured in this run and say so.
+    # Counter-derived figures need rocprofv3 passes of their own: `live_counters` runs three short ones as child processes (this
+    # run's numbers); where that is not possible (no rocprofv3, a pass failed, LARA_BENCH_NO_LIVE_PMC=1) the summaries committed
+    # under profiles/ (tools/gpu_profile.sh, tools/gpu_traffic.sh) are READ instead and the `*_source` fields say so.
     traffic, traffic_src, valu, valu_src, insts, insts_src = None, None, None, None, None, None
-    if args.grid == 64 and args.res == 512:
+    live = None if os.environ.get("LARA_BENCH_NO_LIVE_PMC") == "1" else live_counters(dom, args)
+    if live is not None:
+        src = (f"measured in this run: rocprofv3 --kernel-trace --pmc, three child passes of the serialised raster step (one scene, "
+               f"{live['launches']} launches of {dom} averaged)")
+        # calibrated (profiles/r04a_traffic_calibration.json): gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes; unit KB
+        traffic, traffic_src = int((2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024), src + "; bytes = 2 x FETCH_SIZE + WRITE_SIZE"
+        valu, valu_src = round(4.0 * live["SQ_ACTIVE_INST_VALU"] / (1024.0 * live["GRBM_GUI_ACTIVE"] / 8.0), 4), src
+        insts, insts_src = live["SQ_INSTS_VALU"], src
+    elif args.grid == 64 and args.res == 512:
         # (same regime, and the per-view launches: `<tag>_views_pmc_summary.csv` holds the 8-view launches of a multi-view call)
         same = (lambda f: "trained" in os.path.basename(f)) if args.regime == "trained" else (lambda f: "trained" not in os.path.basename(f))
         tagged = lambda f: same(f) and "_views_" not in os.path.basename(f)
@@ -449,6 +458,48 @@ def _newest_profile(pattern, reader, accept=lambda f: True):
         except Exception:
             continue
     return None, None
+
+
+def live_counters(kernel, args, timeout_s=90):
+    """The dominant kernel's SQ and HBM counters MEASURED IN THIS RUN: three short rocprofv3 passes (counters in their own passes,
+    `--kernel-trace --pmc` only, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass) of this script's
+    serialised raster step (one scene, one operator call per view, one stream), run as child processes from /tmp.  Returns
+    {counter: mean per launch of `kernel`} or None (no rocprofv3 on the box, a pass timed out or produced nothing -- the
+    committed summaries under profiles/ are read instead and say so)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--scenes", "1", "--views", str(args.views), "--res", str(args.res),
+            "--grid", str(args.grid), "--regime", args.regime, "--step", "raster", "--raster-api", "loop", "--streams", "1", "--no-fine",
+            "--no-cpu-baseline", "--no-roofline"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for counters in (["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]):
+        d = tempfile.mkdtemp(prefix="lara_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *counters, "-d", d, "-o", "pmc", "--", *base],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            acc = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if (kernel + "_kernel") in row["Kernel_Name"]:
+                        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in counters:
+                if c not in acc:
+                    return None
+                out[c] = sum(acc[c]) / len(acc[c])
+                out["launches"] = len(acc[c])
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def _valu_issue_frac(csv_path, kernel):
@@ -1669,7 +1720,7 @@ def main():
             pairs = out["cpu_baseline"]["blended_pairs_view0"]
             roof["valu_useful_frac"] = round(pairs * USEFUL_FMA_PER_PAIR[roof["kernel"]] / (roof["valu_insts_per_launch"] * 64.0), 4)
             roof["valu_useful_what"] = (f"{pairs} blended (pixel, splat) pairs of view 0 (counted by the CPU oracle in this run) x "
-                                        f"{USEFUL_FMA_PER_PAIR[roof['kernel']]} FMA-equivalents / (SQ_INSTS_VALU x 64 lanes, committed PMC)")
+                                        f"{USEFUL_FMA_PER_PAIR[roof['kernel']]} FMA-equivalents / (SQ_INSTS_VALU x 64 lanes: {roof['valu_insts_source']})")
     if world > 1:
         dist.destroy_process_group()
     sys.stdout.flush()
