@@ -90,7 +90,8 @@ typedef struct lara2dgs_state_layout {
     int64_t seg_cnt;     /* uint32[tiles]: boundaries in use: the same number, or 0 for a tile whose checkpoint
                           * rows did not fit (its backward then runs as one segment) */
     int64_t bwd_order;   /* uint32[tiles]: tile ids by length of the last (partial) segment, longest first */
-    int64_t bwd_items;   /* uint32[capacity/512+1][2]: (tile, segment) of every full segment (tile = ~0: unused) */
+    int64_t bwd_items;   /* uint32[capacity/512+1 + tiles][2]: (tile, segment) of every full segment (tile = ~0: unused); after the
+                          * backward's ordering pass (header[22] = 1): of every work item, last segments included, dearest first */
     int64_t ckpt;        /* float[capacity/1024+1][10][256]: the ten per-pixel running sums as the forward walk
                           * crosses a segment boundary; lets segments of one tile run on different CUs */
     int64_t pair_mask;   /* uint64[capacity]: per list position, the forward's candidate mask of the entry over the tile's
@@ -98,6 +99,9 @@ typedef struct lara2dgs_state_layout {
                           * the surfel's footprint a second time */
     int64_t tile_maxc;   /* uint32[tiles]: the largest last-contributor position over the tile's pixels, written by the forward
                           * composite: a backward work item (tile, segment) beyond it exits on its first load */
+    int64_t seg_cost;    /* uint32[capacity/512+1 + tiles]: what each backward work item cost the FORWARD (wave-trips of its
+                          * 512-entry round): [seg_base[tile] + s] for the full segments, [capacity/512+1 + tile] for a tile's
+                          * last one; the forward re-orders bwd_items / bwd_order by it, dearest first */
     int64_t total;
 } lara2dgs_state_layout;
 

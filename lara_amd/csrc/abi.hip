@@ -104,6 +104,7 @@ StateView carve_state(const ViewDev &v, void *state) {
     s.ckpt = (float *)(b + L.ckpt);
     s.pair_mask = (uint2 *)(b + L.pair_mask);
     s.tile_maxc = (uint32_t *)(b + L.tile_maxc);
+    s.seg_cost = (uint32_t *)(b + L.seg_cost);
     return s;
 }
 
@@ -217,9 +218,10 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
     StateView st = carve_state(v, const_cast<void *>(state));
     ScratchLayout SL;
     ScratchView sc = carve_scratch(v, scratch, SL);
-    hipError_t e = hipMemsetAsync(sc.pair_valid, 0, (size_t)(SL.total - SL.pair_valid), s);
-    if (e != hipSuccess) { l2d_set_hip_error(e); return LARA2DGS_E_LAUNCH; }
-    int rc = launch_composite_bwd(v, st, sc, dL_dcolor, dL_dallmap, s);
+    // one launch: the validity bitmap zeroed + the work items ordered dearest first (by what they cost the forward)
+    int rc = launch_bwd_order(v, st, sc, s, nullptr, sc.pair_valid, SL.total - SL.pair_valid);
+    if (rc) return rc;
+    rc = launch_composite_bwd(v, st, sc, dL_dcolor, dL_dallmap, s);
     if (rc) return rc;
     return launch_preprocess_bwd(v, means3D, shs, colors_precomp, scales, rotations, transmat_precomp,
                                  radii, st, sc, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors,
@@ -515,22 +517,25 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
             sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL[i]);
             rad[i] = radii + (int64_t)i * v0.P;
         }
-        // validity bitmaps of all views: one strided fill on the caller's stream, in front of the fork
-        zero_strided(sc[0].pair_valid, scratch_stride, SL[0].total - SL[0].pair_valid, n_views, caller);
+        // validity bitmaps of all views + the ordering of every view's work items: one launch per chunk of views on the caller's
+        // stream, in front of the fork
         if (g_batch_kernels.load()) {
             for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
                 ViewBatch vb{};
                 vb.n = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
                 vb.state_stride = state_stride; vb.scratch_stride = scratch_stride;
                 for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
-                rc = launch_composite_bwd(vd[i0], st[i0], sc[i0], dL_dcolor + (int64_t)i0 * 3 * HW, dL_dallmap + (int64_t)i0 * 7 * HW, caller, &vb);
+                rc = launch_bwd_order(vd[i0], st[i0], sc[i0], caller, &vb, sc[i0].pair_valid, SL[i0].total - SL[i0].pair_valid);
+                if (rc == LARA2DGS_OK)
+                    rc = launch_composite_bwd(vd[i0], st[i0], sc[i0], dL_dcolor + (int64_t)i0 * 3 * HW, dL_dallmap + (int64_t)i0 * 7 * HW, caller, &vb);
             }
         } else {
             if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
             for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
             for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
                 hipStream_t s = lane_stream(i % lanes);
-                rc = launch_composite_bwd(vd[i], st[i], sc[i], dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW, s);
+                rc = launch_bwd_order(vd[i], st[i], sc[i], s, nullptr, sc[i].pair_valid, SL[i].total - SL[i].pair_valid);
+                if (rc == LARA2DGS_OK) rc = launch_composite_bwd(vd[i], st[i], sc[i], dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW, s);
             }
             for (int k = 1; k < lanes; k++) {
                 HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));

@@ -62,10 +62,11 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     uint32_t *seg_base;   // [tiles+1] exclusive scan of interior segment boundaries per tile
     uint32_t *seg_cnt;    // [tiles] interior boundaries actually used (0 when the checkpoint slab is full)
     uint32_t *bwd_order;  // [tiles] tile ids by length of their last (partial) segment, longest first
-    uint2 *bwd_items;     // [cap/L2D_SEG+1] (tile, segment) of every full segment
+    uint2 *bwd_items;     // [cap/L2D_SEG+1 + tiles] (tile, segment) of every full segment; once ordered (header[22]): of EVERY work item
     float *ckpt;          // [cap/L2D_SEG+1][L2D_CKPT_F][256] per-pixel prefix sums at segment boundaries
     uint2 *pair_mask;     // [cap] per list position: the forward's 64-bit candidate mask (lo, hi) of the entry
     uint32_t *tile_maxc;  // [tiles] max over the tile's pixels of the last contributor (list position + 1), from the forward
+    uint32_t *seg_cost;   // [cap/L2D_SEG+1 + tiles] forward wave-trips per backward work item (full segments, then last segments)
 };
 
 struct ScratchView {
@@ -106,10 +107,11 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->seg_base = o;    o = align_up(o + (tiles + 1) * 4, 256);
     L->seg_cnt = o;     o = align_up(o + tiles * 4, 256);
     L->bwd_order = o;   o = align_up(o + tiles * 4, 256);
-    L->bwd_items = o;   o = align_up(o + nseg * 8, 256);
+    L->bwd_items = o;   o = align_up(o + (nseg + tiles) * 8, 256);   // (+ tiles: the ordered list also holds every tile's last segment)
     L->ckpt = o;        o = align_up(o + l2d_ckpt_slots(cap) * L2D_CKPT_F * 256 * 4, 256);
     L->pair_mask = o;   o = align_up(o + cap * 8, 256);
     L->tile_maxc = o;   o = align_up(o + tiles * 4, 256);
+    L->seg_cost = o;    o = align_up(o + (nseg + tiles) * 4, 256);
     L->total = o;
 }
 
@@ -149,6 +151,9 @@ int launch_preprocess_fwd_views(const ViewDev &v, int n, const ViewDev *views, c
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb = nullptr);
 int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
                          hipStream_t s, const ViewBatch *vb = nullptr);
+// re-orders the backward's work items by what they cost the forward AND zero-fills [zero_base, zero_base + zero_bytes) (per view at
+// the scratch stride): the one launch in front of composite_bwd
+int launch_bwd_order(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb, void *zero_base, int64_t zero_bytes);
 int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const float *dL_dcolor,
                          const float *dL_dallmap, hipStream_t s, const ViewBatch *vb = nullptr);
 int launch_preprocess_bwd(const ViewDev &v, const float *means3D, const float *shs,

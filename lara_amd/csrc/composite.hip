@@ -306,6 +306,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
                      float *__restrict__ ckpt, uint2 *__restrict__ pair_mask, uint32_t *__restrict__ tile_maxc,
+                     uint32_t *__restrict__ seg_cost,
                      float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs,
                      const ViewBatch vb) {
     {   // this workgroup's view (blockIdx.z; a single-view launch has strides 0)
@@ -314,7 +315,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         geom = l2d_view_ptr(geom, sst); tile_order = l2d_view_ptr(tile_order, sst); cullbox = l2d_view_ptr(cullbox, sst);
         final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
         seg_cnt = l2d_view_ptr(seg_cnt, sst); ckpt = l2d_view_ptr(ckpt, sst); pair_mask = l2d_view_ptr(pair_mask, sst);
-        tile_maxc = l2d_view_ptr(tile_maxc, sst);
+        tile_maxc = l2d_view_ptr(tile_maxc, sst); seg_cost = l2d_view_ptr(seg_cost, sst);
         slabs = l2d_view_ptr(slabs, vb.scratch_stride);
         out_color = l2d_view_ptr(out_color, vb.n ? 3 * HWb : 0); out_allmap = l2d_view_ptr(out_allmap, vb.n ? 7 * HWb : 0);
         if (vb.n) v.bg = vb.bg[blockIdx.z];
@@ -324,6 +325,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     __shared__ float4 rec[REC4 * CHUNK];
     __shared__ unsigned long long qmask[4][16][CHUNK / 64];  // per wave, per quad: candidate words of the round
     __shared__ uint32_t s_tmax;                               // largest last contributor over the tile's pixels
+    __shared__ uint32_t s_cost;                               // wave-trips of the current round, summed over the four waves
     const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -376,8 +378,16 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const long long dbg_t0 = (v.dbg & 32u) ? (long long)__builtin_readcyclecounter() : 0ll;
     int dbg_rounds = 0;
 
-    // software pipeline of the list walk: ids two rounds ahead, cull boxes one round ahead
+    // What each 512-entry round costs (wave-trips of its walk) is what the backward's work item over the same entries will
+    // cost: recorded per (tile, segment) -- full segments at seg_base[tile] + s, everything from the last (partial) segment on in
+    // the tile's own slot -- and used by bwd_order_kernel to launch the backward's items dearest first.
     const int tid = threadIdx.x;
+    const uint32_t cost_nb = MODE == 0 ? seg_cnt[tile] : 0u;
+    uint32_t *const cost_full = seg_cost + seg_base[tile], *const cost_last = seg_cost + (v.cap / L2D_SEG + 1u) + tile;
+    if (MODE == 0) {
+        for (uint32_t q = tid; q <= cost_nb; q += 256) *(q < cost_nb ? cost_full + q : cost_last) = 0u;
+    }
+    int cost_round = -1;
     constexpr int SPT = CHUNK / 256;  // list entries staged per thread and round
     uint32_t id1[SPT], id2[SPT];
     float4 cb1[SPT];
@@ -391,6 +401,11 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     for (int q = 0; q < SPT; q++) cb1[q] = lo + q * 256 + tid < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = lo; base < hi; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
+        if (MODE == 0 && tid == 0) {     // (between this barrier and the staging barrier no wave is in its walk)
+            if (cost_round >= 0) { if ((uint32_t)cost_round < cost_nb) cost_full[cost_round] = s_cost; else *cost_last += s_cost; }
+            s_cost = 0u;
+        }
+        cost_round = (base - lo) / CHUNK;
         dbg_rounds++;
         if (MODE != 1 && base && base % L2D_SEG == 0 && !px.done && (uint32_t)(base / L2D_SEG) <= seg_cnt[tile]) {
             // crossing a segment boundary: park the running sums over entries [0, base) so that the
@@ -473,12 +488,16 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             }
             if (((__ballot(px.done) >> (lane & ~3)) & 0xfull) == 0xfull) { mm = 0ull; w = nw; n0 = false; n1 = false; }
         };
+        uint32_t ntrips = 0;
         while (true) {
             if (__ballot(hA0) == 0ull) break;
             trip(rA0, rA1, jA0, jA1, hA0, hA1, rB0, rB1, jB0, jB1, hB0, hB1);
+            ntrips++;
             if (__ballot(hB0) == 0ull) break;
             trip(rB0, rB1, jB0, jB1, hB0, hB1, rA0, rA1, jA0, jA1, hA0, hA1);
+            ntrips++;
         }
+        if (MODE == 0 && lane == 0 && ntrips) atomicAdd(&s_cost, ntrips);
     }
     const float T = px.T;
     if (MODE == 1) {
@@ -505,7 +524,10 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         for (int d = 1; d < 64; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
         if (lane == 0) atomicMax(&s_tmax, m);
         __syncthreads();
-        if (threadIdx.x == 0) tile_maxc[tile] = s_tmax;
+        if (threadIdx.x == 0) {
+            tile_maxc[tile] = s_tmax;
+            if (cost_round >= 0) { if ((uint32_t)cost_round < cost_nb) cost_full[cost_round] = s_cost; else *cost_last += s_cost; }
+        }
     }
     if (inside) {
         final_T[pix] = T;
@@ -760,7 +782,12 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     // work item = (tile, segment): the full segments first, then every tile's last segment
     const uint32_t n_full = header[3];
     int tile, seg;
-    if (blockIdx.x < n_full) {
+    if (header[22]) {       // the ordered union of all work items (bwd_order_kernel)
+        if (blockIdx.x >= n_full + (uint32_t)v.tiles) return;
+        const uint2 it = bwd_items[blockIdx.x];
+        if (it.x == ~0u) return;
+        tile = (int)it.x; seg = (int)it.y;
+    } else if (blockIdx.x < n_full) {
         const uint2 it = bwd_items[blockIdx.x];
         if (it.x == ~0u) return;  // a segment of a tile that runs unsegmented (checkpoint slab full)
         tile = (int)it.x; seg = (int)it.y;
@@ -1138,6 +1165,76 @@ selftest_butterfly_kernel(const float *__restrict__ in, float *__restrict__ out)
     if (q4 < 2) dst[20] = r[5];
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward launch order: dearest work item first
+// ------------------------------------------------------------------------------------------------
+// tile_scan lists the backward's work items before anything is known about them: the full 512-entry segments in TILE-ID order,
+// the tiles' last segments by length.  A single-view launch then lasts as long as the dear items that happen to start late
+// (tools/bwd_probe.py, trained-like: 43 ms of workgroup time over 768 slots = 56 us, span 144 us, slowest item 109 us).  The
+// forward has walked the same entries in the same 512-entry rounds: its wave-trips per round (seg_cost) are re-used here as the
+// items' cost: ALL work items -- the full segments and every tile's last one -- go into one list, ordered by a 64-bucket
+// counting sort, dearest first (4 wave-trips per bucket, everything from 252 on in the first).  One workgroup; every item is read
+// into registers before the first is written back, so bwd_items is permuted (and extended by the last segments) in place: one
+// global round trip, two barriers.  header[22] marks the list as the ordered union (composite_bwd then maps blockIdx.x through it
+// alone; a second backward over the same state skips the pass).
+// The same launch zero-fills the backward's validity bitmap (workgroups 2..): it replaces the memset launch that stood in front of
+// composite_bwd, so the ordering costs no launch.
+constexpr int BO_PER_THREAD = 17;     // items per thread: more than 17 408 work items stay in tile_scan's order
+__global__ void __launch_bounds__(1024)
+bwd_order_kernel(ViewDev v, uint32_t *__restrict__ header, uint2 *__restrict__ bwd_items, const uint32_t *__restrict__ seg_cnt,
+                 const uint32_t *__restrict__ seg_cost, const long long sst, char *__restrict__ zero_base, const long long zero_bytes,
+                 const long long qst) {
+    if (blockIdx.x >= 1) {      // workgroups 1.. : the zero fill of the backward's validity bitmap (it used to be a launch of its own)
+        uint4 *z = (uint4 *)l2d_view_ptr(zero_base, qst);
+        const long long n16 = zero_bytes / 16;
+        for (long long i = (long long)(blockIdx.x - 1) * 1024 + threadIdx.x; i < n16; i += (long long)(gridDim.x - 1) * 1024)
+            z[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    header = l2d_view_ptr(header, sst); bwd_items = l2d_view_ptr(bwd_items, sst); seg_cnt = l2d_view_ptr(seg_cnt, sst);
+    seg_cost = l2d_view_ptr(seg_cost, sst);
+    __shared__ uint32_t bcnt[64];
+    if (header[1] || (v.dbg & (128u | 256u))) return;      // (overflow; the opt-in forward split records no costs; 256: A/B runs)
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (header[22]) return;                        // already ordered (the costs are indexed by the ORIGINAL positions)
+    // the work items: the full segments as tile_scan listed them, then every tile's last segment (tile, seg_cnt[tile])
+    const uint32_t n_full = header[3], n = n_full + (uint32_t)v.tiles;
+    if (n > (uint32_t)(BO_PER_THREAD * 1024)) return;
+    const uint32_t *cost_last = seg_cost + (v.cap / L2D_SEG + 1u);
+    if (tid < 64) bcnt[tid] = 0u;
+    __syncthreads();
+    uint2 item[BO_PER_THREAD];
+    uint32_t bkt[BO_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < BO_PER_THREAD; k++) {
+        const uint32_t i = (uint32_t)tid + 1024u * k;
+        bkt[k] = 64u;
+        if (i < n) {
+            uint32_t c;
+            if (i < n_full) { item[k] = bwd_items[i]; c = item[k].x == ~0u ? 0u : seg_cost[i]; }
+            else { const uint32_t t = i - n_full; item[k] = make_uint2(t, seg_cnt[t]); c = cost_last[t]; }
+            bkt[k] = 63u - min(63u, c >> 2);
+            atomicAdd(&bcnt[bkt[k]], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint32_t c = bcnt[tid];
+        uint32_t x = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        bcnt[tid] = x - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BO_PER_THREAD; k++)
+        if (bkt[k] < 64u) bwd_items[atomicAdd(&bcnt[bkt[k]], 1u)] = item[k];
+    if (tid == 0) header[22] = 1u;
+}
+
 }  // namespace
 
 int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
@@ -1147,7 +1244,7 @@ int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *
     if (vbp) vb = *vbp;
     const unsigned nz = vbp ? (unsigned)vb.n : 1u;    // blockIdx.z = view (st / sc / out_* are view 0's)
 #define FWD_ARGS v, st.header, st.ranges, st.point_list, (const float4 *)st.geom, st.tile_order, (const float4 *)st.cullbox, \
-                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, st.tile_maxc, out_color, out_allmap, slabs, vb
+                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, st.tile_maxc, st.seg_cost, out_color, out_allmap, slabs, vb
     {
         // Depth-segment split of the long lists: OPT-IN (lara2dgs_set_forward_split / LARA2DGS_FWD_SPLIT=1), off by default
         // because it measured SLOWER: at LaRa's init statistics the four launches take 123 (prepass) + 142 (segment walks) + 14
@@ -1167,6 +1264,17 @@ int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *
         hipLaunchKernelGGL(composite_fwd_kernel<0>, dim3(v.tiles, 1, nz), dim3(256), 0, s, FWD_ARGS);
     }
 #undef FWD_ARGS
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int launch_bwd_order(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vbp, void *zero_base, int64_t zero_bytes) {
+    (void)sc;
+    L2D_PROF("bwd_order", s);
+    const int64_t zb = (zero_bytes + 15) / 16 * 16;      // (the region is 256-byte aligned and padded: rounding up stays inside it)
+    const unsigned zw = zb > 0 ? (unsigned)((zb / 16 + 8191) / 8192 < 128 ? (zb / 16 + 8191) / 8192 : 128) : 0u;
+    hipLaunchKernelGGL(bwd_order_kernel, dim3(1 + zw, 1, vbp ? (unsigned)vbp->n : 1u), dim3(1024), 0, s, v, st.header, st.bwd_items, st.seg_cnt,
+                       st.seg_cost, vbp ? vbp->state_stride : 0ll, (char *)zero_base, (long long)zb, vbp ? vbp->scratch_stride : 0ll);
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }

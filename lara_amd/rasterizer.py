@@ -53,7 +53,7 @@ class GradLayout(ctypes.Structure):
 class StateLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ("header", "geom", "cullbox", "point_list", "ranges", "tile_order", "pair_base", "pair_pos", "final_T", "n_contrib",
-                 "seg_base", "seg_cnt", "bwd_order", "bwd_items", "ckpt", "pair_mask", "tile_maxc", "total")]
+                 "seg_base", "seg_cnt", "bwd_order", "bwd_items", "ckpt", "pair_mask", "tile_maxc", "seg_cost", "total")]
 
 
 _lib = None
@@ -698,9 +698,10 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
         seg_base=sec(L.seg_base, (tiles + 1) * 4, torch.int32, (tiles + 1,)),
         seg_cnt=sec(L.seg_cnt, tiles * 4, torch.int32, (tiles,)),
         bwd_order=sec(L.bwd_order, tiles * 4, torch.int32, (tiles,)),
-        bwd_items=sec(L.bwd_items, (cap // 512 + 1) * 8, torch.int32, (cap // 512 + 1, 2)),
+        bwd_items=sec(L.bwd_items, (cap // 512 + 1 + tiles) * 8, torch.int32, (cap // 512 + 1 + tiles, 2)),
         pair_mask=sec(L.pair_mask, cap * 8, torch.int64, (cap,)),
         tile_maxc=sec(L.tile_maxc, tiles * 4, torch.int32, (tiles,)),
+        seg_cost=sec(L.seg_cost, (cap // 512 + 1 + tiles) * 4, torch.int32, (cap // 512 + 1 + tiles,)),
     )
 
 

@@ -276,6 +276,42 @@ def test_backward_deep_lists_cross_segment_boundaries(hip_lib):
     _grad_check(act, cam, bg)
 
 
+def test_backward_work_items_are_ordered_dearest_first(hip_lib):
+    """Before composite_bwd, `bwd_order_kernel` re-orders the work items -- tile_scan's full (tile, segment) items and every
+    tile's last segment -- by what the same 512-entry round cost the FORWARD (wave-trips, `seg_cost`): afterwards `bwd_items`
+    must hold exactly the same items (a permutation of the union) with non-increasing cost buckets, and `header[22]` is set.
+    The gradients themselves are held to the oracle by the tests around this one (the ordering is on in all of them)."""
+    from lara_amd import GaussianRasterizer, rasterizer
+    act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)      # lists several segments deep
+    cam, bg = cams[1], (1.0, 1.0, 1.0)
+    rs = raster_settings(cam, bg, device=DEV)
+    inp = {k: v.to(DEV).requires_grad_(True) for k, v in act.items()}
+    color, _, allmap = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
+                                              scales=inp["scales"], rotations=inp["rotations"])
+    state, cap = color.grad_fn.saved_tensors[7], color.grad_fn.cap
+    P = act["means3D"].shape[0]
+    v = rasterizer.state_views(state, P, 64, 64, cap)
+    torch.cuda.synchronize()
+    hdr = v["header"].cpu().numpy()
+    n_full, tiles = int(hdr[3]), 16
+    assert hdr[22] == 0 and n_full > 20
+    before = v["bwd_items"][:n_full].cpu().numpy()
+    seg_cnt = v["seg_cnt"].cpu().numpy()
+    cost = v["seg_cost"].cpu().numpy().view(np.uint32)
+    nseg_cap = cap // 512 + 1
+    want = {(int(t), int(q)): int(cost[i]) for i, (t, q) in enumerate(before)}
+    want.update({(t, int(seg_cnt[t])): int(cost[nseg_cap + t]) for t in range(tiles)})
+    assert len(want) == n_full + tiles and max(want.values()) > 0
+    (color.sum() + allmap.sum()).backward()
+    torch.cuda.synchronize()
+    assert int(v["header"][22]) == 1
+    after = [(int(t), int(q)) for t, q in v["bwd_items"][:n_full + tiles].cpu().numpy()]
+    assert sorted(after) == sorted(want)                                    # the same work items, each exactly once
+    buckets = [min(63, want[it] >> 2) for it in after]
+    assert all(a >= b for a, b in zip(buckets, buckets[1:])), "work items are not in non-increasing cost order"
+    assert buckets[0] > buckets[-1]
+
+
 @pytest.fixture
 def forward_split():
     from lara_amd import rasterizer
