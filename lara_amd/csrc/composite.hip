@@ -775,6 +775,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     if (header[1]) return;
     const unsigned long long dbg_t0 = (v.dbg & 32u) ? wall_clock64() : 0ull;
     int dbg_rounds = 0;
+    uint32_t dbg_windows = 0, dbg_trips = 0, dbg_entries = 0, dbg_slots = 0, dbg_rows = 0;   // LARA2DGS_DEBUG_FLAGS & 512
     unsigned long long dbg_tp = 0ull;            // phase timers (LARA2DGS_DEBUG_FLAGS & 64), thread 0 only
     uint32_t dbg_ph[5] = {0u, 0u, 0u, 0u, 0u};   // prologue, stage, setup, phase P, phase S2 (shader clocks)
 #define DBG_PHASE(k) do { if (v.dbg & 64u) { const unsigned long long t__ = __builtin_readcyclecounter(); dbg_ph[k] += (uint32_t)(t__ - dbg_tp); dbg_tp = t__; } } while (0)
@@ -884,7 +885,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         mk2 = whi - 2 * WIN - 1 - tid >= lo ? pair_mask[range.x + whi - 2 * WIN - 1 - tid] : make_uint2(0u, 0u);
         __syncthreads();  // the previous window's last round is done with rec / s_id
         DBG_PHASE(whi == total ? 0 : 4);
+        dbg_windows++;
         if (tid < WIN) stage_entry_masked<WIN>(geom, id0, mk0, tid < wcnt, X0, Y0, rec, s_id, tid);
+        unsigned long long wm0 = 0ull, wm1 = 0ull;      // this quad's candidate bits over the window's 128 slots (set in the first round)
 
         // Slab rounds over the window.  An entry's slab has four slots (the 2x2 pixels) per candidate
         // block of its mask, in mask-bit order: slot = base + 4 * rank(block) + pixel-in-block with
@@ -956,18 +959,32 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             DBG_PHASE(2);
             const int nfit = s_nfit;
             dirty = nfit < SLAB_CHUNK ? (int)s_base[nfit] : min((int)s_total, SLAB_POOL);
+            dbg_entries += (uint32_t)nfit; dbg_slots += (uint32_t)dirty;
 
             // ---- phase P: every quad walks its own candidates over the whole round, last list position
             //      first (window slots ascend as list positions descend)
             {
-                unsigned long long m0 = 0ull, m1 = 0ull;
+                // The (entry x block) bit matrix of the WINDOW is transposed once, in the window's first round (16 ballots per 64
+                // entries, ~130 VALU in all: a fifth of a round's fixed cost when every round redid it for its own entries -- and a
+                // window takes two rounds on average); a round takes its entries' bits [s0, s0 + nfit) out of the quad's
+                // 128-bit window mask.
+                if (s0 == 0) {
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * WIN + min(s0 + 64 * k + lane, WIN - 1);
-                    const uint32_t bm = 64 * k + lane < nfit ? __float_as_uint((wave >> 1) ? mrec->z : mrec->w) : 0u;
-                    unsigned long long m = 0ull;
-                    if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) != 0ull) m = quad_masks(bm, (wave & 1) * 4, grp);
-                    if (k == 0) m0 = m; else m1 = m;
+                    for (int k = 0; k < 2; k++) {
+                        const float4 *mrec = rec + ((wave >> 1) ? 5 : 3) * WIN + 64 * k + lane;    // (slots past wcnt are staged as zeros)
+                        const uint32_t bm = __float_as_uint((wave >> 1) ? mrec->z : mrec->w);
+                        unsigned long long m = 0ull;
+                        if (__ballot((bm & (0x0f0f0f0fu << ((wave & 1) * 4))) != 0u) != 0ull) m = quad_masks(bm, (wave & 1) * 4, grp);
+                        if (k == 0) wm0 = m; else wm1 = m;
+                    }
+                }
+                unsigned long long m0 = wm0, m1 = wm1;
+                {
+                    int sh = s0;
+                    if (sh >= 64) { m0 = m1; m1 = 0ull; sh -= 64; }
+                    if (sh) { m0 = (m0 >> sh) | (m1 << (64 - sh)); m1 >>= sh; }
+                    if (nfit < 64) { m0 &= (1ull << nfit) - 1ull; m1 = 0ull; }
+                    else if (nfit < 128) m1 &= (1ull << (nfit - 64)) - 1ull;
                 }
                 // entries at or beyond the last contributor of all four pixels are not this quad's
                 const int jmin = whi - s0 - (int)quad_last;
@@ -980,6 +997,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 uint32_t mm = (uint32_t)m0, q1 = (uint32_t)(m0 >> 32), q2 = (uint32_t)m1, q3 = (uint32_t)(m1 >> 32);
                 int jb = 0;
                 while (__ballot((mm | q1 | q2 | q3) != 0u) != 0ull) {
+                    dbg_trips++;
                     while (mm == 0u && (q1 | q2 | q3) != 0u) { mm = q1; q1 = q2; q2 = q3; q3 = 0u; jb += 32; }
                     const bool has = mm != 0u;
                     const int j = jb + (has ? __builtin_ctz(mm) : 0);  // entry of this round
@@ -1072,11 +1090,12 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             __syncthreads();
             DBG_PHASE(3);
 
-            // ---- phase S2: two lanes per entry add up the entry's block slots (no geometry any more)
-            {
+            // ---- phase S2: two lanes per entry add up the entry's block slots (no geometry any more); a wave whose 32 entries lie
+            //      beyond the round (a round holds 61 entries on average at LaRa's init statistics) skips it
+            if ((wave << 5) < nfit && !(v.dbg & 2u)) {
                 const int e = tid >> 1, part = tid & 1;
                 const int ws = min(s0 + e, WIN - 1);
-                const bool has = e < nfit && !(v.dbg & 2u);
+                const bool has = e < nfit;
                 const int cnt = has ? __builtin_popcountll(s_live[e]) : 0;
                 // the entry's T rows are needed at the very end: fetch them now, behind the slot loop
                 float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), gq1 = gq0, gq2 = gq0;
@@ -1128,6 +1147,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     row[3] = make_float4(g[15], g[16], g[17], g[18]);
                     row[4] = make_float4(g[19], g[20], 0.f, 0.f);
                     pair_valid[q] = 1;
+                    dbg_rows++;
                 }
             }
             s0 += nfit;
@@ -1137,6 +1157,15 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         DBG_PHASE(4);
         uint32_t *h = const_cast<uint32_t *>(header);
         for (int k = 0; k < 5; k++) atomicAdd(&h[16 + k], dbg_ph[k] >> 6);  // units of 64 clocks
+    }
+    if (v.dbg & 512u) {   // walk statistics (tools/bwd_probe.py): work items, windows, rounds, wave-trips, entries and slots of the rounds, rows
+        uint32_t *h = const_cast<uint32_t *>(header);
+        if (tid == 0) {
+            atomicAdd(&h[24], 1u); atomicAdd(&h[25], dbg_windows); atomicAdd(&h[26], (uint32_t)dbg_rounds);
+            atomicAdd(&h[28], dbg_entries); atomicAdd(&h[29], dbg_slots);
+        }
+        if (lane == 0) atomicAdd(&h[27], dbg_trips);
+        if (dbg_rows) atomicAdd(&h[30], dbg_rows);
     }
     if ((v.dbg & 32u) && tid == 0) {  // work-group residency in 100 MHz ticks: max, sum, first start, last end
         uint32_t *h = const_cast<uint32_t *>(header);

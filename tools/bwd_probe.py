@@ -46,5 +46,10 @@ for regime in ('init', 'trained', 'fine'):  # 'fine': the opacity > 0.005 subset
               f"entries {len(ids)} non-empty cull boxes {nonempty}, mean box {float((cb[:,1]-cb[:,0]).clip(0).mean()):.1f} x {float((cb[:,3]-cb[:,2]).clip(0).mean()):.1f}, tile n_contrib max {int(ncb.max())}")
         ph = [int(x) * 64 / 2.4e3 for x in h[16:21]]  # us at 2.4 GHz, summed over workgroups
         print("   phase time summed over WGs (us): prologue %.0f stage %.0f setup %.0f P %.0f S2 %.0f" % tuple(ph))
+        if int(os.environ.get("EXTRA_FLAGS", "0")) & 512:      # walk statistics of the launch (composite.hip, flag 512)
+            items, windows, rounds_, trips, entries, slots, rows = [int(x) for x in h[24:31]]
+            print(f"   walk: {items} work items, {windows} windows, {rounds_} rounds ({rounds_ / max(windows, 1):.2f} per window), "
+                  f"{entries / max(rounds_, 1):.1f} entries and {slots / max(rounds_, 1):.0f} slots per round ({slots / max(entries, 1):.2f} per entry), "
+                  f"{trips} wave-trips ({trips / max(4 * rounds_, 1):.2f} per wave and round), {rows} gradient rows")
         print(f"{regime} view {ci}: pairs {h[0]} max_list {h[2]}  WG max {h[8]/100:.0f} us  sum {h[9]/100:.0f} us "
               f"(/512 = {h[9]/100/512:.0f} us)  span {span/100:.0f} us")

@@ -53,7 +53,9 @@ def arbitrate(n_worst=3, regime="init", res=512, grid=64, max_tiles=40, verbose=
                                                       opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
                                                       cov3D_precomp=None)
         ((color * torch.from_numpy(dc_).to(dev)).sum() + (allmap * torch.from_numpy(da_).to(dev)).sum()).backward()
-        return {k: t[k].grad.cpu().numpy().astype(np.float64) for k in KEYS}
+        g = {k: t[k].grad.cpu().numpy().astype(np.float64) for k in KEYS}
+        g["_color"], g["_allmap"] = color.detach().cpu().numpy(), allmap.detach().cpu().numpy()
+        return g
 
     g_or = oracle.backward(r, dc, da)
     g_hip = hip(dc, da)
@@ -99,6 +101,12 @@ def arbitrate(n_worst=3, regime="init", res=512, grid=64, max_tiles=40, verbose=
            "fp64_seconds": round(t64, 1), "forward_max_abs_diff_fp32_oracle_vs_fp64_on_tiles": float(
                max(np.abs(c64.detach().numpy()[:, mask] - r.color[:, mask]).max(), np.abs(a64.detach().numpy()[:, mask] - r.allmap[:, mask]).max())),
            "per_tensor": {}}
+    # the HIP forward against the fp64 walk on the same tiles: a (pixel, entry) pair decided the other way at the alpha = 1/255
+    # cut shows up here as a step of about alpha T = 2e-3 in one pixel, against 1e-5 of rounding everywhere else
+    dcol = np.abs(c64.detach().numpy() - g_hip_m["_color"])[:, mask]
+    out["forward_max_abs_diff_hip_vs_fp64_on_tiles"] = float(max(dcol.max(), np.abs(a64.detach().numpy()[1] - g_hip_m["_allmap"][1])[mask].max()))
+    out["forward_pixels_beyond_2e-4_hip_vs_fp64"] = int((dcol.max(0) > 2e-4).sum())
+    out["forward_pixels_beyond_2e-4_fp32_oracle_vs_fp64"] = int((np.abs(c64.detach().numpy() - r.color)[:, mask].max(0) > 2e-4).sum())
     for k in KEYS:
         g64 = inp[k].grad.numpy().reshape(g_or_m[k].shape)
         P = g64.shape[0]
