@@ -9,10 +9,10 @@ COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wn
 for f in abi preprocess binning composite attention encoder encoder_bwd rays surface pointfeat finedec coarsedec loss tsdf; do
   FL=""
   case $f in preprocess|binning|tsdf) FL="-ffp-contract=off";; composite) FL="-fno-slp-vectorize";; esac
-  if [ "$f" = composite ] || [ "$f" = encoder_bwd ] || [ ! -f _obj/$f.o ]; then
+  if [ "$f" = composite ] || [ "$f" = encoder_bwd ] || [ "$f" = attention ] || [ ! -f _obj/$f.o ]; then
     /opt/rocm/bin/hipcc $COMMON $FL $EXTRA -c $f.hip -o $OBJ/$f.o
   else
-    cp _obj/$f.o $OBJ/$f.o        # only composite.hip reads the experiment macros
+    cp _obj/$f.o $OBJ/$f.o        # only composite / encoder_bwd / attention read experiment macros
   fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../liblara2dgs_$TAG.so $OBJ/*.o
