@@ -765,7 +765,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     }
     constexpr int WIN = SLAB_WIN;
     __shared__ float4 rec[REC4 * WIN];
-    __shared__ __attribute__((aligned(16))) float pool[SLAB_POOL * SLAB_F];
+    __shared__ __attribute__((aligned(16))) float pool[(SLAB_POOL + 1) * SLAB_F];    // (+ one slot that stays zero, for phase S2)
     __shared__ uint32_t s_base[SLAB_CHUNK];  // first pool slot of each entry of the round
     __shared__ unsigned long long s_live[SLAB_CHUNK];  // an entry's candidate blocks whose quad still walks it
     __shared__ uint32_t s_ql[64];            // per 2x2 block: last contributor over its four pixels
@@ -850,6 +850,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0xB1, 0xf, 0xf, false));
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0x4E, 0xf, 0xf, false));
     if ((lane & 3) == 0) s_ql[my_blk] = quad_last;  // read by wave 0 after the first window's barrier
+    if (tid < SLAB_F) pool[SLAB_POOL * SLAB_F + tid] = 0.f;
 
     // A pixel whose walk began above this segment resumes from the forward's checkpoint at seg_hi:
     // with F the running sum of f_k * w_k over entries < seg_hi and T_b the transmittance there,
@@ -1103,11 +1104,21 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     const float4 *gm = geom + (size_t)s_id[ws] * 5;
                     gq0 = gm[0]; gq1 = gm[1]; gq2 = gm[2];
                 }
-                float g[24];
-#pragma unroll
-                for (int k = 0; k < 24; k++) g[k] = 0.f;
+                // the lane's first slot is LOADED (a lane without one reads the pool's extra, always-zero slot): no 24 zero moves and
+                // no adds for the first slot
+                float g[22];
                 const float4 *ps = (const float4 *)(pool + (int)s_base[e] * SLAB_F);
-                for (int i = part; i < cnt; i += 2) {
+                {
+                    const float4 *p0 = part < cnt ? ps + part * (SLAB_F / 4) : (const float4 *)(pool + SLAB_POOL * SLAB_F);
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        const float4 t = p0[q];
+                        g[4 * q] = t.x; g[4 * q + 1] = t.y; g[4 * q + 2] = t.z; g[4 * q + 3] = t.w;
+                    }
+                    const float2 t2 = *(const float2 *)(p0 + 5);
+                    g[20] = t2.x; g[21] = t2.y;
+                }
+                for (int i = part + 2; i < cnt; i += 2) {
 #pragma unroll
                     for (int q = 0; q < 5; q++) {
                         const float4 t = ps[i * (SLAB_F / 4) + q];
