@@ -15,7 +15,12 @@ every rank for its B = 4 scenes:
        backward, whose encoder is one autograd node per block, so that under DistributedDataParallel (N > 1,
        train_lightning.py:68-81) each 25 MB bucket's RCCL all-reduce starts while the earlier blocks' backward still runs.
        That all-reduce is the path's only exchange step; the raster is per view and NOT sharded (BASELINE.json north_star)
-       -> per-scene data parallel, weak scaling.
+       -> per-scene data parallel, weak scaling;
+    7. the parameter update: `clip_grad_norm_(0.5)` (train_lightning.py:75) + AdamW over the reference's two parameter groups
+       (system.py:78-106), every step.  `--lr` defaults to 0: all of the update's kernels run and every parameter's version
+       counter advances -- the HIP modules then re-derive their bf16 / transposed operands in the next step's forward, as they
+       must in training -- while the values stay, so that all K timed steps see the same synthetic workload.  (Rounds 1-3
+       timed steps 1-6 only and so kept those operand caches warm; `--no-optimizer` reproduces that.)
 A *frame* is one rasteriser forward + backward; a step holds 64 of them.  `value` = frames of all
 ranks / max-over-ranks wall time of the timed steps, with the collated batch (cameras, images, rays) and the image-feature
 volume already resident in HBM.  Data is synthetic (no dataset / checkpoint in this environment): random-init network of the
@@ -84,6 +89,11 @@ def parse():
                     help="add the reference's 0.5 (1 - MS_SSIM) term (loss.py:41-45) to the timed step's loss: lara_amd.loss.ms_ssim, plain "
                          "torch operators (outside SURVEY.md section 8; the package the reference imports is absent).  Default: the "
                          "step is timed WITHOUT it (the workload string says so) and `step_with_ms_ssim` reports the step with it")
+    ap.add_argument("--lr", type=float, default=0.0,
+                    help="learning rate of the AdamW update inside the timed step (--step pipeline).  Default 0: every kernel of the "
+                         "update runs and the parameters' version counters advance (the bf16 operand caches of the HIP modules are "
+                         "rebuilt every step, as in training) while the values, and with them the synthetic workload, stay put")
+    ap.add_argument("--no-optimizer", action="store_true", help="--step pipeline: forward + loss + backward only (rounds 1-3's step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the side objects (attention, encoder, rays, ...)")
@@ -1150,6 +1160,29 @@ def cpu_encoder_baseline(scenes=1):
                       f"then one timed pass"}
 
 
+def reference_optimizer(module, lr):
+    """`system.configure_optimizers` (lightning/system.py:78-106): AdamW over two groups -- every LayerNorm parameter and every bias
+    without weight decay, the rest with `train.weight_decay` -- with configs/base.yaml's betas; fused multi-tensor update."""
+    no_decay = []
+    for m in module.modules():
+        if isinstance(m, torch.nn.LayerNorm):
+            no_decay.extend(m.parameters())
+        elif isinstance(getattr(m, "bias", None), torch.nn.Parameter):
+            no_decay.append(m.bias)
+    ids = set(map(id, no_decay))
+    decay = [p for p in module.parameters() if id(p) not in ids and p.requires_grad]
+    seen, nd = set(), []
+    for p in no_decay:
+        if p.requires_grad and id(p) not in seen:
+            seen.add(id(p))
+            nd.append(p)
+    groups = [{"params": decay, "weight_decay": 0.05}, {"params": nd, "weight_decay": 0.0}]
+    try:
+        return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.95), fused=True)
+    except (RuntimeError, TypeError):      # (CPU plumbing runs)
+        return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.95))
+
+
 def make_pipeline_step(args, device, rank, world, plumbing):
     """The headline step: `lara_amd.pipeline.LaRaPipeline` (network.py:455-532) + `lara_loss` (loss.py minus MS-SSIM) +
     one backward through everything, the encoder's backward last (autograd's order), DDP over ALL trainable
@@ -1193,17 +1226,33 @@ def make_pipeline_step(args, device, rank, world, plumbing):
                                           "starts while the earlier blocks' backward is still running"}
     params = [p for p in pipe.parameters() if p.requires_grad]
     with_fine = not args.no_fine
+    opt = None if args.no_optimizer else reference_optimizer(pipe, args.lr)
+    info["optimizer"] = None if opt is None else {
+        "what": "AdamW as system.py:78-106 builds it (LayerNorm parameters and biases without weight decay, betas 0.9 / 0.95, weight decay "
+                "0.05, fused multi-tensor kernels) behind clip_grad_norm_(0.5) (train_lightning.py:75), EVERY step (the reference steps every "
+                "second batch: accumulate_grad_batches=2)", "lr": args.lr, "parameters": n_par,
+        "note": "lr 0: all of the update's kernels run and every parameter's version advances, so the HIP modules re-derive their bf16 / "
+                "transposed operands each step as they do in training; the values stay, so all K steps time the same synthetic workload"}
 
     poison = os.environ.get("LARA2DGS_POISON_BUFFERS") == "1"
+
+    def update():
+        if opt is not None:
+            torch.nn.utils.clip_grad_norm_(params, 0.5)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in params:
+                p.grad = None
+        feat_vol.grad = None
+    info["update"] = update
 
     def full_step(ms_ssim=args.ms_ssim):
         out = model(batch, feat_vol, with_fine=with_fine)
         loss, _ = lara_loss(batch, out, 2000, ms_ssim=ms_ssim)       # past iteration 1000: distortion + normal terms are on (loss.py:48)
         loss.backward()
         pipe.join_streams()
-        for p in params:
-            p.grad = None
-        feat_vol.grad = None
+        update()
         if poison:      # debugging mode: every state / scratch buffer 0xFF-filled between guard zones; checked (and released) per step
             bad = rasterizer.check_poison_guards()
             if bad:
@@ -1243,15 +1292,12 @@ def ddp_single_rank_leg(info, args, device):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     try:
         model = DDP(pipe, device_ids=[device.index], find_unused_parameters=True, bucket_cap_mb=dp.DDP_BUCKET_MB)
-        params = [p for p in pipe.parameters() if p.requires_grad]
 
         def one():
             loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=not args.no_fine), 2000, ms_ssim=False)
             loss.backward()
             pipe.join_streams()
-            for p in params:
-                p.grad = None
-            feat_vol.grad = None
+            info["update"]()
         for _ in range(3):
             one()
         torch.cuda.synchronize()
@@ -1513,7 +1559,8 @@ def main():
                 (f"configs[2]: the whole data-dependent LaRa training step (lightning/network.py:455-532 + loss.py {'WITH its MS-SSIM term (torch operators)' if args.ms_ssim else 'minus MS-SSIM'}), per GPU "
                  f"{args.scenes} scenes: VolTransformer ({enc['layers']} layers, {enc['parameters'] / 1e6:.2f} M parameters) -> coarse decoder MLP "
                  f"-> {args.views} coarse views/scene -> " + ("" if args.no_fine else f"_check_mask ({args.fine_mask}) -> point sampler on 4 input views -> "
-                 f"forward_fine -> {args.views} fine views/scene -> ") + f"loss -> ONE backward through all of it; @{args.res}x{args.res}, P={P} "
+                 f"forward_fine -> {args.views} fine views/scene -> ") + f"loss -> ONE backward through all of it"
+                 + ("" if info.get("optimizer") is None else " -> clip_grad_norm_ + AdamW update of every parameter") + f"; @{args.res}x{args.res}, P={P} "
                  f"surfels/scene, SH degree 1, random-init network (= SURVEY 8d's init regime)")
                 if args.step == "pipeline" and not plumbing else
                 (f"configs[2]: LaRa training step on the hot path (round 2's definition: encoder and raster on independent tensors), per GPU {args.scenes} scenes: "
@@ -1531,6 +1578,7 @@ def main():
                            "streams per call)" if args.raster_api == "views" or args.step == "pipeline" else
                            "loop: one GaussianRasterizer call per view (the reference's loop)"),
             "grad_allreduce": info["grad_allreduce"],
+            "optimizer": info.get("optimizer"),
         },
     }
     solo = rank == 0 and world == 1 and not plumbing
@@ -1562,15 +1610,12 @@ def main():
         from lara_amd.pipeline import lara_loss as torch_loss
         _leg("drop_in_step")
         pipe_, batch_, fv_, _fs = info["pipeline"]
-        pars_ = [p for p in pipe_.parameters() if p.requires_grad]
 
         def drop_in():
             o = reference_style.network_forward(pipe_, batch_, fv_, with_fine=not args.no_fine)
             l, _ = torch_loss(batch_, o, 2000, ms_ssim=False)
             l.backward()
-            for p in pars_:
-                p.grad = None
-            fv_.grad = None
+            info["update"]()
         for _ in range(2):
             drop_in()
         torch.cuda.synchronize()
