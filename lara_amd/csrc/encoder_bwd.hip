@@ -35,6 +35,16 @@ struct TnP {
     const int *nbr;  // GATHER: [T][M] byte offsets of the B rows
     int M, lda, ldb, N, Kc, T, chunk, tiles;
 };
+// Several products in ONE launch (gemm_tn_group): a workgroup finds its product through the cumulative slot counts (a slot =
+// the eight workgroups -- one per XCD -- of one (tile, split / 8) pair).  The five weight gradients of a block's linear layers
+// are 4 + 4 + 28 + 8 + 8 tiles: launched one by one each needs 128-256 splits to fill the device, and writes and re-reads
+// 52-67 MB of partial tiles -- as much as its operands; together 24 splits do.
+constexpr int TN_GROUP_MAX = 6;
+struct TnGroup {
+    TnP p[TN_GROUP_MAX];
+    int first_slot[TN_GROUP_MAX + 1];
+    int count;
+};
 
 // v_perm_b32 picks bytes of {S0 (bytes 4-7), S1 (bytes 0-3)}: one instruction per fragment dword
 __device__ __forceinline__ bf16x8 pack_lo(const uint32_t *w) {  // the low halves of 8 dwords
@@ -187,10 +197,14 @@ constexpr int TL_ROWS = 32, TL_STAGES = 2, TL_TILE = TL_ROWS * 256, TL_STAGE = 2
 
 template <bool GATHER>
 __global__ void __launch_bounds__(256)
-gemm_bf16_tn_lds_kernel(const TnP p) {
+gemm_bf16_tn_lds_kernel(const TnGroup grp) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[TL_STAGES * TL_STAGE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3, which = 0;
+    while (which + 1 < grp.count && slot >= grp.first_slot[which + 1]) which++;
+    slot -= grp.first_slot[which];
+    const TnP &p = grp.p[which];
     const int sq = __builtin_amdgcn_readfirstlane(slot / p.tiles);
     const int tile = slot - sq * p.tiles, split = sq * 8 + xcd;
     const int tpt = (p.Kc + 127) / 128, ctiles = tpt * p.T;
@@ -310,8 +324,19 @@ accum_partials_kernel(float *__restrict__ dst, const float *__restrict__ part, c
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, nsl = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (c < n)
-        for (int q = sl; q < parts; q += nsl) s += part[(size_t)q * stride + c];
+    if (c < n) {
+        // four independent chains: a slice walks up to 128 parts, and one dependent load + add per part is pure latency
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int q = sl;
+        for (; q + 3 * nsl < parts; q += 4 * nsl) {
+            s += part[(size_t)q * stride + c];
+            s1 += part[(size_t)(q + nsl) * stride + c];
+            s2 += part[(size_t)(q + 2 * nsl) * stride + c];
+            s3 += part[(size_t)(q + 3 * nsl) * stride + c];
+        }
+        for (; q < parts; q += nsl) s += part[(size_t)q * stride + c];
+        s = (s + s1) + (s2 + s3);
+    }
     red[sl][lane] = s;
     __syncthreads();
     if (sl == 0 && c < n) {
@@ -333,6 +358,40 @@ accum_partials4_kernel(float *__restrict__ dst, const float *__restrict__ part, 
     if (c < n)
         for (int q = sl; q < parts; q += 4) {
             const float4 v = *(const float4 *)(part + (size_t)q * stride + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && c < n) {
+        float4 d = *(float4 *)(dst + c);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const float4 v = red[k][lane]; d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w; }
+        *(float4 *)(dst + c) = d;
+    }
+}
+
+// the same for the products of one gemm_tn_group launch: workgroup -> product through the cumulative workgroup counts
+struct AccGroup {
+    float *dst[TN_GROUP_MAX];
+    const float *part[TN_GROUP_MAX];
+    int n[TN_GROUP_MAX], parts[TN_GROUP_MAX], first_wg[TN_GROUP_MAX + 1];
+    int count;
+};
+__global__ void __launch_bounds__(256)
+accum_partials4_group_kernel(const AccGroup a) {
+    __shared__ float4 red[4][64];
+    int wg = blockIdx.x, which = 0;
+    while (which + 1 < a.count && wg >= a.first_wg[which + 1]) which++;
+    wg -= a.first_wg[which];
+    float *dst = a.dst[which];
+    const float *part = a.part[which];
+    const int n = a.n[which], parts = a.parts[which];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = (wg * 64 + lane) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n)
+        for (int q = sl; q < parts; q += 4) {
+            const float4 v = *(const float4 *)(part + (size_t)q * n + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     red[sl][lane] = s;
@@ -377,8 +436,16 @@ accum_ln_partials_kernel(float *d0, float *d1, float *d2, const float *__restric
     if (!dst) return;
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    for (int q = sl; q < parts; q += 16) s += part[(size_t)q * 768 + blockIdx.y * 256 + c];
+    float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // (four independent chains, as in accum_partials_kernel)
+    int q = sl;
+    for (; q + 48 < parts; q += 64) {
+        s += part[(size_t)q * 768 + blockIdx.y * 256 + c];
+        s1 += part[(size_t)(q + 16) * 768 + blockIdx.y * 256 + c];
+        s2 += part[(size_t)(q + 32) * 768 + blockIdx.y * 256 + c];
+        s3 += part[(size_t)(q + 48) * 768 + blockIdx.y * 256 + c];
+    }
+    for (; q < parts; q += 16) s += part[(size_t)q * 768 + blockIdx.y * 256 + c];
+    s = (s + s1) + (s2 + s3);
     red[sl][lane] = s;
     __syncthreads();
     if (sl == 0) {
@@ -655,8 +722,10 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     static const bool force_direct = getenv("LARA_TN_DIRECT") != nullptr;  // (experiments: the per-lane-load kernel)
     const bool staged = !((M & 31) || (N & 7) || (Kc & 7) || (lda & 7) || (ldb & 7)) && !force_direct;
     if (staged) {
-        if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
+        TnGroup g{};
+        g.p[0] = p; g.count = 1; g.first_slot[0] = 0; g.first_slot[1] = tiles * splits / 8;
+        if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, g);
     } else {
         if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
@@ -668,6 +737,70 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
         hipLaunchKernelGGL(accum_partials4_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
     else
         hipLaunchKernelGGL(accum_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
+    return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
+}
+
+// dst_k[N_k, Kc_k] += A_k^T . B_k for several products that are ready at the same time, as one launch + one reduction launch
+// (plain products only: no gathered rows, T = 1).  Falls back to one launch per product where the staged kernel's alignment
+// conditions do not hold.
+struct TnJob {
+    const unsigned short *A; int lda, N;
+    const unsigned short *B; int ldb, Kc;
+    int M;
+    float *dst;
+};
+int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
+    static const bool off = getenv("LARA_TN_NO_GROUP") != nullptr;      // (A/B runs: one launch per product, as before round 4)
+    bool ok = !off && count >= 1 && count <= TN_GROUP_MAX;
+    int tiles_all = 0;
+    for (int k = 0; k < count && ok; k++) {
+        const TnJob &j = jobs[k];
+        ok = !((j.M & 31) || (j.N & 7) || (j.Kc & 7) || (j.lda & 7) || (j.ldb & 7)) && ((j.N * j.Kc) & 3) == 0 &&
+             (size_t)(j.M + 1) * j.lda * 2 < (1ull << 32) && (size_t)(j.M + 1) * j.ldb * 2 < (1ull << 32) && j.M < (1 << 24) &&
+             (((uintptr_t)j.dst) & 15) == 0;
+        tiles_all += ((j.N + 127) / 128) * ((j.Kc + 127) / 128);
+    }
+    if (!ok) {
+        for (int k = 0; k < count; k++) {
+            const int rc = gemm_tn(jobs[k].A, jobs[k].lda, jobs[k].N, jobs[k].B, jobs[k].ldb, jobs[k].Kc, 1, nullptr, jobs[k].M,
+                                   jobs[k].dst, part, s);
+            if (rc) return rc;
+        }
+        return LARA2DGS_OK;
+    }
+    // about 1280 workgroups (five per CU: the kernel is latency-bound below four), splits in multiples of 8 (one per XCD), at
+    // least 256 token rows per split
+    static const int want = getenv("LARA_TN_GROUP_WANT") ? atoi(getenv("LARA_TN_GROUP_WANT")) : 1280;
+    int base = max(8, (want / tiles_all) & ~7);
+    TnGroup g{};
+    AccGroup a{};
+    g.count = a.count = count;
+    size_t off_f = 0;     // floats
+    for (;;) {
+        off_f = 0;
+        int slot = 0, wg = 0;
+        for (int k = 0; k < count; k++) {
+            const TnJob &j = jobs[k];
+            int splits = base;
+            while (splits > 8 && j.M / splits < 256) splits -= 8;
+            const int tiles = ((j.N + 127) / 128) * ((j.Kc + 127) / 128), n = j.N * j.Kc;
+            TnP &p = g.p[k];
+            p.A = j.A; p.B = j.B; p.part = part + off_f; p.nbr = nullptr; p.M = j.M; p.lda = j.lda; p.ldb = j.ldb; p.N = j.N; p.Kc = j.Kc;
+            p.T = 1; p.chunk = (((j.M + splits - 1) / splits) + 63) & ~63; p.tiles = tiles;
+            g.first_slot[k] = slot;
+            slot += tiles * splits / 8;
+            a.dst[k] = j.dst; a.part[k] = part + off_f; a.n[k] = n; a.parts[k] = splits; a.first_wg[k] = wg;
+            wg += (n / 4 + 63) / 64;
+            off_f += (size_t)splits * n;
+        }
+        g.first_slot[count] = slot;
+        a.first_wg[count] = wg;
+        if (off_f * 4 <= TN_PART_BYTES || base == 8) break;
+        base -= 8;
+    }
+    if (off_f * 4 > TN_PART_BYTES) return LARA2DGS_E_INVALID;
+    hipLaunchKernelGGL((gemm_bf16_tn_lds_kernel<false>), dim3(g.first_slot[count] * 8), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(accum_partials4_group_kernel, dim3(a.first_wg[count]), dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
 }
 
@@ -716,7 +849,7 @@ SaveWs save_layout(int64_t M) {
 }
 // scratch of lara_groupblock_backward (followed by a SaveWs for the recompute mode)
 struct BwdWs {
-    size_t gb, tmpf, dzb, dq, dkv, dob, nbr, lnpart, tnpart, save, total;
+    size_t gb, tmpf, dzb, dq, dkv, dob, nbr, lnpart, tnpart, save, gb3, gb2, total;
 };
 BwdWs bwd_layout(int64_t M) {
     BwdWs w{};
@@ -729,6 +862,7 @@ BwdWs bwd_layout(int64_t M) {
     w.lnpart = take(((size_t)(M + 63) / 64) * 768 * 4);
     w.tnpart = take(TN_PART_BYTES);
     w.save = take(save_layout(M).total);
+    w.gb3 = take(b256); w.gb2 = take(b256);   // bf16(g) behind norm3's / norm2's backward, kept for the block's grouped weight gradients
     w.total = o;
     return w;
 }
@@ -850,6 +984,7 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     unsigned short *z = (unsigned short *)(sv + S.z);  // (read only; the GEMM parameter block is not const-correct)
     const float *x1 = (const float *)(sv + S.x1), *x2 = (const float *)(sv + S.x2);
     unsigned short *gb = (unsigned short *)(ws + L.gb);
+    unsigned short *gb3 = (unsigned short *)(ws + L.gb3), *gb2 = (unsigned short *)(ws + L.gb2);
     unsigned short *dzb = (unsigned short *)(ws + L.dzb), *dq = (unsigned short *)(ws + L.dq);
     // dK|dV: into the caller's all-layers buffer (its dcond product runs once, after the sweep) or into the workspace
     unsigned short *dkv = dkv_ext ? dkv_ext : (unsigned short *)(ws + L.dkv);
@@ -876,45 +1011,49 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
         p.R = R; p.Cin = 256; p.zero_off = (uint32_t)((size_t)M * 512);
         if (launch_gemm_ring<1, 1>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     }
+    // The bf16 copy of g that each LayerNorm backward leaves goes to its own buffer (gb3 behind norm3, gb2 behind norm2, gb --
+    // the one the next block's convolution gathers from -- behind norm1), so that the five weight gradients of the block's linear
+    // layers, whose operands are then all alive at the end of the block, run as ONE grouped product (gemm_tn_group).
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(g, false, x2, w->ln3_w, w->eps, nullptr, g, gb, dw->ln3_w, dw->ln3_b, dw->b2, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(g, false, x2, w->ln3_w, w->eps, nullptr, g, gb3, dw->ln3_w, dw->ln3_b, dw->b2, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x2 = x1 + mlp(norm2(x1)) ----
     {
         L2D_PROF("gbb_dx_mlp", s);
-        gemm_nt<7>(gb, wt->w2_t, dzb, M, 512, 256, nullptr, z, s);  // dz = (g2 W2) * gelu'(z)
+        gemm_nt<7>(gb3, wt->w2_t, dzb, M, 512, 256, nullptr, z, s);  // dz = (g2 W2) * gelu'(z)
         gemm_nt<0>(dzb, wt->w1_t, tmpb, M, 256, 512, nullptr, nullptr, s);   // bf16: see ln_bwd_kernel
     }
     {
         L2D_PROF("gbb_dw_mlp", s);
-        if ((rc = gemm_tn(gb, 256, 256, h, 512, 512, 1, nullptr, M, dw->w2, tnpart, s))) return rc;
-        if ((rc = gemm_tn(dzb, 512, 512, xn2, 256, 256, 1, nullptr, M, dw->w1, tnpart, s))) return rc;
         if ((rc = colsum_bf16(dzb, M, 512, dw->b1, lnpart, s))) return rc;
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(tmpb, true, x1, w->ln2_w, w->eps, g, g, gb, dw->ln2_w, dw->ln2_b, nullptr, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(tmpb, true, x1, w->ln2_w, w->eps, g, g, gb2, dw->ln2_w, dw->ln2_b, nullptr, lnpart, M, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x1 = x0 + cross_attn(norm1(x0), cond, cond) ----
     {
         L2D_PROF("gbb_dx_attn", s);
-        gemm_nt<0>(gb, wt->wo_t, dob, M, 256, 256, nullptr, nullptr, s);
+        gemm_nt<0>(gb2, wt->wo_t, dob, M, 256, 256, nullptr, nullptr, s);
         hipLaunchKernelGGL(group_attn_bwd_kernel, dim3((G + 1) / 2), dim3(256), 0, s, q, kv, dob, dq, dkv, G, ld_dkv);
         if (!dkv_ext) gemm_nt<1>(dkv, wt->wkv_t, dcond, Mkv, cond_dim, 512, dcond, nullptr, s);
         gemm_nt<0>(dq, wt->wq_t, tmpb, M, 256, 256, nullptr, nullptr, s);
     }
     {
-        L2D_PROF("gbb_dw_attn", s);
-        if ((rc = gemm_tn(gb, 256, 256, o, 256, 256, 1, nullptr, M, dw->wo, tnpart, s))) return rc;
-        if ((rc = gemm_tn(dq, 256, 256, xn1, 256, 256, 1, nullptr, M, dw->wq, tnpart, s))) return rc;
-        if ((rc = gemm_tn(dkv, ld_dkv, 512, cond_bf16, cond_dim, cond_dim, 1, nullptr, Mkv, dw->wkv, tnpart, s))) return rc;
-    }
-    {
         L2D_PROF("gbb_ln_bwd", s);
         if ((rc = ln_bwd(tmpb, true, x_in, w->ln1_w, w->eps, g, g, gb, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
+    }
+    {
+        L2D_PROF("gbb_dw_linear", s);      // dW2, dW1, dWo, dWq, dWkv
+        const TnJob jobs[5] = {{gb3, 256, 256, h, 512, 512, M, dw->w2},
+                               {dzb, 512, 512, xn2, 256, 256, M, dw->w1},
+                               {gb2, 256, 256, o, 256, 256, M, dw->wo},
+                               {dq, 256, 256, xn1, 256, 256, M, dw->wq},
+                               {dkv, ld_dkv, 512, cond_bf16, cond_dim, cond_dim, Mkv, dw->wkv}};
+        if ((rc = gemm_tn_group(jobs, 5, tnpart, s))) return rc;
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -45,8 +45,8 @@ for k, ms in rec:
 G = M // 8
 gemm = {"q": 2 * M * 256 * 256, "kv": 2 * G * 4 * 800 * 512, "o": 2 * M * 256 * 256, "mlp": 2 * 2 * M * 256 * 512,
         "conv": 2 * M * 27 * 256 * 256}
-fl = {"gbb_dw_conv": gemm["conv"], "gbb_dx_conv": gemm["conv"], "gbb_dx_mlp": gemm["mlp"], "gbb_dw_mlp": gemm["mlp"],
-      "gbb_dx_attn": gemm["q"] + gemm["kv"] + gemm["o"], "gbb_dw_attn": gemm["q"] + gemm["kv"] + gemm["o"],
+fl = {"gbb_dw_conv": gemm["conv"], "gbb_dx_conv": gemm["conv"], "gbb_dx_mlp": gemm["mlp"], "gbb_dw_linear": gemm["mlp"] + gemm["q"] + gemm["kv"] + gemm["o"],
+      "gbb_dx_attn": gemm["q"] + gemm["kv"] + gemm["o"], 
       "gbb_recompute": gemm["q"] + gemm["kv"] + gemm["o"] + gemm["mlp"]}
 tot = 0.0
 for k, (n, t) in sorted(agg.items()):
