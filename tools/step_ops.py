@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Which torch operators does the headline step launch, how often, and from which line of this package?  One step of
-`bench.py`'s pipeline under torch.profiler (with_stack), device kernels grouped by the innermost frame under lara_amd/ or
-bench.py.  Run on the GPU box:  python tools/step_ops.py [--top 40]"""
+`bench.py`'s pipeline under torch.profiler (with_stack), device kernels grouped by operator (an autograd Function's
+time INCLUDES the torch operators it calls, which are also listed on their own: the rows do not add up to the step).  Run on the GPU box:  python tools/step_ops.py [--top 40]"""
 import argparse, collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
