@@ -1246,6 +1246,7 @@ def make_pipeline_step(args, device, rank, world, plumbing):
                 p.grad = None
         feat_vol.grad = None
     info["update"] = update
+    info["opt"] = opt
 
     def full_step(ms_ssim=args.ms_ssim):
         out = model(batch, feat_vol, with_fine=with_fine)
@@ -1602,6 +1603,50 @@ def main():
                                     "ms_per_step": round(1e3 * d1 / args.steps, 3),
                                     "what": "the headline step + 0.5 (1 - MS_SSIM) for the coarse and the fine image (lara_amd.loss.ms_ssim: "
                                             "torch matmul / pooling operators, fp32, no HIP kernel of this repo)"}
+    if solo and args.step == "pipeline" and not args.no_side_legs and info.get("optimizer") is not None and args.lr == 0.0:
+        # The same step with the reference's learning rate (configs/base.yaml: 4e-4) instead of 0: the parameters now MOVE, i.e. the
+        # Gaussians the network emits -- and with them the raster's workload -- drift from step to step; the figure shows that the
+        # update itself costs the same either way.  The parameters and the optimiser state are put back afterwards.
+        _leg("step_with_reference_lr")
+        pipe_, opt_ = info["pipeline"][0], info["opt"]
+        snap = {k: v.detach().clone() for k, v in pipe_.state_dict().items()}
+        opt_snap = opt_.state_dict()
+        opt_snap = {"state": {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()} for k, st in opt_snap["state"].items()},
+                    "param_groups": [dict(g) for g in opt_snap["param_groups"]]}
+        for g_ in opt_.param_groups:
+            g_["lr"] = 4e-4
+
+        def surfel_stats():      # what the raster's workload depends on
+            with torch.no_grad():
+                g_ = pipe_.gaussians(info["pipeline"][2])
+                return {"opacity_mean": round(float(torch.sigmoid(g_["opacity"]).mean()), 4),
+                        "scale_mean": round(float(g_["scaling"].mean()), 5),
+                        "kept_by_the_fine_mask": round(float(g_["masks"].float().mean()), 4)}
+        try:
+            fs = info["pipeline"][3]
+            before = surfel_stats()
+            torch.cuda.synchronize()
+            per = []
+            for _ in range(args.steps):
+                t1 = time.perf_counter()
+                fs()
+                torch.cuda.synchronize()
+                per.append(time.perf_counter() - t1)
+            d1 = sum(per)
+            out["step_with_reference_lr"] = {"value": round(frames_per_step * args.steps / d1, 3), "unit": "frames/s",
+                                             "ms_per_step": round(1e3 * d1 / args.steps, 3), "lr": 4e-4,
+                                             "ms_first_step": round(1e3 * per[0], 2), "ms_last_step": round(1e3 * per[-1], 2),
+                                             "surfels_before": before, "surfels_after": surfel_stats(),
+                                             "what": f"the headline step with AdamW's learning rate at the reference's 4e-4 for {args.steps} steps from the "
+                                                     "random-init network, each step synchronised: the update costs what it costs at rate 0 (first step), "
+                                                     "and the parameters -- hence the surfels the network emits and the raster's work -- move from there "
+                                                     "(restored afterwards)"}
+        finally:
+            for g_ in opt_.param_groups:
+                g_["lr"] = args.lr
+            with torch.no_grad():
+                pipe_.load_state_dict(snap)
+            opt_.load_state_dict(opt_snap)
     if solo and args.step == "pipeline" and not args.no_side_legs:
         # The same step as an UNMODIFIED LaRa issues it around the drop-in rasteriser (lara_amd.reference_style: one
         # GaussianRasterizer call per view on one stream, render_img's post-processing / get_point_feats / forward_fine / the coarse
