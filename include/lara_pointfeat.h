@@ -56,6 +56,21 @@ int lara_point_feats_backward_concat(int32_t n, int32_t V, int32_t row_views, in
                                      const float *acc_map, const float *depth, const float *g_out, float *d_points,
                                      float *d_image, float *d_acc_map, float *d_depth, void *workspace, void *stream);
 
+/* The fine stage's `x[mask]` rows (network.py:514-524: centres, SH, opacity, scaling, rotation of the surfels the mask keeps) as
+ * ONE launch per direction instead of one index_select / index_copy_ per tensor.  `idx`: n int64 row indices on the device.
+ *   scatter = 0 (forward):   items[k].dst[r][0..width) = items[k].src[idx[r]][0..width)         for r < n
+ *   scatter = 1 (backward):  items[k].dst[idx[r]][0..width) = items[k].src[r][0..width)         (dst zero-filled by the caller;
+ *                            the indices of a mask are unique, so this is a copy, not an accumulation)
+ * All tensors fp32, row-major, rows of `width` floats; count <= LARA_ROWS_MAX; n * (sum of widths) < 2^31. */
+#define LARA_ROWS_MAX 8
+typedef struct {
+    const float *src;
+    float *dst;
+    int32_t width;
+} lara_rows_item;
+
+int lara_take_rows(int32_t n, const int64_t *idx, int32_t count, const lara_rows_item *items, int32_t scatter, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,6 +219,31 @@ void launch_pack(const PfP &p, float4 *packed, hipStream_t s) {
     hipLaunchKernelGGL(pack_stack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, packed);
 }
 
+// ---- rows of several row-major fp32 tensors through one index list, one thread per (row, float) --------------------------------
+// forward: dst_k[r][:] = src_k[idx[r]][:];  scatter (the backward for UNIQUE indices): dst_k[idx[r]][:] = src_k[r][:] into
+// zero-filled dst_k.  The five per-surfel tensors of the fine pass are 3 + 12 + 1 + 2 + 4 = 22 floats per row: torch issues five
+// index_select / index_copy_ launches per scene and direction (57 us each at 262 144 rows); this is one.
+struct RowsP {
+    const float *src[LARA_ROWS_MAX];
+    float *dst[LARA_ROWS_MAX];
+    int width[LARA_ROWS_MAX], first[LARA_ROWS_MAX + 1];
+    const int64_t *idx;
+    int n, count;
+};
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) take_rows_kernel(const RowsP p) {
+    const int total = p.first[p.count];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.n * total) return;
+    const int r = t / total, c = t - r * total;
+    int k = 0;
+    while (k + 1 < p.count && c >= p.first[k + 1]) k++;
+    const int w = p.width[k], cc = c - p.first[k];
+    const size_t far = (size_t)p.idx[r] * w + cc, near = (size_t)r * w + cc;
+    if (SCATTER) p.dst[k][far] = p.src[k][near];
+    else p.dst[k][near] = p.src[k][far];
+}
+
 }  // namespace
 
 extern "C" {
@@ -296,6 +321,33 @@ int lara_point_feats_backward_concat(int32_t n, int32_t V, int32_t row_views, in
         if (maps)
             hipLaunchKernelGGL(unpack_grad_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, p, (const float4 *)dpacked, npix,
                                d_image, d_acc_map, d_depth);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+
+/* ---- the fine stage's subset rows (network.py:514-524: `x[mask]` of the five per-surfel tensors), one launch for all of them ---- */
+int lara_take_rows(int32_t n, const int64_t *idx, int32_t count, const lara_rows_item *items, int32_t scatter, void *stream) {
+    if (n < 0 || count < 0 || count > LARA_ROWS_MAX) return LARA2DGS_E_INVALID;
+    if (n == 0 || count == 0) return LARA2DGS_OK;
+    if (!idx || !items) return LARA2DGS_E_INVALID;
+    RowsP p{};
+    p.n = n; p.count = count; p.idx = idx;
+    int total = 0;
+    for (int k = 0; k < count; k++) {
+        if (!items[k].src || !items[k].dst || items[k].width <= 0) return LARA2DGS_E_INVALID;
+        p.src[k] = items[k].src; p.dst[k] = items[k].dst; p.width[k] = items[k].width; p.first[k] = total;
+        total += items[k].width;
+    }
+    p.first[count] = total;
+    if ((int64_t)n * total >= (1ll << 31)) return LARA2DGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(((int64_t)n * total + 255) / 256);
+    {
+        L2D_PROF(scatter ? "take_rows_bwd" : "take_rows_fwd", s);
+        if (scatter) hipLaunchKernelGGL(take_rows_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(take_rows_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -51,6 +51,8 @@ def _lib():
         lib.lara_fine_ln_forward.argtypes = [i32, vp, vp, vp, ctypes.c_float, vp, vp, vp]
         lib.lara_fine_ln_backward.restype = ctypes.c_int
         lib.lara_fine_ln_backward.argtypes = [i32] + [vp] * 7
+        lib.lara_take_rows.restype = ctypes.c_int
+        lib.lara_take_rows.argtypes = [i32, vp, i32, ctypes.POINTER(_RowsItem), i32, vp]
         _configured = True
     return lib
 
@@ -125,6 +127,55 @@ class _TakeRows(torch.autograd.Function):
         out = g.new_zeros((ctx.n,) + tuple(g.shape[1:]))
         out.index_copy_(0, idx, g.contiguous())
         return out, None
+
+
+class _RowsItem(ctypes.Structure):        # include/lara_pointfeat.h: lara_rows_item
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("width", ctypes.c_int32)]
+
+
+def _rows_call(idx, srcs, dsts, scatter):
+    items = (_RowsItem * len(srcs))()
+    for k, (a, b) in enumerate(zip(srcs, dsts)):
+        items[k].src, items[k].dst, items[k].width = a.data_ptr(), b.data_ptr(), a[0].numel()
+    dev = srcs[0].device
+    with torch.cuda.device(dev):
+        _check(_lib().lara_take_rows(idx.numel(), idx.data_ptr(), len(srcs), items, int(scatter), torch.cuda.current_stream(dev).cuda_stream),
+               "lara_take_rows")
+
+
+class _TakeRowsMulti(torch.autograd.Function):
+    """(idx, x_0 .. x_{k-1}) -> (x_0[idx] .. x_{k-1}[idx]) for UNIQUE indices, one launch per direction for all k tensors
+    (`lara_take_rows`, include/lara_pointfeat.h)."""
+
+    @staticmethod
+    def forward(ctx, idx, *xs):
+        if not xs[0].is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        idx = idx.contiguous()
+        xs = [x.detach().float().contiguous() for x in xs]
+        n = idx.numel()
+        outs = [torch.empty((n,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device) for x in xs]
+        if n:
+            _rows_call(idx, xs, outs, False)
+        ctx.save_for_backward(idx)
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        (idx,) = ctx.saved_tensors
+        dev = idx.device
+        grads = [None if g is None else torch.zeros(shape, dtype=torch.float32, device=dev) for g, shape in zip(gs, ctx.shapes)]
+        live = [(g.float().contiguous(), d) for g, d in zip(gs, grads) if g is not None]
+        if live and idx.numel():
+            _rows_call(idx, [g for g, _ in live], [d for _, d in live], True)
+        return (None,) + tuple(grads)
+
+
+def take_rows_multi(xs, idx):
+    """``[x[idx] for x in xs]`` for the fine stage's subsets with ONE launch per direction (see `take_rows`; `idx` = unique
+    row indices, e.g. ``mask.nonzero().squeeze(-1)``)."""
+    return _TakeRowsMulti.apply(idx, *xs)
 
 
 def take_rows(x, idx):

@@ -32,11 +32,13 @@ from __future__ import annotations
 import contextlib
 import math
 
+import os
+
 import torch
 from torch import nn
 
 from . import cameras, coarse
-from .fine import _tn_over_points, fold_fine_weights, forward_fine, sample_point_feats, take_rows
+from .fine import _tn_over_points, fold_fine_weights, forward_fine, sample_point_feats, take_rows, take_rows_multi
 from .renderer import Renderer
 
 
@@ -322,17 +324,21 @@ class LaRaPipeline(nn.Module):
                     co = per_scene[i]
                     H, VW = co["acc_map"].shape
                     V, W = len(cams_of[i]), VW // len(cams_of[i])
-                    centers_f = take_rows(sc["centers"][i], idx[i])
+                    # the five x[mask] of network.py:514-524 as one launch per direction
+                    five = [sc["centers"][i], sc["shs"][i], sc["opacity"][i], sc["scaling"][i], sc["rotation"][i]]
+                    if os.environ.get("LARA_ROWS_ONE_BY_ONE") == "1":        # (A/B runs: one index_select per tensor, as before)
+                        centers_f, shs_sel, opacity_f, scaling_f, rotation_f = [take_rows(x, idx[i]) for x in five]
+                    else:
+                        centers_f, shs_sel, opacity_f, scaling_f, rotation_f = take_rows_multi(five, idx[i])
                     # the sampler reads the first n_sel views of the side-by-side maps in place (network.py:499 stacks them)
                     pf = sample_point_feats(centers_f, batch["tar_w2c"][i, :n_sel], batch["tar_ixt"][i, :n_sel], inps[i],
                                             co["image"], co["acc_map"], co["depth"], row_views=V)
                     vox = torch.div(idx[i], self.K, rounding_mode="floor")
                     sh_res = forward_fine(self.decoder, _TakeVoxelRows.apply(sc["vol"][i], vox), torch.einsum("lcb->blc", pf), folded)
-                    shs_f = sh_res.view(-1, *g["shs"].shape[-2:]) + take_rows(sc["shs"][i], idx[i])
+                    shs_f = sh_res.view(-1, *g["shs"].shape[-2:]) + shs_sel
                     self._mark("sampler+forward_fine")
                     co.update(self.gs_render.render_views(
-                        cams_of[i], batch["tar_rays"][i], centers_f, shs_f, take_rows(sc["opacity"][i], idx[i]),
-                        take_rows(sc["scaling"][i], idx[i]), take_rows(sc["rotation"][i], idx[i]), dev,
+                        cams_of[i], batch["tar_rays"][i], centers_f, shs_f, opacity_f, scaling_f, rotation_f, dev,
                         bg_colors=batch["bg_color"][i], prex="_fine", concat=True))
                     self._mark("fine views")
         outs = per_scene                                                        # network.py:527: already [H, V*W, C] per key

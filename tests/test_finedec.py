@@ -143,3 +143,30 @@ def test_take_rows_matches_advanced_indexing():
     a.backward(g)
     b.backward(g)
     assert torch.equal(x.grad, y.grad)
+
+
+@pytest.mark.gpu
+def test_take_rows_multi_matches_advanced_indexing():
+    """The five `x[mask]` of network.py:514-524 as one launch per direction (`lara_take_rows`): values and gradients bit for bit
+    those of advanced indexing; an output nobody uses gets no gradient; an empty subset works."""
+    from lara_amd.fine import take_rows_multi
+    torch.manual_seed(1)
+    shapes = [(3,), (4, 3), (1,), (2,), (4,)]
+    xs = [torch.randn(3001, *s, device="cuda", requires_grad=True) for s in shapes]
+    ys = [x.detach().clone().requires_grad_(True) for x in xs]
+    idx = (torch.rand(3001, device="cuda") > 0.47).nonzero().squeeze(-1)
+    outs = take_rows_multi(xs, idx)
+    refs = [y[idx] for y in ys]
+    for a, b in zip(outs, refs):
+        assert a.shape == b.shape and torch.equal(a, b)
+    gs = [torch.randn_like(b) for b in refs]
+    use = [0, 1, 3, 4]                       # the opacity output's gradient stays undefined
+    torch.autograd.backward([outs[k] for k in use], [gs[k] for k in use])
+    torch.autograd.backward([refs[k] for k in use], [gs[k] for k in use])
+    for k, (x, y) in enumerate(zip(xs, ys)):
+        if k in use:
+            assert torch.equal(x.grad, y.grad), k
+        else:
+            assert x.grad is None or not bool(x.grad.any()), k
+    empty = take_rows_multi([x.detach() for x in xs], idx[:0])
+    assert [tuple(e.shape) for e in empty] == [(0,) + s for s in shapes]
