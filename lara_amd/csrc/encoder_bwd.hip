@@ -325,17 +325,19 @@ accum_partials_kernel(float *__restrict__ dst, const float *__restrict__ part, c
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < n) {
-        // four independent chains: a slice walks up to 128 parts, and one dependent load + add per part is pure latency
-        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        // sixteen loads in flight per thread: a slice walks up to 128 parts, and one load + add per part at a time is pure latency
         int q = sl;
-        for (; q + 3 * nsl < parts; q += 4 * nsl) {
-            s += part[(size_t)q * stride + c];
-            s1 += part[(size_t)(q + nsl) * stride + c];
-            s2 += part[(size_t)(q + 2 * nsl) * stride + c];
-            s3 += part[(size_t)(q + 3 * nsl) * stride + c];
+        for (; q + 15 * nsl < parts; q += 16 * nsl) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = part[(size_t)(q + u * nsl) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] += v[u + 8];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] += v[u + 4];
+            s += (v[0] + v[2]) + (v[1] + v[3]);
         }
         for (; q < parts; q += nsl) s += part[(size_t)q * stride + c];
-        s = (s + s1) + (s2 + s3);
     }
     red[sl][lane] = s;
     __syncthreads();
@@ -436,16 +438,19 @@ accum_ln_partials_kernel(float *d0, float *d1, float *d2, const float *__restric
     if (!dst) return;
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;     // (four independent chains, as in accum_partials_kernel)
+    float s = 0.f;      // (sixteen loads in flight per thread, as in accum_partials_kernel)
     int q = sl;
-    for (; q + 48 < parts; q += 64) {
-        s += part[(size_t)q * 768 + blockIdx.y * 256 + c];
-        s1 += part[(size_t)(q + 16) * 768 + blockIdx.y * 256 + c];
-        s2 += part[(size_t)(q + 32) * 768 + blockIdx.y * 256 + c];
-        s3 += part[(size_t)(q + 48) * 768 + blockIdx.y * 256 + c];
+    for (; q + 240 < parts; q += 256) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = part[(size_t)(q + 16 * u) * 768 + blockIdx.y * 256 + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] += v[u + 8];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] += v[u + 4];
+        s += (v[0] + v[2]) + (v[1] + v[3]);
     }
     for (; q < parts; q += 16) s += part[(size_t)q * 768 + blockIdx.y * 256 + c];
-    s = (s + s1) + (s2 + s3);
     red[sl][lane] = s;
     __syncthreads();
     if (sl == 0) {
