@@ -50,3 +50,21 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_reference_optimizer_groups_follow_system_configure_optimizers():
+    """`bench.reference_optimizer` builds what lightning/system.py:78-106 builds: every LayerNorm parameter and every bias in the
+    group without weight decay, every other parameter (once) in the decayed one; AdamW with configs/base.yaml's betas."""
+    import torch
+    import bench
+    m = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.LayerNorm(8), torch.nn.Conv3d(2, 2, 3), torch.nn.Linear(8, 4, bias=False))
+    m[0].weight.requires_grad_(True)
+    opt = bench.reference_optimizer(m, 4e-4)
+    decay, no_decay = opt.param_groups
+    assert decay["weight_decay"] == 0.05 and no_decay["weight_decay"] == 0.0
+    ids = lambda g: {id(p) for p in g["params"]}
+    assert ids(decay) == {id(m[0].weight), id(m[2].weight), id(m[3].weight)}
+    assert ids(no_decay) == {id(m[0].bias), id(m[1].weight), id(m[1].bias), id(m[2].bias)}
+    assert len(no_decay["params"]) == 4 and opt.defaults["betas"] == (0.9, 0.95) and decay["lr"] == 4e-4
+    m[0](torch.randn(3, 8)).sum().backward()
+    opt.step()          # (the CPU fallback of the fused update)
