@@ -828,9 +828,9 @@ int colsum_bf16(const unsigned short *src, int rows, int C, float *dst, float *p
 
 template <int EPI>
 void gemm_nt(const unsigned short *A, const unsigned short *W, void *C, int M, int N, int K, const float *resid,
-             unsigned short *C2, hipStream_t s) {
+             unsigned short *C2, hipStream_t s, float *colsum = nullptr) {
     GemmP p{};
-    p.A = A; p.W = W; p.C = C; p.resid = resid; p.C2 = C2; p.M = M; p.N = N; p.K = K;
+    p.A = A; p.W = W; p.C = C; p.resid = resid; p.C2 = C2; p.M = M; p.N = N; p.K = K; p.colsum = colsum;
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, EPI>), dim3((M + 127) / 128, (N + 127) / 128), dim3(256), 0, s, p);
 }
 
@@ -1027,12 +1027,10 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     // ---- x2 = x1 + mlp(norm2(x1)) ----
     {
         L2D_PROF("gbb_dx_mlp", s);
-        gemm_nt<7>(gb3, wt->w2_t, dzb, M, 512, 256, nullptr, z, s);  // dz = (g2 W2) * gelu'(z)
+        // dz = (g2 W2) * gelu'(z); its column sums per 128-row tile (= the pieces of db1) come out of the same epilogue
+        gemm_nt<7>(gb3, wt->w2_t, dzb, M, 512, 256, nullptr, z, s, lnpart);
+        hipLaunchKernelGGL(accum_partials_kernel, dim3(512 / 64), dim3(1024), 0, s, dw->b1, lnpart, 512, (M + 127) / 128, (size_t)512);
         gemm_nt<0>(dzb, wt->w1_t, tmpb, M, 256, 512, nullptr, nullptr, s);   // bf16: see ln_bwd_kernel
-    }
-    {
-        L2D_PROF("gbb_dw_mlp", s);
-        if ((rc = colsum_bf16(dzb, M, 512, dw->b1, lnpart, s))) return rc;
     }
     {
         L2D_PROF("gbb_ln_bwd", s);

@@ -84,6 +84,7 @@ struct GemmP {
     int Cout;            // EPI 5
     uint32_t zero_off;   // AMODE 1: byte offset from A of a zeroed row of Cin bf16 (the padding voxels)
     unsigned short *C2;  // EPI 6: bf16 [M, N] pre-activation out; EPI 7: the same, read
+    float *colsum;       // EPI 7 (gemm_bf16_nt_kernel, optional): [row tiles of 128][N] column sums of the stored bf16 values per row tile
 };
 
 // 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_exp / v_rcp
@@ -148,7 +149,7 @@ __device__ __forceinline__ void xcd_tile(int &rt, int &ct) {
 // is EPI 5's output offset of the row's voxel (2d, 2h, 2w).  Shared by both GEMM kernels.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP &p, float4 v, const int row, const int col, const int N,
-                                              const unsigned long long base_out) {
+                                              const unsigned long long base_out, float4 *stored = nullptr) {
     const size_t o = (size_t)row * N + col;
     if (EPI == 2 || EPI == 3 || EPI == 6) {
         const float4 bs = *(const float4 *)(p.bias + col);
@@ -171,6 +172,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP &p, float4 v, const in
         ushort4 h;
         h.x = f2bf(v.x); h.y = f2bf(v.y); h.z = f2bf(v.z); h.w = f2bf(v.w);
         *(ushort4 *)((unsigned short *)p.C + o) = h;
+        if (stored) *stored = make_float4(bf2f(h.x), bf2f(h.y), bf2f(h.z), bf2f(h.w));     // (what a later column sum of C would add up)
     } else if (EPI == 8) {
         *(float4 *)((float *)p.C + o) = v;
     } else if (EPI == 1 || EPI == 3) {
@@ -314,6 +316,7 @@ gemm_bf16_nt_kernel(const GemmP p) {
     // 16-byte row-contiguous loads of the residual and 16-byte stores.
     float *ep = (float *)&lds[0][0] + wave * (32 * 68);  // 32 rows x (64 + 4 pad) floats per wave
     unsigned long long *rowbase = (unsigned long long *)((float *)&lds[0][0] + 4 * (32 * 68)) + wave * 32;  // EPI 5
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);          // EPI 7: this thread's share of the tile's column sums
 #pragma unroll
     for (int ij = 0; ij < MI * (NJ / 2); ij++) {
         const int i = ij / (NJ / 2), jh = ij % (NJ / 2);  // 32 rows x 64 columns of the wave tile per trip
@@ -334,9 +337,28 @@ gemm_bf16_nt_kernel(const GemmP p) {
         for (int q = 0; q < 8; q++) {
             const int idx = q * 64 + lane, lr = idx >> 4, c4 = (idx & 15) * 4;
             const int row = bm0 + wm + i * 32 + lr, col = bn0 + wn + jh * 64 + c4;
-            if (row < M && col < N)
-                gemm_epilogue<EPI>(p, *(const float4 *)(ep + lr * 68 + c4), row, col, N, EPI == 5 ? rowbase[lr] : 0ull);
+            if (row < M && col < N) {
+                if (EPI == 7 && NJ == 2) {
+                    float4 st;
+                    gemm_epilogue<EPI>(p, *(const float4 *)(ep + lr * 68 + c4), row, col, N, 0ull, &st);
+                    cs.x += st.x; cs.y += st.y; cs.z += st.z; cs.w += st.w;
+                } else {
+                    gemm_epilogue<EPI>(p, *(const float4 *)(ep + lr * 68 + c4), row, col, N, EPI == 5 ? rowbase[lr] : 0ull);
+                }
+            }
         }
+    }
+    // EPI 7: the bias gradient of the layer in front is the column sum of what was just stored.  A thread holds four columns of
+    // 16 of the wave's 64 rows; the four lane groups add up with two shuffles, the two waves of a column half through LDS, and the
+    // workgroup leaves one row of per-tile sums (a separate pass over C would read it all again: 134 MB per block of LaRa's encoder)
+    if (EPI == 7 && NJ == 2 && p.colsum) {
+        cs.x += __shfl_xor(cs.x, 16); cs.y += __shfl_xor(cs.y, 16); cs.z += __shfl_xor(cs.z, 16); cs.w += __shfl_xor(cs.w, 16);
+        cs.x += __shfl_xor(cs.x, 32); cs.y += __shfl_xor(cs.y, 32); cs.z += __shfl_xor(cs.z, 32); cs.w += __shfl_xor(cs.w, 32);
+        __syncthreads();
+        float *cb = (float *)&lds[0][0];      // [2 row halves][GN]
+        if (lane < 16) *(float4 *)(cb + (wave >> 1) * GN + wn + lane * 4) = cs;
+        __syncthreads();
+        if (tid < GN && bn0 + tid < N) p.colsum[(size_t)rt_ * N + bn0 + tid] = cb[tid] + cb[GN + tid];
     }
 }
 
