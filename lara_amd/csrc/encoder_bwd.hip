@@ -460,6 +460,51 @@ accum_ln_partials_kernel(float *d0, float *d1, float *d2, const float *__restric
     }
 }
 
+// Several of those column reductions in one launch (a block's three LayerNorm backward passes and its b1 gradient leave eight of
+// them; one by one they are eight-to-twelve-workgroup kernels that run alone on the device, 17 us each): dst_k[c] += sum over
+// q < parts_k of part_k[q * stride_k + c], 64 columns per workgroup, 16 slices of the parts, sixteen loads in flight per thread.
+constexpr int RED_GROUP_MAX = 8;
+struct RedGroup {
+    float *dst[RED_GROUP_MAX];
+    const float *part[RED_GROUP_MAX];
+    int n[RED_GROUP_MAX], parts[RED_GROUP_MAX], stride[RED_GROUP_MAX], first_wg[RED_GROUP_MAX + 1];
+    int count;
+};
+__global__ void __launch_bounds__(1024)
+reduce_group_kernel(const RedGroup g) {
+    __shared__ float red[16][64];
+    int wg = blockIdx.x, which = 0;
+    while (which + 1 < g.count && wg >= g.first_wg[which + 1]) which++;
+    wg -= g.first_wg[which];
+    const float *part = g.part[which];
+    const int n = g.n[which], parts = g.parts[which];
+    const size_t stride = (size_t)g.stride[which];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = wg * 64 + lane;
+    float s = 0.f;
+    if (c < n) {
+        int q = sl;
+        for (; q + 240 < parts; q += 256) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = part[(size_t)(q + 16 * u) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] += v[u + 8];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] += v[u + 4];
+            s += (v[0] + v[2]) + (v[1] + v[3]);
+        }
+        for (; q < parts; q += 16) s += part[(size_t)q * stride + c];
+    }
+    red[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && c < n) {
+        float t = red[0][lane];
+        for (int k = 1; k < 16; k++) t += red[k][lane];
+        g.dst[which][c] += t;
+    }
+}
+
 // nbr[tap][m] = BYTE offset (rows of `row_bytes`) of the token row of voxel(m) + (dz, dy, dx), or of row
 // `zero_row` outside the volume
 __global__ void __launch_bounds__(256)
@@ -810,12 +855,42 @@ int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
 }
 
 // LayerNorm backward + the reductions of its partial sums into dgamma, dbeta, dbias (any may be null)
+// pending column reductions of a block (reduce_group_kernel)
+struct RedList {
+    RedGroup g{};
+    int wgs = 0;
+    bool overflow = false;
+    void add(float *dst, const float *part, int n, int parts, int stride) {
+        if (!dst) return;
+        if (g.count >= RED_GROUP_MAX) { overflow = true; return; }
+        const int k = g.count++;
+        g.dst[k] = dst; g.part[k] = part; g.n[k] = n; g.parts[k] = parts; g.stride[k] = stride; g.first_wg[k] = wgs;
+        wgs += (n + 63) / 64;
+        g.first_wg[g.count] = wgs;
+    }
+    int launch(hipStream_t s) {
+        if (overflow) return LARA2DGS_E_INVALID;
+        if (g.count) hipLaunchKernelGGL(reduce_group_kernel, dim3(wgs), dim3(1024), 0, s, g);
+        g.count = 0; wgs = 0;
+        return LARA2DGS_OK;
+    }
+};
+
+// `later`: the three reductions are queued there (the caller launches them with others) instead of launched here; `part` must
+// then stay untouched until it does
 int ln_bwd(const void *dy, bool dy_bf16, const float *x, const float *gamma, float eps, const float *skip, float *dx,
-           unsigned short *dx_bf16, float *dgamma, float *dbeta, float *dbias, float *part, int M, hipStream_t s) {
+           unsigned short *dx_bf16, float *dgamma, float *dbeta, float *dbias, float *part, int M, hipStream_t s,
+           RedList *later = nullptr) {
     const int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
     if (dy_bf16) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, eps, skip, dx, dx_bf16, part, M);
     else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, gamma, eps, skip, dx, dx_bf16, part, M);
-    hipLaunchKernelGGL(accum_ln_partials_kernel, dim3(4, 3), dim3(1024), 0, s, dgamma, dbeta, dbias, part, blocks);
+    if (later) {
+        later->add(dgamma, part, 256, blocks, 768);
+        later->add(dbeta, part + 256, 256, blocks, 768);
+        later->add(dbias, part + 512, 256, blocks, 768);
+    } else {
+        hipLaunchKernelGGL(accum_ln_partials_kernel, dim3(4, 3), dim3(1024), 0, s, dgamma, dbeta, dbias, part, blocks);
+    }
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
 }
 
@@ -854,7 +929,7 @@ SaveWs save_layout(int64_t M) {
 }
 // scratch of lara_groupblock_backward (followed by a SaveWs for the recompute mode)
 struct BwdWs {
-    size_t gb, tmpf, dzb, dq, dkv, dob, nbr, lnpart, tnpart, save, gb3, gb2, total;
+    size_t gb, tmpf, dzb, dq, dkv, dob, nbr, lnpart, tnpart, save, gb3, gb2, lnpart4, total;
 };
 BwdWs bwd_layout(int64_t M) {
     BwdWs w{};
@@ -867,7 +942,8 @@ BwdWs bwd_layout(int64_t M) {
     w.lnpart = take(((size_t)(M + 63) / 64) * 768 * 4);
     w.tnpart = take(TN_PART_BYTES);
     w.save = take(save_layout(M).total);
-    w.gb3 = take(b256); w.gb2 = take(b256);   // bf16(g) behind norm3's / norm2's backward, kept for the block's grouped weight gradients
+    w.gb3 = take(b256); w.gb2 = take(b256);
+    w.lnpart4 = take(4 * ((size_t)(M + LNB_ROWS - 1) / LNB_ROWS) * 768 * 4);   // four sets of per-workgroup partial column sums, reduced together   // bf16(g) behind norm3's / norm2's backward, kept for the block's grouped weight gradients
     w.total = o;
     return w;
 }
@@ -997,6 +1073,12 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     unsigned short *dob = (unsigned short *)(ws + L.dob);
     unsigned short *tmpb = (unsigned short *)(ws + L.tmpf);   // dX of the MLP / of the Q projection, bf16 [M, 256]
     float *lnpart = (float *)(ws + L.lnpart), *tnpart = (float *)(ws + L.tnpart);
+    // the block's four sets of per-workgroup partial column sums (three LayerNorm backward passes, the b1 gradient) live side by
+    // side and are reduced by ONE launch at the end of the block
+    const size_t lnset = ((size_t)(M + LNB_ROWS - 1) / LNB_ROWS) * 768;
+    float *lnp4 = (float *)(ws + L.lnpart4);
+    RedList red;
+    (void)lnpart;
     int *nbr = (int *)(ws + L.nbr);
     if (!chained) {  // (a chained call finds the zero row, the neighbour table and bf16(g) where the call before left them)
         if (hipMemsetAsync(gb + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
@@ -1021,20 +1103,20 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     // layers, whose operands are then all alive at the end of the block, run as ONE grouped product (gemm_tn_group).
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(g, false, x2, w->ln3_w, w->eps, nullptr, g, gb3, dw->ln3_w, dw->ln3_b, dw->b2, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(g, false, x2, w->ln3_w, w->eps, nullptr, g, gb3, dw->ln3_w, dw->ln3_b, dw->b2, lnp4, M, s, &red))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x2 = x1 + mlp(norm2(x1)) ----
     {
         L2D_PROF("gbb_dx_mlp", s);
         // dz = (g2 W2) * gelu'(z); its column sums per 128-row tile (= the pieces of db1) come out of the same epilogue
-        gemm_nt<7>(gb3, wt->w2_t, dzb, M, 512, 256, nullptr, z, s, lnpart);
-        hipLaunchKernelGGL(accum_partials_kernel, dim3(512 / 64), dim3(1024), 0, s, dw->b1, lnpart, 512, (M + 127) / 128, (size_t)512);
+        gemm_nt<7>(gb3, wt->w2_t, dzb, M, 512, 256, nullptr, z, s, lnp4 + lnset);
+        red.add(dw->b1, lnp4 + lnset, 512, (M + 127) / 128, 512);
         gemm_nt<0>(dzb, wt->w1_t, tmpb, M, 256, 512, nullptr, nullptr, s);   // bf16: see ln_bwd_kernel
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(tmpb, true, x1, w->ln2_w, w->eps, g, g, gb2, dw->ln2_w, dw->ln2_b, nullptr, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(tmpb, true, x1, w->ln2_w, w->eps, g, g, gb2, dw->ln2_w, dw->ln2_b, nullptr, lnp4 + 2 * lnset, M, s, &red))) return rc;
     }
     L2D_CHECK_LAUNCH();
     // ---- x1 = x0 + cross_attn(norm1(x0), cond, cond) ----
@@ -1047,7 +1129,8 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     }
     {
         L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(tmpb, true, x_in, w->ln1_w, w->eps, g, g, gb, dw->ln1_w, dw->ln1_b, nullptr, lnpart, M, s))) return rc;
+        if ((rc = ln_bwd(tmpb, true, x_in, w->ln1_w, w->eps, g, g, gb, dw->ln1_w, dw->ln1_b, nullptr, lnp4 + 3 * lnset, M, s, &red))) return rc;
+        if ((rc = red.launch(s))) return rc;      // dgamma / dbeta of the three LayerNorms, b2, b1: eight column reductions, one launch
     }
     {
         L2D_PROF("gbb_dw_linear", s);      // dW2, dW1, dWo, dWq, dWkv
