@@ -157,13 +157,6 @@ def fine_subsets(scenes):
         return [(torch.sigmoid(sc["opacity"].detach()).squeeze(-1) > FINE_OPACITY).nonzero().squeeze(-1) for sc in scenes]
 
 
-def view_lanes_for(n_streams):
-    """Lanes of the library's multi-view calls: its second lane fills the device when ONE stream feeds it (1341 vs the
-    loop's 1012 frames/s); with two scene streams the application fills it already and the second lane only costs
-    (raster alone 1383 -> 1421, training step 762 -> 786 frames/s; profiles/README.md)."""
-    return 1 if n_streams >= 2 else 2
-
-
 def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="loop"):
     """All forwards of the batch, then one backward through every view (as loss.backward() does).
     Per scene: the coarse views (network.py:487-497) and, with `fine_idx`, the fine views over the masked subset with
@@ -177,8 +170,6 @@ def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="
     subset gathers once per scene, as `lara_amd.renderer.Renderer.render_views` does) instead of one call per view."""
     from lara_amd import GaussianRasterizer, rasterize_gaussians_views
     from lara_amd import rasterizer as _rz
-    if api == "views" and "LARA2DGS_VIEW_STREAMS" not in os.environ:
-        _rz.set_view_lanes(view_lanes_for(n_streams))
     outs, grads = [], []
     cur = torch.cuda.current_stream()
     while len(_streams) < n_streams and n_streams > 1:
@@ -1205,8 +1196,6 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     pipe._streams = _streams      # one pair of scene streams for every leg of this process: the device has 4 hardware queues, and a
                                   # second pair (the side legs' `step`) would alias onto them and serialise (93.5 vs 82.3 ms)
     pipe.train()
-    if "LARA2DGS_VIEW_STREAMS" not in os.environ:
-        rasterizer.set_view_lanes(view_lanes_for(args.streams))
     batch = synthetic_batch(batch_size=args.scenes, n_views=args.views, H=args.res, W=args.res, n_input=4, seed=7 + rank, device=device)
     g = torch.Generator(device="cpu").manual_seed(11 + rank)
     batch["tar_rgb"] = torch.rand(batch["tar_rgb"].shape, generator=g).to(device)
@@ -1327,8 +1316,6 @@ def pipeline_breakdown(info, args):
     pipe, batch, feat_vol, full_step = info["pipeline"]
     prev_streams = pipe.n_streams
     pipe.n_streams = 1
-    if "LARA2DGS_VIEW_STREAMS" not in os.environ:
-        rasterizer.set_view_lanes(1)      # strictly serial: stage times add up
     res = {}
     try:
         for _ in range(3):      # (the caller's stream has its own allocator pool: let it see the step's sizes first)
@@ -1383,8 +1370,6 @@ def pipeline_breakdown(info, args):
             res["opacity_mean"] = round(float(torch.sigmoid(g["opacity"]).mean()), 4)
     finally:
         pipe.n_streams = prev_streams
-        if "LARA2DGS_VIEW_STREAMS" not in os.environ:
-            rasterizer.set_view_lanes(view_lanes_for(args.streams))
     return res
 
 
@@ -1573,10 +1558,8 @@ def main():
             "frames_per_step": frames_per_step,
             "parallelism": f"dp{joined} (per-scene; raster not sharded)",
             "hip_streams": args.streams,
-            "view_lanes": (int(os.environ["LARA2DGS_VIEW_STREAMS"]) if "LARA2DGS_VIEW_STREAMS" in os.environ
-                           else view_lanes_for(args.streams)) if args.raster_api == "views" or args.step == "pipeline" else None,
-            "raster_api": ("views: one multi-view rasteriser call per scene and pass (opt-in lara_amd API; `view_lanes` "
-                           "streams per call)" if args.raster_api == "views" or args.step == "pipeline" else
+            "raster_api": ("views: one multi-view rasteriser call per scene and pass (opt-in lara_amd API; every kernel one "
+                           "launch over the cameras)" if args.raster_api == "views" or args.step == "pipeline" else
                            "loop: one GaussianRasterizer call per view (the reference's loop)"),
             "grad_allreduce": info["grad_allreduce"],
             "optimizer": info.get("optimizer"),
@@ -1626,6 +1609,9 @@ def main():
             fs = info["pipeline"][3]
             before = surfel_stats()
             torch.cuda.synchronize()
+            from lara_amd import rasterizer as _rz5
+            _rz5.check_pending(block=True)
+            reruns0 = _rz5.capacity_report()["reruns"]
             per = []
             for _ in range(args.steps):
                 t1 = time.perf_counter()
@@ -1633,10 +1619,20 @@ def main():
                 torch.cuda.synchronize()
                 per.append(time.perf_counter() - t1)
             d1 = sum(per)
+            _rz5.check_pending(block=True)
+            cap_rep = _rz5.capacity_report()
             out["step_with_reference_lr"] = {"value": round(frames_per_step * args.steps / d1, 3), "unit": "frames/s",
                                              "ms_per_step": round(1e3 * d1 / args.steps, 3), "lr": 4e-4,
                                              "ms_first_step": round(1e3 * per[0], 2), "ms_last_step": round(1e3 * per[-1], 2),
                                              "surfels_before": before, "surfels_after": surfel_stats(),
+                                             "binning_capacity": {
+                                                 "calls_repeated_at_a_larger_capacity": cap_rep.pop("reruns") - reruns0,
+                                                 "per_size_class": [{"surfels_sized_for": b[1], "image": [b[2], b[3]], "D_max": r_["D_max"],
+                                                                     "capacity_next_call": r_["capacity"],
+                                                                     "D_over_capacity": round(r_["D_max"] / r_["capacity"], 3)}
+                                                                    for b, r_ in sorted(cap_rep.items())],
+                                                 "what": "the pair capacity follows the measured pair counts (2 x the high-water mark of the size class, "
+                                                         "lara_amd/rasterizer.py); a call that outgrows it is repeated, never an error"},
                                              "what": f"the headline step with AdamW's learning rate at the reference's 4e-4 for {args.steps} steps from the "
                                                      "random-init network, each step synchronised: the update costs what it costs at rate 0 (first step), "
                                                      "and the parameters -- hence the surfels the network emits and the raster's work -- move from there "
@@ -1648,10 +1644,10 @@ def main():
                 pipe_.load_state_dict(snap)
             opt_.load_state_dict(opt_snap)
     if solo and args.step == "pipeline" and not args.no_side_legs:
-        # The same step as an UNMODIFIED LaRa issues it around the drop-in rasteriser (lara_amd.reference_style: one
+        # The same step as an UNMODIFIED LaRa issues it around the drop-in rasteriser (tools.reference_style: one
         # GaussianRasterizer call per view on one stream, render_img's post-processing / get_point_feats / forward_fine / the coarse
         # MLP / the loss as plain torch operators, `x[mask]` indexing).  The encoder stays this package's HIP VolTransformer in both.
-        from lara_amd import reference_style
+        from tools import reference_style
         from lara_amd.pipeline import lara_loss as torch_loss
         _leg("drop_in_step")
         pipe_, batch_, fv_, _fs = info["pipeline"]
@@ -1672,7 +1668,7 @@ def main():
         out["drop_in_step"] = {"value": round(frames_per_step / d1, 3), "unit": "frames/s", "ms_per_step": round(1e3 * d1, 3),
                                "what": "the headline's step as train_lightning.py issues it UNCHANGED around the shim: per-view GaussianRasterizer "
                                        "calls on one stream, reference-style torch operators for render_img's post-processing, the coarse MLP, "
-                                       "get_point_feats, forward_fine, x[mask] and the loss (lara_amd.reference_style); same HIP VolTransformer"}
+                                       "get_point_feats, forward_fine, x[mask] and the loss (tools.reference_style); same HIP VolTransformer"}
         del drop_in
         torch.cuda.empty_cache()
         # SURVEY 8d's second regime for the whole step: the same network with its opacity logits biased to an opaque thin shell
@@ -1768,8 +1764,6 @@ def main():
             rasterizer.set_cull_transparent(prev)
         _leg("forward_only")
         out["forward_only"] = forward_only_leg(scenes, settings, args)
-        if "LARA2DGS_VIEW_STREAMS" not in os.environ:
-            rasterizer.set_view_lanes(None)     # the one-stream side legs below: the library's default (two lanes)
         if not args.no_side_legs:
             _leg("mesh_eval")
             out["mesh_eval"] = mesh_eval_leg(args, device)

@@ -17,14 +17,17 @@
  *     D2H copy of `num_rendered` once per view);
  *   - the caller owns every allocation: outputs, the `state` buffer that forward hands to
  *     backward (the reference's geomBuffer/binningBuffer/imgBuffer), and a transient `scratch`;
- *   - the library keeps no global state (bar the optional profiling log and, for the multi-view calls, the
- *     side streams it keeps per caller stream) and is re-entrant across streams;
+ *   - the library keeps no global state and no settings (bar the optional profiling log) and is re-entrant across
+ *     streams;
  *   - functions return 0 on success or a negative LARA2DGS_E_* code; nothing throws.
- *   - binning capacity: the number of (tile, surfel) pairs is data dependent and only known on the
- *     device.  The caller passes `capacity`; if a view needs more, the kernels raise the
- *     `overflow` word of the state header AND poison the outputs with NaN (loud in the data); the
- *     Python operator checks the header lazily and raises.  See DESIGN.md "binning without a
- *     host sync".
+ *   - binning capacity: the number of (tile, surfel) pairs D is data dependent and only known on the
+ *     device.  The caller passes `capacity`; if a view needs more, the kernels write the real D into
+ *     header[0], raise the `overflow` word header[1] AND poison the outputs with NaN (loud in the data).
+ *     Nothing else was harmed: the caller repeats the SAME call with buffers sized for the reported D.
+ *     The Python operator does exactly that -- it sizes a call from the counts earlier calls of the same
+ *     size reported (2 x their maximum), reads the header lazily through pinned memory and repeats a
+ *     call that did not fit; the reference resizes its buffers after a blocking read of num_rendered and
+ *     can never fail on D either (lara_amd/rasterizer.py "workspace policy").
  */
 #ifndef LARA2DGS_H
 #define LARA2DGS_H
@@ -36,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LARA2DGS_ABI_VERSION 8
+#define LARA2DGS_ABI_VERSION 9
 
 #define LARA2DGS_OK 0
 #define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
@@ -87,12 +90,11 @@ typedef struct lara2dgs_state_layout {
     int64_t n_contrib;   /* uint32[2][H][W]: last contributor, median contributor */
     int64_t seg_base;    /* uint32[tiles+1]: exclusive scan of floor((len-1)/512) = interior boundaries when a
                           * tile's list is cut into 512-entry segments (the backward's unit of work) */
-    int64_t seg_cnt;     /* uint32[tiles]: boundaries in use: the same number, or 0 for a tile whose checkpoint
-                          * rows did not fit (its backward then runs as one segment) */
+    int64_t seg_cnt;     /* uint32[tiles]: floor((len-1)/512) per tile, the same numbers un-scanned */
     int64_t bwd_order;   /* uint32[tiles]: tile ids by length of the last (partial) segment, longest first */
-    int64_t bwd_items;   /* uint32[capacity/512+1 + tiles][2]: (tile, segment) of every full segment (tile = ~0: unused); after the
+    int64_t bwd_items;   /* uint32[capacity/512+1 + tiles][2]: (tile, segment) of every full segment; after the
                           * backward's ordering pass (header[22] = 1): of every work item, last segments included, dearest first */
-    int64_t ckpt;        /* float[capacity/1024+1][10][256]: the ten per-pixel running sums as the forward walk
+    int64_t ckpt;        /* float[capacity/512+1][10][256]: the ten per-pixel running sums as the forward walk
                           * crosses a segment boundary; lets segments of one tile run on different CUs */
     int64_t pair_mask;   /* uint64[capacity]: per list position, the forward's candidate mask of the entry over the tile's
                           * 8x8 grid of 2x2 pixel blocks (bit gy*8+gx); the backward reads it instead of scan-converting
@@ -131,14 +133,15 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
                      float *out_allmap, int32_t *out_radii, void *state, void *scratch,
                      void *stream);
 
-/* Replaces `_C.rasterize_gaussians_backward(...)`.  `state` is the buffer forward filled.
+/* Replaces `_C.rasterize_gaussians_backward(...)`.  `state` is the buffer forward filled; the backward WRITES to it (it
+ * re-orders the work-item list `bwd_items` in place and sets header[22]): one backward at a time per state buffer.
  * Gradient outputs (any may be NULL when the corresponding input was NULL):
  *   dL_dmeans3D [P,3], dL_dmeans2D [P,3], dL_dshs [P,M,3], dL_dcolors [P,3], dL_dopacities [P],
  *   dL_dscales [P,2], dL_drotations [P,4], dL_dtransmat [P,9].  They are fully overwritten. */
 int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const float *shs,
                       const float *colors_precomp, const float *scales, const float *rotations,
                       const float *transmat_precomp, const int32_t *radii, const float *dL_dcolor,
-                      const float *dL_dallmap, const void *state, void *scratch,
+                      const float *dL_dallmap, void *state, void *scratch,
                       float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs, float *dL_dcolors,
                       float *dL_dopacities, float *dL_dscales, float *dL_drotations,
                       float *dL_dtransmat, void *stream);
@@ -149,36 +152,15 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
  * One call rasterises the SAME surfels from n_views cameras.  `views` is an array of n_views records that agree in
  * everything but the four camera pointers (and bg).  Outputs are stacked: out_color [n,3,H,W], out_allmap [n,7,H,W],
  * out_radii [n,P]; view i's saved state lives at state + i * state_stride (state_stride >= lara2dgs_state_bytes,
- * 256-byte multiple) -- per-camera state carved from one allocation.  The views are independent until the gradient
- * sum, so the library deals them round-robin to LARA2DGS_VIEW_STREAMS lanes (default 2: more streams than the
- * device's 4 hardware queues alias and serialise again): lane 0 is `stream` itself, the others are side streams the
- * library keeps per caller stream, forked from and joined back into `stream` with events, no host synchronisation.
- * The composite kernels end in a tail of a few heavy tiles that the other lane's kernels fill.  `scratch` holds
- * n_scratch transient buffers of scratch_stride bytes each (>= lara2dgs_scratch_bytes); n_scratch bounds the number of views in flight.  With
- * n_scratch >= n_views the per-surfel preprocess of ALL cameras is ONE launch (camera = fast index of the workgroup id:
- * the surfels' inputs are read from HBM once), and the lanes run binning + composite only. */
-/* Lanes of the multi-view calls from now on (1..8; the only process-wide setting of the library, initialised from
- * LARA2DGS_VIEW_STREAMS, default 2).  Two lanes pay when ONE stream feeds the device; an application that already
- * issues from two streams (one per scene) is better off with 1 (measured: training step 762 -> 786 frames/s).
- * Returns the previous value. */
-int lara2dgs_set_view_lanes(int32_t lanes);
-/* Forward composite: cut tile lists longer than 2048 entries into (at most 8) depth segments composited by different
- * workgroups (a transmittance prepass gives every segment its starting T, M1, M2, so the 1e-4 stop, the median and the
- * contributor records keep the reference's sequential semantics; images equal to rounding).  Off by default -- at LaRa's
- * statistics it measured slower than one workgroup per tile --, initialised from LARA2DGS_FWD_SPLIT.
- * Process-wide like the lane count.  Returns the previous value. */
-int lara2dgs_set_forward_split(int32_t on);
-/* Multi-view calls with a scratch buffer per view: run binning and composite of ALL views as one launch per kernel on the
- * caller's stream (workgroup z index = view; the views' buffers sit at a constant stride), instead of one launch per view and
- * kernel dealt to the lanes.  On by default (LARA2DGS_VIEWS_BATCH_KERNELS=0 turns it off); same results bit for bit.  Returns
- * the previous value. */
-int lara2dgs_set_views_batch_kernels(int32_t on);
+ * 256-byte multiple) -- per-camera state carved from one allocation; `scratch` holds n_views transient buffers of
+ * scratch_stride bytes each (>= lara2dgs_scratch_bytes).  Every kernel of the call is ONE launch over the cameras on `stream`
+ * (workgroup z index = view, chunks of 8): the surfels' inputs are read from HBM once for the n cameras, and one view's tail
+ * of long tile lists is filled by the next view's workgroups.  Per-view results are the per-view call's, bit for bit. */
 int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                            const float *shs, const float *colors_precomp, const float *opacities,
                            const float *scales, const float *rotations, const float *transmat_precomp,
                            float *out_color, float *out_allmap, int32_t *out_radii, void *state,
-                           int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
-                           void *stream);
+                           int64_t state_stride, void *scratch, int64_t scratch_stride, void *stream);
 
 /* Offsets (in floats) of the gradient arrays inside one flat gradient buffer; -1 = absent. */
 typedef struct lara2dgs_grad_layout {
@@ -190,16 +172,14 @@ int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int3
 /* Backward of lara2dgs_forward_views: dL_dcolor [n,3,H,W], dL_dallmap [n,7,H,W], radii [n,P].  grad_out
  * ([layout.total] floats; every gradient array in it is fully overwritten) receives the gradients summed over the
  * views in view order -- the sum over a scene's views that autograd otherwise forms with n-1 accumulation kernels per
- * input, and bit-reproducible.  With n_scratch >= n_views the lanes run composite_bwd only and ONE per-surfel launch
- * folds the n views' contributions in registers (grad_tmp is not used and may be NULL).  With fewer scratch buffers
- * every view writes its gradients into its own slice of grad_tmp ([n_views][layout.total] floats, required) and one
- * kernel adds the slices in the same order: same bits either way. */
+ * input, and bit-reproducible: each view's per-pair gradient rows stay in its own scratch buffer and ONE per-surfel launch
+ * folds the n views' contributions in registers, in view order.  Writes to `state` like lara2dgs_backward. */
 int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                             const float *shs, const float *colors_precomp, const float *scales,
                             const float *rotations, const float *transmat_precomp, const int32_t *radii,
-                            const float *dL_dcolor, const float *dL_dallmap, const void *state,
-                            int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
-                            float *grad_tmp, float *grad_out, void *stream);
+                            const float *dL_dcolor, const float *dL_dallmap, void *state,
+                            int64_t state_stride, void *scratch, int64_t scratch_stride,
+                            float *grad_out, void *stream);
 
 /* Replaces `_C.mark_visible(means3D, viewmatrix, projmatrix)` (GaussianRasterizer.markVisible).
  * present: uint8 [P]. */

@@ -26,13 +26,9 @@
 extern "C" {
 #endif
 
-/* bytes of the caller-owned workspace for G groups */
+/* bytes of the caller-owned workspace for G groups (size it with THIS function: round 4 added 256 KB in front for the fused
+ * kernel's packed weight fragments) */
 int64_t lara_groupattn_workspace_bytes(int32_t G);
-
-/* How lara_groupattn_forward runs the step behind the K|V projection: 0 = four launches (LayerNorm + cast, Q projection,
- * attention, output projection + residual); 1 / 2 = ONE wave-private kernel (first / second cut).
- * Same results.  Initial value: LARA_GA_FUSED in the environment (default: see attention.hip).  Returns the previous mode. */
-int lara_groupattn_set_fused(int32_t mode);
 
 /* y[G,8,256] (fp32) = x + out_proj(attention(LN(x), cond)).  x fp32 [G,8,256];
  * cond_bf16 [G,4,cond_dim] bf16; ln_weight / ln_bias fp32 [256].  Returns 0 or LARA2DGS_E_*. */

@@ -44,15 +44,6 @@ L2dProfScope::~L2dProfScope() {
 
 namespace {
 
-// forward composite: cut lists beyond 2048 entries into depth segments (opt-in; composite.hip: launch_composite_fwd)
-int env_flag(const char *name, int dflt = 0) {
-    const char *e = getenv(name);
-    return e ? (atoi(e) != 0 ? 1 : 0) : dflt;
-}
-// multi-view calls: binning + composite of all views as one launch per kernel (default) instead of per view on the lanes
-std::atomic<int> g_batch_kernels{env_flag("LARA2DGS_VIEWS_BATCH_KERNELS", 1)};
-std::atomic<int> g_fwd_split{env_flag("LARA2DGS_FWD_SPLIT")};
-
 bool make_view(const lara2dgs_view *view, ViewDev &v) {
     if (!view) return false;
     if (view->P < 0 || view->image_height <= 0 || view->image_width <= 0) return false;
@@ -73,7 +64,7 @@ bool make_view(const lara2dgs_view *view, ViewDev &v) {
     v.cap = (unsigned)view->capacity;
     {
         static const unsigned dbg = getenv("LARA2DGS_DEBUG_FLAGS") ? (unsigned)strtoul(getenv("LARA2DGS_DEBUG_FLAGS"), nullptr, 0) : 0u;
-        v.dbg = (dbg & ~128u) | (g_fwd_split.load() ? 128u : 0u);
+        v.dbg = dbg;
     }
     v.bg = view->bg;
     v.viewmatrix = view->viewmatrix;
@@ -117,7 +108,6 @@ ScratchView carve_scratch(const ViewDev &v, void *scratch, ScratchLayout &L) {
     s.sub_start = (uint32_t *)(b + L.sub_start);
     s.sort_parts = (uint32_t *)(b + L.sort_parts);
     s.sort_items = (uint2 *)(b + L.sort_items);
-    s.fwd_slabs = (void *)(b + L.fwd_slabs);
     s.rect = (uint4 *)(b + L.rect);
     s.keys = (uint64_t *)(b + L.keys);
     s.block_tot = (uint32_t *)(b + L.block_tot);
@@ -198,7 +188,7 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
 int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const float *shs,
                       const float *colors_precomp, const float *scales, const float *rotations,
                       const float *transmat_precomp, const int32_t *radii, const float *dL_dcolor,
-                      const float *dL_dallmap, const void *state, void *scratch,
+                      const float *dL_dallmap, void *state, void *scratch,
                       float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs, float *dL_dcolors,
                       float *dL_dopacities, float *dL_dscales, float *dL_drotations,
                       float *dL_dtransmat, void *stream) {
@@ -215,7 +205,7 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
     if (has_sr && (!dL_dscales || !dL_drotations)) return LARA2DGS_E_INVALID;
     if (transmat_precomp && !dL_dtransmat) return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    StateView st = carve_state(v, const_cast<void *>(state));
+    StateView st = carve_state(v, state);
     ScratchLayout SL;
     ScratchView sc = carve_scratch(v, scratch, SL);
     // one launch: the validity bitmap zeroed + the work items ordered dearest first (by what they cost the forward)
@@ -270,44 +260,8 @@ int lara2dgs_profile_collect(char *names, int names_len, float *ms, int max_entr
 
 }  // extern "C"
 
-// ---- multi-view calls: a per-thread pool of side streams, forked from / joined into the caller's stream ----------
+// ---- multi-view calls ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int MAX_SIDE = 8;
-// Lane 0 of a multi-view call is the caller's stream itself; lanes 1.. are side streams that belong to that caller
-// stream (process-wide map: PyTorch replays the backward on its autograd thread, on the forward's stream -- both
-// directions share the lanes, and two caller streams never funnel into the same side stream).
-struct SidePool {
-    int n = 0;   // side streams created so far
-    hipStream_t s[MAX_SIDE];
-    hipEvent_t fork = nullptr, join[MAX_SIDE];
-};
-std::mutex g_side_mu;
-std::map<std::pair<int, hipStream_t>, SidePool> g_side;
-
-// lanes of a multi-view call (>= 1): LARA2DGS_VIEW_STREAMS at load (default 2), lara2dgs_set_view_lanes at run time
-std::atomic<int> g_lanes{[] {
-    const char *e = getenv("LARA2DGS_VIEW_STREAMS");
-    const int k = e ? atoi(e) : 2;
-    return k < 1 ? 1 : (k > MAX_SIDE ? MAX_SIDE : k);
-}()};
-
-// the side streams of `caller` on the current device (created on first use, grown on demand, kept for the life of
-// the process); the returned copy holds at least lanes - 1 of them
-bool side_pool(hipStream_t caller, int lanes, SidePool *out) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    SidePool &p = g_side[{dev, caller}];
-    if (!p.fork && hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return false;
-    while (p.n < lanes - 1) {
-        if (hipStreamCreateWithFlags(&p.s[p.n], hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&p.join[p.n], hipEventDisableTiming) != hipSuccess) return false;
-        p.n++;
-    }
-    *out = p;
-    return true;
-}
-
 #define HIP_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { l2d_set_hip_error(e__); return LARA2DGS_E_LAUNCH; } } while (0)
 
 bool views_agree(int n, const lara2dgs_view *views) {
@@ -315,7 +269,7 @@ bool views_agree(int n, const lara2dgs_view *views) {
         const lara2dgs_view &a = views[0], &b = views[i];
         if (a.P != b.P || a.sh_degree != b.sh_degree || a.sh_coeffs != b.sh_coeffs || a.image_height != b.image_height ||
             a.image_width != b.image_width || a.capacity != b.capacity || a.prefiltered != b.prefiltered ||
-            a.scale_modifier != b.scale_modifier || a.debug != b.debug) return false;   // (the batched preprocess runs all cameras with views[0]'s scalars)
+            a.scale_modifier != b.scale_modifier || a.debug != b.debug) return false;   // (the batched kernels run all cameras with views[0]'s scalars)
     }
     return true;
 }
@@ -348,30 +302,14 @@ inline void zero_strided(void *base, int64_t stride, int64_t bytes, int n_views,
     hipLaunchKernelGGL(zero_strided_kernel, dim3(gx ? gx : 1, (unsigned)n_views), dim3(256), 0, s, (char *)base, stride, (bytes + 15) / 16 * 16);
 }
 
-// out[i] = sum over the n slices of tmp, slice order fixed (bit-reproducible); float4 lanes
-__global__ void __launch_bounds__(256) sum_slices_kernel(const float4 *__restrict__ tmp, float4 *__restrict__ out,
-                                                         int64_t n4, int64_t stride4, int n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 a = tmp[i];
-        for (int k = 1; k < n; k++) {
-            const float4 b = tmp[i + k * stride4];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-        out[i] = a;
-    }
+bool strides_ok(const lara2dgs_view &v0, int64_t state_stride, int64_t scratch_stride) {
+    return state_stride % 256 == 0 && scratch_stride % 256 == 0 &&
+           state_stride >= lara2dgs_state_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity) &&
+           scratch_stride >= lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity);
 }
 }  // namespace
 
 extern "C" {
-
-int lara2dgs_set_forward_split(int32_t on) { return g_fwd_split.exchange(on != 0); }
-
-int lara2dgs_set_views_batch_kernels(int32_t on) { return g_batch_kernels.exchange(on != 0); }
-
-int lara2dgs_set_view_lanes(int32_t lanes) {
-    const int k = lanes < 1 ? 1 : (lanes > MAX_SIDE ? MAX_SIDE : lanes);
-    return g_lanes.exchange(k);
-}
 
 int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int32_t has_colors,
                              int32_t has_scale_rot, int32_t has_transmat, lara2dgs_grad_layout *out) {
@@ -380,92 +318,58 @@ int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int3
     return LARA2DGS_OK;
 }
 
+// Every kernel of a multi-view call is ONE launch over the cameras on the caller's stream (workgroup z index = view; chunks of
+// L2D_MAX_VIEWS): the surfels' inputs come from HBM once for the n cameras, and one view's tail of long tile lists is filled by
+// the next view's workgroups.  (Rounds 2-4 also kept a per-view path dealt to side streams -- "lanes" -- with two process-wide
+// setters; it measured slower in every configuration once the kernels were batched and is gone: the library keeps no settings.)
 int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                            const float *shs, const float *colors_precomp, const float *opacities,
                            const float *scales, const float *rotations, const float *transmat_precomp,
                            float *out_color, float *out_allmap, int32_t *out_radii, void *state,
-                           int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
-                           void *stream) {
-    if (n_views <= 0 || !views || n_scratch <= 0 || !state || !scratch) return LARA2DGS_E_INVALID;
+                           int64_t state_stride, void *scratch, int64_t scratch_stride, void *stream) {
+    if (n_views <= 0 || !views || !state || !scratch) return LARA2DGS_E_INVALID;
     if (!views_agree(n_views, views)) return LARA2DGS_E_INVALID;
     const lara2dgs_view &v0 = views[0];
-    if (state_stride % 256 || scratch_stride % 256 ||
-        state_stride < lara2dgs_state_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity) ||
-        scratch_stride < lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity))
-        return LARA2DGS_E_INVALID;
+    if (!strides_ok(v0, state_stride, scratch_stride)) return LARA2DGS_E_INVALID;
     hipStream_t caller = (hipStream_t)stream;
-    int lanes = g_lanes.load();
-    if (lanes > n_views) lanes = n_views;
-    if (lanes > n_scratch) lanes = n_scratch;
-    SidePool pool_, *pool = &pool_;
-    if (!side_pool(caller, lanes, pool)) return LARA2DGS_E_LAUNCH;
-    auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
     const int64_t HW = (int64_t)v0.image_height * v0.image_width;
-    int rc = LARA2DGS_OK;
-    // With a scratch buffer per view the preprocess of ALL cameras is one launch on the caller's stream (the surfels'
-    // inputs are read from HBM once for the n cameras); the lanes then only run binning + composite of their views.
-    const bool batched = n_scratch >= n_views && v0.P > 0;
-    if (batched) {
-        if (!out_color || !out_allmap || !means3D || !opacities || !out_radii) return LARA2DGS_E_INVALID;
-        if ((shs == nullptr) == (colors_precomp == nullptr)) return LARA2DGS_E_INVALID;
-        if ((scales && rotations) == (transmat_precomp != nullptr)) return LARA2DGS_E_INVALID;
-        std::vector<ViewDev> vd(n_views);
-        std::vector<StateView> st(n_views);
-        std::vector<ScratchView> sc(n_views);
-        std::vector<int32_t *> rad(n_views);
-        for (int i = 0; i < n_views; i++) {
-            if (!make_view(&views[i], vd[i])) return LARA2DGS_E_INVALID;
-            if (shs && vd[i].M < (vd[i].deg + 1) * (vd[i].deg + 1)) return LARA2DGS_E_INVALID;
-            st[i] = carve_state(vd[i], (char *)state + i * state_stride);
-            ScratchLayout SL;
-            sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL);
-            rad[i] = out_radii + (int64_t)i * v0.P;
-            if (i == 0)   // the views agree in (P, H, W, capacity): one layout, one strided fill for all of them
-                zero_strided(sc[0].tile_count, scratch_stride, SL.sub_start - SL.tile_count, n_views, caller);
-        }
-        for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
-            const int nb = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
-            rc = launch_preprocess_fwd_views(vd[i0], nb, &vd[i0], means3D, shs, colors_precomp, opacities, scales, rotations,
-                                             transmat_precomp, &st[i0], &sc[i0], &rad[i0], caller);
-        }
-        if (rc != LARA2DGS_OK) return rc;
-        if (g_batch_kernels.load()) {
-            // binning and composite of ALL views as one launch per kernel on the caller's stream (blockIdx.z = view): one
-            // kernel's tail of long lists is filled by the next view's workgroups, and 4 launches replace 4 per view
-            for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
-                ViewBatch vb{};
-                vb.n = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
-                vb.state_stride = state_stride; vb.scratch_stride = scratch_stride;
-                for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
-                rc = launch_binning(vd[i0], st[i0], sc[i0], caller, &vb);
-                if (rc == LARA2DGS_OK)
-                    rc = launch_composite_fwd(vd[i0], st[i0], sc[i0], out_color + (int64_t)i0 * 3 * HW, out_allmap + (int64_t)i0 * 7 * HW,
-                                              caller, &vb);
-            }
-            return rc;
-        }
-        if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
-        for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
-        for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
-            hipStream_t s = lane_stream(i % lanes);
-            rc = launch_binning(vd[i], st[i], sc[i], s);
-            if (rc == LARA2DGS_OK) rc = launch_composite_fwd(vd[i], st[i], sc[i], out_color + i * 3 * HW, out_allmap + i * 7 * HW, s);
-        }
-    } else {
-        if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
-        for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
-        for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
-            const int k = i % lanes;  // views on one lane are serialised: they share that lane's scratch
+    if (v0.P == 0) {    // nothing to bin: every view is its background (the per-view entry point knows how)
+        int rc = LARA2DGS_OK;
+        for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++)
             rc = lara2dgs_forward(&views[i], means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp,
-                                  out_color + i * 3 * HW, out_allmap + i * 7 * HW,
-                                  out_radii ? out_radii + (int64_t)i * v0.P : nullptr,
-                                  (char *)state + i * state_stride, (char *)scratch + k * scratch_stride, lane_stream(k));
-        }
+                                  out_color + i * 3 * HW, out_allmap + i * 7 * HW, out_radii,
+                                  (char *)state + i * state_stride, (char *)scratch + i * scratch_stride, stream);
+        return rc;
     }
-    // always join, also after a failure: the caller's stream must not run ahead of what was enqueued
-    for (int k = 1; k < lanes; k++) {
-        HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
-        HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
+    if (!out_color || !out_allmap || !means3D || !opacities || !out_radii) return LARA2DGS_E_INVALID;
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return LARA2DGS_E_INVALID;
+    if ((scales && rotations) == (transmat_precomp != nullptr)) return LARA2DGS_E_INVALID;
+    std::vector<ViewDev> vd(n_views);
+    std::vector<StateView> st(n_views);
+    std::vector<ScratchView> sc(n_views);
+    std::vector<int32_t *> rad(n_views);
+    for (int i = 0; i < n_views; i++) {
+        if (!make_view(&views[i], vd[i])) return LARA2DGS_E_INVALID;
+        if (shs && vd[i].M < (vd[i].deg + 1) * (vd[i].deg + 1)) return LARA2DGS_E_INVALID;
+        st[i] = carve_state(vd[i], (char *)state + i * state_stride);
+        ScratchLayout SL;
+        sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL);
+        rad[i] = out_radii + (int64_t)i * v0.P;
+        if (i == 0)   // the views agree in (P, H, W, capacity): one layout, one strided fill for all of them
+            zero_strided(sc[0].tile_count, scratch_stride, SL.sub_start - SL.tile_count, n_views, caller);
+    }
+    int rc = LARA2DGS_OK;
+    for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
+        ViewBatch vb{};
+        vb.n = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
+        vb.state_stride = state_stride; vb.scratch_stride = scratch_stride;
+        for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
+        rc = launch_preprocess_fwd_views(vd[i0], vb.n, &vd[i0], means3D, shs, colors_precomp, opacities, scales, rotations,
+                                         transmat_precomp, &st[i0], &sc[i0], &rad[i0], caller);
+        if (rc == LARA2DGS_OK) rc = launch_binning(vd[i0], st[i0], sc[i0], caller, &vb);
+        if (rc == LARA2DGS_OK)
+            rc = launch_composite_fwd(vd[i0], st[i0], sc[i0], out_color + (int64_t)i0 * 3 * HW, out_allmap + (int64_t)i0 * 7 * HW,
+                                      caller, &vb);
     }
     return rc;
 }
@@ -473,16 +377,13 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
 int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                             const float *shs, const float *colors_precomp, const float *scales,
                             const float *rotations, const float *transmat_precomp, const int32_t *radii,
-                            const float *dL_dcolor, const float *dL_dallmap, const void *state,
-                            int64_t state_stride, void *scratch, int64_t scratch_stride, int32_t n_scratch,
-                            float *grad_tmp, float *grad_out, void *stream) {
-    if (n_views <= 0 || !views || n_scratch <= 0 || !state || !scratch || !grad_out) return LARA2DGS_E_INVALID;
+                            const float *dL_dcolor, const float *dL_dallmap, void *state,
+                            int64_t state_stride, void *scratch, int64_t scratch_stride,
+                            float *grad_out, void *stream) {
+    if (n_views <= 0 || !views || !state || !scratch || !grad_out) return LARA2DGS_E_INVALID;
     if (!views_agree(n_views, views)) return LARA2DGS_E_INVALID;
     const lara2dgs_view &v0 = views[0];
-    if (state_stride % 256 || scratch_stride % 256 ||
-        state_stride < lara2dgs_state_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity) ||
-        scratch_stride < lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity))
-        return LARA2DGS_E_INVALID;
+    if (!strides_ok(v0, state_stride, scratch_stride)) return LARA2DGS_E_INVALID;
     if (!dL_dcolor || !dL_dallmap) return LARA2DGS_E_INVALID;
     const bool has_sh = shs != nullptr, has_col = colors_precomp != nullptr, has_sr = scales && rotations,
                has_tm = transmat_precomp != nullptr;
@@ -490,94 +391,41 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
     grad_layout(v0.P, v0.sh_coeffs, has_sh, has_col, has_sr, has_tm, &G);
     hipStream_t caller = (hipStream_t)stream;
     if (v0.P == 0 || G.total == 0) return LARA2DGS_OK;
-    int lanes = g_lanes.load();
-    if (lanes > n_views) lanes = n_views;
-    if (lanes > n_scratch) lanes = n_scratch;
-    SidePool pool_, *pool = &pool_;
-    if (!side_pool(caller, lanes, pool)) return LARA2DGS_E_LAUNCH;
-    auto lane_stream = [&](int k) { return k == 0 ? caller : pool->s[k - 1]; };
     const int64_t HW = (int64_t)v0.image_height * v0.image_width;
     auto at = [&](float *base, int64_t off) { return off < 0 ? (float *)nullptr : base + off; };
+    if (!means3D || !radii) return LARA2DGS_E_INVALID;
+    if (has_sh == has_col || has_sr == has_tm) return LARA2DGS_E_INVALID;
+    std::vector<ViewDev> vd(n_views);
+    std::vector<StateView> st(n_views);
+    std::vector<ScratchView> sc(n_views);
+    std::vector<const int32_t *> rad(n_views);
+    std::vector<ScratchLayout> SL(n_views);
+    for (int i = 0; i < n_views; i++) {
+        if (!make_view(&views[i], vd[i])) return LARA2DGS_E_INVALID;
+        st[i] = carve_state(vd[i], (char *)state + i * state_stride);
+        sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL[i]);
+        rad[i] = radii + (int64_t)i * v0.P;
+    }
+    // Per chunk of views: the ordering of every view's work items (which also zero-fills the validity bitmaps), composite_bwd --
+    // each view's gradient rows stay in its own scratch buffer -- and ONE preprocess_bwd launch that walks every surfel through
+    // the views in view order and writes the summed gradients: no per-view gradient tensors, no summation pass.
     int rc = LARA2DGS_OK;
-    // With a scratch buffer per view the lanes only run composite_bwd (each view's gradient rows stay in its own
-    // scratch); after the join ONE preprocess_bwd launch walks every surfel through the n views and writes the summed
-    // gradients -- no per-view gradient tensors (grad_tmp is not touched), no summation pass.
-    const bool batched = n_scratch >= n_views;
-    if (batched) {
-        if (!means3D || !radii) return LARA2DGS_E_INVALID;
-        if (has_sh == has_col || has_sr == has_tm) return LARA2DGS_E_INVALID;
-        std::vector<ViewDev> vd(n_views);
-        std::vector<StateView> st(n_views);
-        std::vector<ScratchView> sc(n_views);
-        std::vector<const int32_t *> rad(n_views);
-        std::vector<ScratchLayout> SL(n_views);
-        for (int i = 0; i < n_views; i++) {
-            if (!make_view(&views[i], vd[i])) return LARA2DGS_E_INVALID;
-            st[i] = carve_state(vd[i], (char *)const_cast<void *>(state) + i * state_stride);
-            sc[i] = carve_scratch(vd[i], (char *)scratch + i * scratch_stride, SL[i]);
-            rad[i] = radii + (int64_t)i * v0.P;
-        }
-        // validity bitmaps of all views + the ordering of every view's work items: one launch per chunk of views on the caller's
-        // stream, in front of the fork
-        if (g_batch_kernels.load()) {
-            for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
-                ViewBatch vb{};
-                vb.n = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
-                vb.state_stride = state_stride; vb.scratch_stride = scratch_stride;
-                for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
-                rc = launch_bwd_order(vd[i0], st[i0], sc[i0], caller, &vb, sc[i0].pair_valid, SL[i0].total - SL[i0].pair_valid);
-                if (rc == LARA2DGS_OK)
-                    rc = launch_composite_bwd(vd[i0], st[i0], sc[i0], dL_dcolor + (int64_t)i0 * 3 * HW, dL_dallmap + (int64_t)i0 * 7 * HW, caller, &vb);
-            }
-        } else {
-            if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
-            for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
-            for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
-                hipStream_t s = lane_stream(i % lanes);
-                rc = launch_bwd_order(vd[i], st[i], sc[i], s, nullptr, sc[i].pair_valid, SL[i].total - SL[i].pair_valid);
-                if (rc == LARA2DGS_OK) rc = launch_composite_bwd(vd[i], st[i], sc[i], dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW, s);
-            }
-            for (int k = 1; k < lanes; k++) {
-                HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
-                HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
-            }
-        }
-        for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
-            const int nb = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
-            rc = launch_preprocess_bwd_views(vd[i0], nb, &vd[i0], i0 > 0, means3D, shs, colors_precomp, scales, rotations,
+    for (int i0 = 0; i0 < n_views && rc == LARA2DGS_OK; i0 += L2D_MAX_VIEWS) {
+        ViewBatch vb{};
+        vb.n = n_views - i0 < L2D_MAX_VIEWS ? n_views - i0 : L2D_MAX_VIEWS;
+        vb.state_stride = state_stride; vb.scratch_stride = scratch_stride;
+        for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
+        rc = launch_bwd_order(vd[i0], st[i0], sc[i0], caller, &vb, sc[i0].pair_valid, SL[i0].total - SL[i0].pair_valid);
+        if (rc == LARA2DGS_OK)
+            rc = launch_composite_bwd(vd[i0], st[i0], sc[i0], dL_dcolor + (int64_t)i0 * 3 * HW, dL_dallmap + (int64_t)i0 * 7 * HW, caller, &vb);
+        if (rc == LARA2DGS_OK)
+            rc = launch_preprocess_bwd_views(vd[i0], vb.n, &vd[i0], i0 > 0, means3D, shs, colors_precomp, scales, rotations,
                                              transmat_precomp, &rad[i0], &st[i0], &sc[i0], at(grad_out, G.means3D),
                                              at(grad_out, G.means2D), at(grad_out, G.shs), at(grad_out, G.colors),
                                              at(grad_out, G.opacities), at(grad_out, G.scales), at(grad_out, G.rotations),
                                              at(grad_out, G.transmat), caller);
-        }
-        return rc;
     }
-    if (!grad_tmp) return LARA2DGS_E_INVALID;
-    if (lanes > 1) HIP_TRY(hipEventRecord(pool->fork, caller));
-    for (int k = 1; k < lanes; k++) HIP_TRY(hipStreamWaitEvent(pool->s[k - 1], pool->fork, 0));
-    for (int i = 0; i < n_views && rc == LARA2DGS_OK; i++) {
-        const int k = i % lanes;
-        float *g = grad_tmp + (int64_t)i * G.total;
-        rc = lara2dgs_backward(&views[i], means3D, shs, colors_precomp, scales, rotations, transmat_precomp,
-                               radii + (int64_t)i * v0.P, dL_dcolor + i * 3 * HW, dL_dallmap + i * 7 * HW,
-                               (const char *)state + i * state_stride, (char *)scratch + k * scratch_stride,
-                               at(g, G.means3D), at(g, G.means2D), at(g, G.shs), at(g, G.colors), at(g, G.opacities),
-                               at(g, G.scales), at(g, G.rotations), at(g, G.transmat), lane_stream(k));
-    }
-    for (int k = 1; k < lanes; k++) {
-        HIP_TRY(hipEventRecord(pool->join[k - 1], pool->s[k - 1]));
-        HIP_TRY(hipStreamWaitEvent(caller, pool->join[k - 1], 0));
-    }
-    if (rc != LARA2DGS_OK) return rc;
-    {
-        L2D_PROF("sum_view_grads", caller);
-        const int64_t n4 = G.total / 4;
-        const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(sum_slices_kernel, dim3(grid), dim3(256), 0, caller, (const float4 *)grad_tmp,
-                           (float4 *)grad_out, n4, G.total / 4, (int)n_views);
-    }
-    L2D_CHECK_LAUNCH();
-    return LARA2DGS_OK;
+    return rc;
 }
 
 }  // extern "C"

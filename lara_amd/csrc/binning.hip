@@ -218,13 +218,11 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         const uint32_t incl = carry_s + wave_off + x;
         if (i < v.tiles) {
             seg_base[i] = incl - nb;
-            // checkpoint rows are a fixed slab: a tile whose rows do not fit runs unsegmented
-            const bool fits = (int64_t)incl <= l2d_ckpt_slots((int64_t)v.cap);
-            const uint32_t used = fits ? nb : 0u;
-            seg_cnt[i] = used;
+            // (the checkpoint slab holds cap / L2D_SEG + 1 rows: every boundary of a frame that fits the capacity has one)
+            seg_cnt[i] = nb;
             if (!overflow)
-                for (uint32_t q = 0; q < nb; q++) bwd_items[incl - nb + q] = make_uint2(fits ? (uint32_t)i : ~0u, q);
-            const uint32_t pl = len - used * L2D_SEG;  // length of the last segment
+                for (uint32_t q = 0; q < nb; q++) bwd_items[incl - nb + q] = make_uint2((uint32_t)i, q);
+            const uint32_t pl = len - nb * L2D_SEG;  // length of the last segment
             atomicAdd(&bcnt[63u - (uint32_t)(((uint64_t)min(pl, (uint32_t)L2D_SEG) * 64u) / (L2D_SEG + 1u))], 1u);
         }
         __syncthreads();

@@ -60,7 +60,7 @@ struct StateView {  // typed pointers into the caller's `state` buffer
     float *final_T;       // [L2D_CKPT_F][HW] end-of-walk T, M1, M2, C(3), D, N(3)
     uint32_t *n_contrib;  // [2][HW]
     uint32_t *seg_base;   // [tiles+1] exclusive scan of interior segment boundaries per tile
-    uint32_t *seg_cnt;    // [tiles] interior boundaries actually used (0 when the checkpoint slab is full)
+    uint32_t *seg_cnt;    // [tiles] interior segment boundaries of the tile's list = (len - 1) / L2D_SEG
     uint32_t *bwd_order;  // [tiles] tile ids by length of their last (partial) segment, longest first
     uint2 *bwd_items;     // [cap/L2D_SEG+1 + tiles] (tile, segment) of every full segment; once ordered (header[22]): of EVERY work item
     float *ckpt;          // [cap/L2D_SEG+1][L2D_CKPT_F][256] per-pixel prefix sums at segment boundaries
@@ -80,14 +80,15 @@ struct ScratchView {
     uint32_t *block_tot;   // [ceil(P/256)] pairs per surfel block, then (in place) their exclusive scan
     float4 *pair_grad;     // [cap][5] backward: per (tile, surfel) gradient rows, surfel-major (aliases the forward region)
     uint32_t *pair_valid;  // [cap] bytes, backward: byte q != 0 <=> gradient row q (surfel-major) was written
-    void *fwd_slabs;       // forward composite of split tiles: per (tile, segment) rows (aliases the region the sort is done with)
 };
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-// Checkpoint rows: half of the worst case cap / L2D_SEG.  Tiles whose boundaries do not fit (more pairs
-// than half the capacity: 8 per surfel by default) simply run their backward unsegmented.
-__host__ __device__ static inline int64_t l2d_ckpt_slots(int64_t cap) { return cap / (2 * L2D_SEG) + 1; }
+// Checkpoint rows: the worst case.  A tile of `len` entries has (len - 1) / L2D_SEG interior boundaries, so a frame of
+// D <= cap pairs never needs more than cap / L2D_SEG rows (round 5: the slab used to be half of that, and a frame beyond half
+// the capacity ran some tiles unsegmented; with the capacity following the measured pair count -- rasterizer.py -- frames
+// between cap / 2 and cap are the normal case, and 20 bytes per pair of capacity buy them the segmented backward).
+__host__ __device__ static inline int64_t l2d_ckpt_slots(int64_t cap) { return cap / L2D_SEG + 1; }
 
 static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state_layout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
@@ -115,7 +116,7 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->total = o;
 }
 
-struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, sort_parts, sort_items, rect, keys, block_tot, pair_grad, pair_valid, fwd_slabs, total; };
+struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, sort_parts, sort_items, rect, keys, block_tot, pair_grad, pair_valid, total; };
 static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     int64_t o = 0;
@@ -132,11 +133,7 @@ static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayou
     L->pair_grad = fwd0;  // backward reuses the forward-only region
     L->pair_valid = align_up(fwd0 + cap * GRAD_F * 4, 256);
     const int64_t bwd_end = align_up(L->pair_valid + cap + 256, 256);
-    // forward composite of split tiles (after the sort: rect / keys are dead): 18 rows of 256 floats per (tile, 512 entries)
-    L->fwd_slabs = fwd0;
-    const int64_t slab_end = align_up(fwd0 + (cap / L2D_SEG + tiles + 1) * 18 * 256 * 4, 256);
     L->total = fwd_end > bwd_end ? fwd_end : bwd_end;
-    if (slab_end > L->total) L->total = slab_end;
 }
 
 // ---- launchers (one per .hip translation unit) -------------------------------------------------

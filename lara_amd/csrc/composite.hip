@@ -261,44 +261,11 @@ struct FwdPixel {
         last_contributor = valid ? (uint32_t)(base + j + 1) : last_contributor;
     }
 
-    // transmittance prepass of a heavy tile's segment (see composite_fwd_kernel): only what a LATER segment needs to start
-    // from -- the segment's transmittance and its M1 / M2 sums, all relative to T = 1 at the segment's first entry; no
-    // termination here (a pixel that ends inside the segment makes every later segment start below 1e-4, i.e. finished)
-    __device__ __forceinline__ void blend_prepass(bool valid, const Hit &h) {
-        const float a = valid ? h.alpha : 0.f;
-        const float depth = valid ? h.depth : 1.0f;
-        const float w = a * T;
-        const float mm = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N * __builtin_amdgcn_rcpf(depth));
-        M1 += mm * w;
-        M2 += mm * mm * w;
-        T *= 1.0f - a;
-        done = done || T < 0.0001f;     // every later segment starts below 1e-4 whatever follows: nothing more to add up
-    }
 };
 
-// A tile whose list is longer than FWD_SPLIT is composited by several workgroups, one per depth segment, instead of one
-// (a single workgroup per tile makes the launch last as long as its longest list: 5.3 k entries against a mean of 1.5 k at
-// LaRa's init statistics).  Segments are cut on multiples of L2D_SEG; at most 8 per tile.
-constexpr int FWD_SPLIT = 2048;
-__device__ __forceinline__ int fwd_seg_len(const int total) {
-    const int n = (((total + 7) / 8 + L2D_SEG - 1) / L2D_SEG) * L2D_SEG;
-    return n < 2 * L2D_SEG ? 2 * L2D_SEG : n;
-}
-// per (tile, segment) scratch rows of 256 floats (thread = pixel): [0..2] prepass t, M1', M2'; [3..] the main pass' results
-constexpr int FSLAB_F = 18;
-enum { FS_T = 3, FS_M1, FS_M2, FS_C0, FS_C1, FS_C2, FS_DD, FS_N0, FS_N1, FS_N2, FS_DIST, FS_MEDD, FS_MEDC, FS_LAST, FS_DONE };
-__device__ __forceinline__ float *fwd_slab(float *slabs, const uint32_t *seg_base, const int tile, const int lo) {
-    return slabs + ((size_t)seg_base[tile] + (size_t)tile + (size_t)(lo / L2D_SEG)) * (FSLAB_F * 256);
-}
-
-// MODE 0: the whole list of a tile with at most FWD_SPLIT entries (one workgroup per tile; longer lists return at once).
-// MODE 1: transmittance prepass of segment blockIdx.y of a longer list: per pixel the product of (1 - alpha) and the M1 / M2
-//         sums over the segment, relative to T = 1 at its start -> slab rows 0..2.
-// MODE 2: the segment's real walk.  It starts from T, M1, M2 = the prefix of the EARLIER segments' prepass rows (so every
-//         decision that reads T -- the 1e-4 stop, the median -- is taken on the true transmittance, with the reference's
-//         sequential semantics), accumulates colour / normal / depth / distortion from zero and leaves them, with the
-//         contributor records, in slab rows FS_*; composite_fwd_combine_kernel adds the segments of a tile in order.
-template <int MODE>
+// One workgroup per tile walks the tile's whole list.  (Round 3 built a depth-segment split of the long lists -- transmittance
+// prepass, per-segment walks from the true prefix, a combine pass: exact, and 406 us against 254 at LaRa's statistics; DESIGN.md
+// section 3.2.  It shipped as an opt-in until round 5 and is gone: the tails are filled by the other views of a multi-view launch.)
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
@@ -307,8 +274,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                      const uint32_t *__restrict__ seg_base, const uint32_t *__restrict__ seg_cnt,
                      float *__restrict__ ckpt, uint2 *__restrict__ pair_mask, uint32_t *__restrict__ tile_maxc,
                      uint32_t *__restrict__ seg_cost,
-                     float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs,
-                     const ViewBatch vb) {
+                     float *__restrict__ out_color, float *__restrict__ out_allmap, const ViewBatch vb) {
     {   // this workgroup's view (blockIdx.z; a single-view launch has strides 0)
         const long long sst = vb.state_stride, HWb = (long long)v.H * v.W * 4;
         header = l2d_view_ptr(header, sst); ranges = l2d_view_ptr(ranges, sst); point_list = l2d_view_ptr(point_list, sst);
@@ -316,7 +282,6 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
         seg_cnt = l2d_view_ptr(seg_cnt, sst); ckpt = l2d_view_ptr(ckpt, sst); pair_mask = l2d_view_ptr(pair_mask, sst);
         tile_maxc = l2d_view_ptr(tile_maxc, sst); seg_cost = l2d_view_ptr(seg_cost, sst);
-        slabs = l2d_view_ptr(slabs, vb.scratch_stride);
         out_color = l2d_view_ptr(out_color, vb.n ? 3 * HWb : 0); out_allmap = l2d_view_ptr(out_allmap, vb.n ? 7 * HWb : 0);
         if (vb.n) v.bg = vb.bg[blockIdx.z];
     }
@@ -339,8 +304,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const float lx = (float)lxi, ly = (float)lyi;
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
 
-    if (header[1]) {  // binning capacity exceeded: make the failure loud in the data
-        if (MODE != 0) return;
+    if (header[1]) {  // binning capacity exceeded: make the failure loud in the data (the host repeats the call at the reported size)
         if (inside) {
             const float qnan = __uint_as_float(0x7fc00000u);
             for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = qnan;
@@ -353,27 +317,12 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
-    const bool split = total > FWD_SPLIT && (v.dbg & 128u);      // flag 128: lara2dgs_set_forward_split (opt-in, see launch_composite_fwd)
-    if ((MODE == 0) == split) return;
     // (tried in round 4: s_setprio for the waves of the long lists, so that a single-view launch -- which lasts as long as its
     // longest list, 5.3 k entries against a mean of 1.5 k -- gets that list done sooner.  No effect, 260.5 vs 261 us: the long
     // list's workgroup is not held back by its co-residents' issue slots but by its own per-round chain of gathers and barriers.)
-    const int segf = MODE == 0 ? total : fwd_seg_len(total);
-    const int lo = MODE == 0 ? 0 : (int)blockIdx.y * segf, hi = min(total, lo + segf);   // this workgroup's entries [lo, hi)
-    if (lo >= hi && MODE != 0) return;
+    const int lo = 0, hi = total;   // this workgroup's entries [lo, hi)
     FwdPixel px;
     px.done = !inside;
-    if (MODE == 2 && lo > 0) {      // the prefix of the earlier segments (at most 7 of them)
-        float T = 1.0f, M1 = 0.f, M2 = 0.f;
-        for (int l0 = 0; l0 < lo; l0 += segf) {
-            const float *sl = fwd_slab(slabs, seg_base, tile, l0) + threadIdx.x;
-            M1 += T * sl[256];
-            M2 += T * sl[512];
-            T *= sl[0];
-        }
-        px.T = T; px.M1 = M1; px.M2 = M2;
-        px.done = px.done || T < 0.0001f;        // the walk ended in an earlier segment (T never drops below 1e-4 otherwise)
-    }
     uint32_t *dbg_hdr = const_cast<uint32_t *>(header);
     const long long dbg_t0 = (v.dbg & 32u) ? (long long)__builtin_readcyclecounter() : 0ll;
     int dbg_rounds = 0;
@@ -382,11 +331,9 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     // cost: recorded per (tile, segment) -- full segments at seg_base[tile] + s, everything from the last (partial) segment on in
     // the tile's own slot -- and used by bwd_order_kernel to launch the backward's items dearest first.
     const int tid = threadIdx.x;
-    const uint32_t cost_nb = MODE == 0 ? seg_cnt[tile] : 0u;
+    const uint32_t cost_nb = seg_cnt[tile];
     uint32_t *const cost_full = seg_cost + seg_base[tile], *const cost_last = seg_cost + (v.cap / L2D_SEG + 1u) + tile;
-    if (MODE == 0) {
-        for (uint32_t q = tid; q <= cost_nb; q += 256) *(q < cost_nb ? cost_full + q : cost_last) = 0u;
-    }
+    for (uint32_t q = tid; q <= cost_nb; q += 256) *(q < cost_nb ? cost_full + q : cost_last) = 0u;
     int cost_round = -1;
     constexpr int SPT = CHUNK / 256;  // list entries staged per thread and round
     uint32_t id1[SPT], id2[SPT];
@@ -401,13 +348,13 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     for (int q = 0; q < SPT; q++) cb1[q] = lo + q * 256 + tid < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = lo; base < hi; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
-        if (MODE == 0 && tid == 0) {     // (between this barrier and the staging barrier no wave is in its walk)
+        if (tid == 0) {     // (between this barrier and the staging barrier no wave is in its walk)
             if (cost_round >= 0) { if ((uint32_t)cost_round < cost_nb) cost_full[cost_round] = s_cost; else *cost_last += s_cost; }
             s_cost = 0u;
         }
         cost_round = (base - lo) / CHUNK;
         dbg_rounds++;
-        if (MODE != 1 && base && base % L2D_SEG == 0 && !px.done && (uint32_t)(base / L2D_SEG) <= seg_cnt[tile]) {
+        if (base && base % L2D_SEG == 0 && !px.done) {
             // crossing a segment boundary: park the running sums over entries [0, base) so that the
             // backward can start a walk here (pixels that are done never read theirs)
             float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)(base / L2D_SEG - 1)) * (L2D_CKPT_F * 256) + tid;
@@ -424,7 +371,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             id2[q] = base + 2 * CHUNK + o < hi ? point_list[range.x + base + 2 * CHUNK + o] : 0u;
             cb1[q] = base + CHUNK + o < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
             stage_entry<CHUNK>(geom, id0, cb0, base + o < hi, X0, Y0, rec, nullptr, o,
-                               (MODE != 1 && base + o < hi) ? pair_mask + range.x + base + o : nullptr);
+                               base + o < hi ? pair_mask + range.x + base + o : nullptr);
         }
         __syncthreads();
         if (__ballot(!px.done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
@@ -479,13 +426,8 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 atomicAdd(&dbg_hdr[5], (unsigned)e0 + (unsigned)e1);
                 if (lane == 0) atomicAdd(&dbg_hdr[6], 1u);
             }
-            if (MODE == 1) {
-                px.blend_prepass(e0 && !px.done, h0);
-                px.blend_prepass(e1 && !px.done, h1);
-            } else {
-                px.blend<CHUNK>(rec, j0, base, e0, h0);
-                px.blend<CHUNK>(rec, j1, base, e1, h1);
-            }
+            px.blend<CHUNK>(rec, j0, base, e0, h0);
+            px.blend<CHUNK>(rec, j1, base, e1, h1);
             if (((__ballot(px.done) >> (lane & ~3)) & 0xfull) == 0xfull) { mm = 0ull; w = nw; n0 = false; n1 = false; }
         };
         uint32_t ntrips = 0;
@@ -497,25 +439,9 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             trip(rB0, rB1, jB0, jB1, hB0, hB1, rA0, rA1, jA0, jA1, hA0, hA1);
             ntrips++;
         }
-        if (MODE == 0 && lane == 0 && ntrips) atomicAdd(&s_cost, ntrips);
+        if (lane == 0 && ntrips) atomicAdd(&s_cost, ntrips);
     }
     const float T = px.T;
-    if (MODE == 1) {
-        float *sl = fwd_slab(slabs, seg_base, tile, lo) + threadIdx.x;
-        sl[0] = px.T; sl[256] = px.M1; sl[512] = px.M2;
-        return;
-    }
-    if (MODE == 2) {
-        float *sl = fwd_slab(slabs, seg_base, tile, lo) + threadIdx.x;
-        sl[FS_T * 256] = px.T; sl[FS_M1 * 256] = px.M1; sl[FS_M2 * 256] = px.M2;
-        sl[FS_C0 * 256] = px.C0; sl[FS_C1 * 256] = px.C1; sl[FS_C2 * 256] = px.C2;
-        sl[FS_DD * 256] = px.Dd; sl[FS_N0 * 256] = px.N0; sl[FS_N1 * 256] = px.N1; sl[FS_N2 * 256] = px.N2;
-        sl[FS_DIST * 256] = px.distortion; sl[FS_MEDD * 256] = px.median_depth;
-        sl[FS_MEDC * 256] = __uint_as_float(px.median_contributor); sl[FS_LAST * 256] = __uint_as_float(px.last_contributor);
-        sl[FS_DONE * 256] = px.done ? 1.0f : 0.f;
-        return;
-    }
-
     {   // the backward's work items of this tile end at the deepest contributor of any of its pixels: one word per tile
         if (threadIdx.x == 0) s_tmax = 0u;
         __syncthreads();
@@ -553,85 +479,6 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             out_allmap[5 * HW + pix] = (float)dbg_rounds;
         }
     }
-}
-
-// Adds the depth segments of a split tile in list order (thread = pixel): colour, normal, depth and distortion sums add up --
-// every segment blended with the true T, M1 and M2 --, the transmittance and the M sums are the last live segment's, the
-// contributor records the last segment's that has one; a pixel whose walk ended in segment s ignores the later ones.  The
-// checkpoint rows a segment parked hold its C / Dd / N sums from the SEGMENT's start: the earlier segments' totals are added
-// here, so that the backward finds the same absolute prefix sums as after a single-workgroup walk.
-__global__ void __launch_bounds__(256)
-composite_fwd_combine_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
-                             const uint32_t *__restrict__ tile_order, float *__restrict__ final_T,
-                             uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ seg_base,
-                             const uint32_t *__restrict__ seg_cnt, float *__restrict__ ckpt, uint32_t *__restrict__ tile_maxc,
-                             float *__restrict__ out_color, float *__restrict__ out_allmap, float *__restrict__ slabs, const ViewBatch vb) {
-    {
-        const long long sst = vb.state_stride, HWb = (long long)v.H * v.W * 4;
-        tile_maxc = l2d_view_ptr(tile_maxc, sst);
-        header = l2d_view_ptr(header, sst); ranges = l2d_view_ptr(ranges, sst); tile_order = l2d_view_ptr(tile_order, sst);
-        final_T = l2d_view_ptr(final_T, sst); n_contrib = l2d_view_ptr(n_contrib, sst); seg_base = l2d_view_ptr(seg_base, sst);
-        seg_cnt = l2d_view_ptr(seg_cnt, sst); ckpt = l2d_view_ptr(ckpt, sst); slabs = l2d_view_ptr(slabs, vb.scratch_stride);
-        out_color = l2d_view_ptr(out_color, vb.n ? 3 * HWb : 0); out_allmap = l2d_view_ptr(out_allmap, vb.n ? 7 * HWb : 0);
-        if (vb.n) v.bg = vb.bg[blockIdx.z];
-    }
-    if (header[1]) return;
-    const int tile = (int)tile_order[blockIdx.x];
-    const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    if (total <= FWD_SPLIT || !(v.dbg & 128u)) return;
-    const int tx = tile % v.gx, ty = tile / v.gx;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 2;
-    const int lxi = (wave & 1) * 8 + (grp & 3) * 2 + (lane & 1), lyi = (wave >> 1) * 8 + (grp >> 2) * 2 + ((lane >> 1) & 1);
-    const int pxi = tx * TILE + lxi, pyi = ty * TILE + lyi;
-    const bool inside = pxi < v.W && pyi < v.H;
-    const size_t HW = (size_t)v.H * v.W, pix = (size_t)pyi * v.W + pxi;
-    const int segf = fwd_seg_len(total);
-    float T = 1.0f, M1 = 0.f, M2 = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, dist = 0.f, medd = 0.f;
-    uint32_t medc = 0, last = 0;
-    bool done = false;
-    for (int lo = 0; lo < total; lo += segf) {
-        const float *sl = fwd_slab(slabs, seg_base, tile, lo) + threadIdx.x;
-        if (lo > 0 && !done) {       // this segment's checkpoint rows: + the prefix of the segments in front of it
-            const int hi = min(total, lo + segf);
-            for (int b = lo; b < hi; b += L2D_SEG) {
-                if ((uint32_t)(b / L2D_SEG) > seg_cnt[tile]) break;
-                float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)(b / L2D_SEG - 1)) * (L2D_CKPT_F * 256) + threadIdx.x;
-                ck[3 * 256] += C0; ck[4 * 256] += C1; ck[5 * 256] += C2; ck[6 * 256] += Dd;
-                ck[7 * 256] += N0; ck[8 * 256] += N1; ck[9 * 256] += N2;
-            }
-        }
-        if (done) continue;
-        T = sl[FS_T * 256]; M1 = sl[FS_M1 * 256]; M2 = sl[FS_M2 * 256];
-        C0 += sl[FS_C0 * 256]; C1 += sl[FS_C1 * 256]; C2 += sl[FS_C2 * 256];
-        Dd += sl[FS_DD * 256]; N0 += sl[FS_N0 * 256]; N1 += sl[FS_N1 * 256]; N2 += sl[FS_N2 * 256];
-        dist += sl[FS_DIST * 256];
-        const uint32_t mc = __float_as_uint(sl[FS_MEDC * 256]), lc = __float_as_uint(sl[FS_LAST * 256]);
-        if (mc) { medc = mc; medd = sl[FS_MEDD * 256]; }
-        if (lc) last = lc;
-        done = sl[FS_DONE * 256] != 0.f;
-    }
-    {
-        __shared__ uint32_t s_tmax;
-        if (threadIdx.x == 0) s_tmax = 0u;
-        __syncthreads();
-        atomicMax(&s_tmax, last);
-        __syncthreads();
-        if (threadIdx.x == 0) tile_maxc[tile] = s_tmax;
-    }
-    if (!inside) return;
-    final_T[pix] = T; final_T[pix + HW] = M1; final_T[pix + 2 * HW] = M2;
-    final_T[pix + 3 * HW] = C0; final_T[pix + 4 * HW] = C1; final_T[pix + 5 * HW] = C2;
-    final_T[pix + 6 * HW] = Dd; final_T[pix + 7 * HW] = N0; final_T[pix + 8 * HW] = N1; final_T[pix + 9 * HW] = N2;
-    n_contrib[pix] = last; n_contrib[pix + HW] = medc;
-    out_color[0 * HW + pix] = C0 + T * v.bg[0];
-    out_color[1 * HW + pix] = C1 + T * v.bg[1];
-    out_color[2 * HW + pix] = C2 + T * v.bg[2];
-    out_allmap[0 * HW + pix] = Dd;
-    out_allmap[1 * HW + pix] = 1.0f - T;
-    out_allmap[2 * HW + pix] = N0; out_allmap[3 * HW + pix] = N1; out_allmap[4 * HW + pix] = N2;
-    out_allmap[5 * HW + pix] = medd;
-    out_allmap[6 * HW + pix] = dist;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -786,11 +633,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     if (header[22]) {       // the ordered union of all work items (bwd_order_kernel)
         if (blockIdx.x >= n_full + (uint32_t)v.tiles) return;
         const uint2 it = bwd_items[blockIdx.x];
-        if (it.x == ~0u) return;
         tile = (int)it.x; seg = (int)it.y;
     } else if (blockIdx.x < n_full) {
         const uint2 it = bwd_items[blockIdx.x];
-        if (it.x == ~0u) return;  // a segment of a tile that runs unsegmented (checkpoint slab full)
         tile = (int)it.x; seg = (int)it.y;
     } else if (blockIdx.x - n_full < (uint32_t)v.tiles) {
         tile = (int)bwd_order[blockIdx.x - n_full];
@@ -801,7 +646,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     // The tile only needs entries [0, max over its pixels of last_contributor): the forward left that maximum in tile_maxc, so a
     // work item beyond it (most of them once surfaces are opaque) leaves here, before any per-pixel load or barrier.
     const uint2 range = ranges[tile];
-    const int seg_lo = seg * L2D_SEG;      // the last segment runs to the end of the list (all of it for a tile that is not segmented)
+    const int seg_lo = seg * L2D_SEG;      // the last segment runs to the end of the list
     const int seg_hi = seg == (int)seg_cnt[tile] ? (int)(range.y - range.x) : seg_lo + L2D_SEG;
     const int total = min((int)tile_maxc[tile], seg_hi);
     const int lo = seg_lo;
@@ -1217,7 +1062,7 @@ selftest_butterfly_kernel(const float *__restrict__ in, float *__restrict__ out)
 // into registers before the first is written back, so bwd_items is permuted (and extended by the last segments) in place: one
 // global round trip, two barriers.  header[22] marks the list as the ordered union (composite_bwd then maps blockIdx.x through it
 // alone; a second backward over the same state skips the pass).
-// The same launch zero-fills the backward's validity bitmap (workgroups 2..): it replaces the memset launch that stood in front of
+// The same launch zero-fills the backward's validity bitmap (workgroups 1..): it replaces the memset launch that stood in front of
 // composite_bwd, so the ordering costs no launch.
 constexpr int BO_PER_THREAD = 17;     // items per thread: more than 17 408 work items stay in tile_scan's order
 __global__ void __launch_bounds__(1024)
@@ -1234,7 +1079,7 @@ bwd_order_kernel(ViewDev v, uint32_t *__restrict__ header, uint2 *__restrict__ b
     header = l2d_view_ptr(header, sst); bwd_items = l2d_view_ptr(bwd_items, sst); seg_cnt = l2d_view_ptr(seg_cnt, sst);
     seg_cost = l2d_view_ptr(seg_cost, sst);
     __shared__ uint32_t bcnt[64];
-    if (header[1] || (v.dbg & (128u | 256u))) return;      // (overflow; the opt-in forward split records no costs; 256: A/B runs)
+    if (header[1] || (v.dbg & 256u)) return;      // (overflow; 256: A/B runs that keep tile_scan's order)
     const int tid = threadIdx.x, lane = tid & 63;
     if (header[22]) return;                        // already ordered (the costs are indexed by the ORIGINAL positions)
     // the work items: the full segments as tile_scan listed them, then every tile's last segment (tile, seg_cnt[tile])
@@ -1251,7 +1096,7 @@ bwd_order_kernel(ViewDev v, uint32_t *__restrict__ header, uint2 *__restrict__ b
         bkt[k] = 64u;
         if (i < n) {
             uint32_t c;
-            if (i < n_full) { item[k] = bwd_items[i]; c = item[k].x == ~0u ? 0u : seg_cost[i]; }
+            if (i < n_full) { item[k] = bwd_items[i]; c = seg_cost[i]; }
             else { const uint32_t t = i - n_full; item[k] = make_uint2(t, seg_cnt[t]); c = cost_last[t]; }
             bkt[k] = 63u - min(63u, c >> 2);
             atomicAdd(&bcnt[bkt[k]], 1u);
@@ -1279,31 +1124,16 @@ bwd_order_kernel(ViewDev v, uint32_t *__restrict__ header, uint2 *__restrict__ b
 
 int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
                          hipStream_t s, const ViewBatch *vbp) {
-    float *slabs = (float *)sc.fwd_slabs;
+    (void)sc;
     ViewBatch vb{};
     if (vbp) vb = *vbp;
-    const unsigned nz = vbp ? (unsigned)vb.n : 1u;    // blockIdx.z = view (st / sc / out_* are view 0's)
-#define FWD_ARGS v, st.header, st.ranges, st.point_list, (const float4 *)st.geom, st.tile_order, (const float4 *)st.cullbox, \
-                 st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.pair_mask, st.tile_maxc, st.seg_cost, out_color, out_allmap, slabs, vb
+    const unsigned nz = vbp ? (unsigned)vb.n : 1u;    // blockIdx.z = view (st / out_* are view 0's)
     {
-        // Depth-segment split of the long lists: OPT-IN (lara2dgs_set_forward_split / LARA2DGS_FWD_SPLIT=1), off by default
-        // because it measured SLOWER: at LaRa's init statistics the four launches take 123 (prepass) + 142 (segment walks) + 14
-        // (combine) + 127 us (short lists) = 406 us against 254 us for the single launch.  The prepass repeats the staging and
-        // the alpha evaluation of 45 % of the pairs (the blend it leaves out is the small part), and the short lists alone
-        // still take 127 us for 55 % of the pairs: what idles the single launch (VALU issue 0.59) is mostly the four waves of a
-        // workgroup waiting for each other at the round barriers, not the one long list at the end.  Kept because it is
-        // exact (parity-tested in both settings) and documents the measurement.
         L2D_PROF("composite_fwd", s);
-        if (v.dbg & 128u) {
-            // long lists first (workgroups of short lists and of segments beyond a list's end return on their first loads)
-            hipLaunchKernelGGL(composite_fwd_kernel<1>, dim3(v.tiles, 8, nz), dim3(256), 0, s, FWD_ARGS);
-            hipLaunchKernelGGL(composite_fwd_kernel<2>, dim3(v.tiles, 8, nz), dim3(256), 0, s, FWD_ARGS);
-            hipLaunchKernelGGL(composite_fwd_combine_kernel, dim3(v.tiles, 1, nz), dim3(256), 0, s, v, st.header, st.ranges, st.tile_order,
-                               st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.ckpt, st.tile_maxc, out_color, out_allmap, slabs, vb);
-        }
-        hipLaunchKernelGGL(composite_fwd_kernel<0>, dim3(v.tiles, 1, nz), dim3(256), 0, s, FWD_ARGS);
+        hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles, 1, nz), dim3(256), 0, s, v, st.header, st.ranges, st.point_list,
+                           (const float4 *)st.geom, st.tile_order, (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base,
+                           st.seg_cnt, st.ckpt, st.pair_mask, st.tile_maxc, st.seg_cost, out_color, out_allmap, vb);
     }
-#undef FWD_ARGS
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;
 }

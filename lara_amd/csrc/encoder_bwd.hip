@@ -760,7 +760,7 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     const size_t out_bytes = (size_t)N * T * Kc * 4;
     // about 1024 workgroups per launch (4 per CU: one round), in multiples of 8 splits (one per XCD, see the
     // kernel), at least 256 token rows each; a split that starts beyond M writes zeros
-    static const int want = getenv("LARA_TN_WANT") ? atoi(getenv("LARA_TN_WANT")) : 1024;
+    const int want = 1024;
     int splits = max(1, min(want / tiles, (int)(TN_PART_BYTES / out_bytes)));
     splits = max(8, splits & ~7);
     while (splits > 8 && M / splits < 256) splits -= 8;
@@ -769,8 +769,7 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     p.A = A; p.B = B; p.part = part; p.nbr = nbr; p.M = M; p.lda = lda; p.ldb = ldb; p.N = N; p.Kc = Kc; p.T = T;
     p.chunk = chunk; p.tiles = tiles;
     if ((size_t)splits * out_bytes > TN_PART_BYTES) return LARA2DGS_E_INVALID;
-    static const bool force_direct = getenv("LARA_TN_DIRECT") != nullptr;  // (experiments: the per-lane-load kernel)
-    const bool staged = !((M & 31) || (N & 7) || (Kc & 7) || (lda & 7) || (ldb & 7)) && !force_direct;
+    const bool staged = !((M & 31) || (N & 7) || (Kc & 7) || (lda & 7) || (ldb & 7));
     if (staged) {
         TnGroup g{};
         g.p[0] = p; g.count = 1; g.first_slot[0] = 0; g.first_slot[1] = tiles * splits / 8;
@@ -800,14 +799,13 @@ struct TnJob {
     float *dst;
 };
 int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
-    static const bool off = getenv("LARA_TN_NO_GROUP") != nullptr;      // (A/B runs: one launch per product, as before round 4)
-    bool ok = !off && count >= 1 && count <= TN_GROUP_MAX;
+    bool ok = count >= 1 && count <= TN_GROUP_MAX;
     int tiles_all = 0;
     for (int k = 0; k < count && ok; k++) {
         const TnJob &j = jobs[k];
         ok = !((j.M & 31) || (j.N & 7) || (j.Kc & 7) || (j.lda & 7) || (j.ldb & 7)) && ((j.N * j.Kc) & 3) == 0 &&
              (size_t)(j.M + 1) * j.lda * 2 < (1ull << 32) && (size_t)(j.M + 1) * j.ldb * 2 < (1ull << 32) && j.M < (1 << 24) &&
-             (((uintptr_t)j.dst) & 15) == 0;
+             j.ldb < (1 << 23) && (((uintptr_t)j.dst) & 15) == 0;      // (the same 24-bit row multiplies as gemm_tn)
         tiles_all += ((j.N + 127) / 128) * ((j.Kc + 127) / 128);
     }
     if (!ok) {
@@ -820,7 +818,7 @@ int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
     }
     // about 1280 workgroups (five per CU: the kernel is latency-bound below four), splits in multiples of 8 (one per XCD), at
     // least 256 token rows per split
-    static const int want = getenv("LARA_TN_GROUP_WANT") ? atoi(getenv("LARA_TN_GROUP_WANT")) : 1280;
+    const int want = 1280;
     int base = max(8, (want / tiles_all) & ~7);
     TnGroup g{};
     AccGroup a{};

@@ -126,161 +126,9 @@ __device__ __forceinline__ float wave_total(float x) {
 //      residual is added from x and the result stored.
 // Each wave streams both weight matrices (256 KB) from L2 for its 32 rows: 1.07 GB of L2 reads per layer at 4
 // scenes -- the price of having no barrier; HBM sees x, K|V and y only.
-__global__ void __launch_bounds__(128)
-group_attn_fused_kernel(const float *x /* may alias y: the block runs in place */, const float *__restrict__ gamma,
-                        const float *__restrict__ beta, const float eps, const unsigned short *__restrict__ Wq,
-                        const unsigned short *__restrict__ KV, const unsigned short *__restrict__ Wo, float *y, const int G) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[2][24576];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 2 + wave, g0 = unit * 4;
-    if (g0 >= G) return;
-    unsigned char *R = lds_all[wave], *Kr = R + 16384, *Vr = R + 20480;
-    const int c16 = lane & 15, q4 = lane >> 4;
-    const int q_rows = min(32, (G - g0) * 8), kv_rows = min(16, (G - g0) * 4);  // ragged last unit
-    const int srow = lane >> 4, sphys = lane & 15;
-    const size_t row0 = (size_t)g0 * 8;
+// (That first cut -- round 2, `group_attn_fused_kernel`, weights read straight from the row-major matrix -- lost to the four
+// launches it replaced and was removed in round 5; group_attn_fused2_kernel below is the same design with packed weights.)
 
-    // ---- 1. LayerNorm -> bf16 rows in LDS
-    {
-        const float4 gm = ((const float4 *)gamma)[lane], bt = ((const float4 *)beta)[lane];
-        const int hh = lane >> 5, chunk = (lane & 31) >> 1, sub = (lane & 1) * 8;
-#pragma unroll 4
-        for (int r = 0; r < 32; r++) {
-            const float4 v = ((const float4 *)(x + (row0 + min(r, q_rows - 1)) * 256))[lane];
-            const float mean = wave_total((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
-            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d4 = v.w - mean;
-            const float rstd = 1.0f / sqrtf(wave_total(a * a + b * b + c * c + d4 * d4) * (1.0f / 256.0f) + eps);
-            ushort4 o;
-            o.x = f2bf(a * rstd * gm.x + bt.x); o.y = f2bf(b * rstd * gm.y + bt.y);
-            o.z = f2bf(c * rstd * gm.z + bt.z); o.w = f2bf(d4 * rstd * gm.w + bt.w);
-            *(ushort4 *)(R + hh * 8192 + r * 256 + ((chunk ^ (r & 15)) << 4) + sub) = o;
-        }
-    }
-    // row-operand fragments of a 32 x 256 bf16 block held in R: B[k = 16 ks + 8 (lane >> 5) + e][j = lane & 31]
-    const int frow = lane & 31, fk = 8 * (lane >> 5);
-    auto load_rows = [&](bf16x8 (&bf)[16]) {
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++) {
-            const int f = ks * 16 + fk;
-            bf[ks] = *(const bf16x8 *)(R + (f >> 7) * 8192 + frow * 256 + ((((f & 127) >> 3) ^ (frow & 15)) << 4));
-        }
-    };
-    bf16x8 bf[16], wf[16];
-    load_rows(bf);
-#pragma unroll
-    for (int ks = 0; ks < 16; ks++) wf[ks] = *(const bf16x8 *)(Wq + (size_t)frow * 256 + fk + ks * 16);
-    // ---- 2. Q^T tiles: 8 tiles of 32 features; the accumulator's registers 4g..4g+3 are features
-    //         n0 + 8g + 4 (lane >> 5) + (0..3) of row (lane & 31)
-#pragma unroll 1
-    for (int nt = 0; nt < 8; nt++) {
-        // the weight fragments of the NEXT tile are requested before this tile's MFMAs (a tile is one L2 round trip)
-        const unsigned short *wnext = Wq + (size_t)(min(nt + 1, 7) * 32 + frow) * 256 + fk;
-        bf16x8 wn[16];
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++) wn[ks] = *(const bf16x8 *)(wnext + ks * 16);
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bf[ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int f = nt * 32 + 8 * g + 4 * (lane >> 5);
-            ushort4 o;
-            o.x = f2bf(acc[4 * g]); o.y = f2bf(acc[4 * g + 1]); o.z = f2bf(acc[4 * g + 2]); o.w = f2bf(acc[4 * g + 3]);
-            *(ushort4 *)(R + (f >> 7) * 8192 + frow * 256 + ((((f & 127) >> 3) ^ (frow & 15)) << 4) + ((f & 7) << 1)) = o;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++) wf[ks] = wn[ks];
-    }
-    // ---- 3. attention, half of the heads at a time (Q is in place; K|V rows come by LDS-DMA)
-    for (int hh = 0; hh < 2; hh++) {
-        unsigned char *Qr = R + hh * 8192;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = 4 * i + srow, chunk = sphys ^ (row & 15);
-            const unsigned short *src = KV + (size_t)(g0 * 4 + min(row, kv_rows - 1)) * 512 + hh * 128 + chunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(Kr + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 256),
-                                             (__attribute__((address_space(3))) void *)(Vr + i * 1024), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll 2
-        for (int hl = 0; hl < 8; hl++) {
-            const int ck = 2 * hl + (q4 >> 1), sub = (q4 & 1) * 8;
-            const s16x4 kf = *(const s16x4 *)(Kr + c16 * 256 + ((ck ^ c16) << 4) + sub);
-            s16x4 vf;
-            const int cv = 2 * hl + (c16 >> 3), vb = (c16 & 7) * 2;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int row = 4 * q4 + e;
-                vf[e] = *(const short *)(Vr + row * 256 + ((cv ^ row) << 4) + vb);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int qrow = 16 * t + c16;
-                const s16x4 qf = *(const s16x4 *)(Qr + qrow * 256 + ((ck ^ (qrow & 15)) << 4) + sub);
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-                sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf, qf, sc, 0, 0, 0);
-                const bool valid = q4 == 2 * t + (c16 >> 3);
-                const float s0 = sc[0] * 0.25f, s1 = sc[1] * 0.25f, s2 = sc[2] * 0.25f, s3 = sc[3] * 0.25f;
-                const float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-                const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx), e2 = __expf(s2 - mx), e3 = __expf(s3 - mx);
-                const float inv = valid ? 1.0f / (e0 + e1 + e2 + e3) : 0.f;
-                s16x4 pf;
-                pf[0] = (short)f2bf(e0 * inv); pf[1] = (short)f2bf(e1 * inv);
-                pf[2] = (short)f2bf(e2 * inv); pf[3] = (short)f2bf(e3 * inv);
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, vf, o, 0, 0, 0);
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int orow = 16 * t + 4 * q4 + rr;
-                    *(unsigned short *)(Qr + orow * 256 + ((cv ^ (orow & 15)) << 4) + vb) = f2bf(o[rr]);
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- 4. y^T = W_o O^T, + x, stored 16 bytes per lane
-    load_rows(bf);
-#pragma unroll
-    for (int ks = 0; ks < 16; ks++) wf[ks] = *(const bf16x8 *)(Wo + (size_t)frow * 256 + fk + ks * 16);
-    const bool row_ok = frow < q_rows;
-#pragma unroll 1
-    for (int nt = 0; nt < 8; nt++) {
-        // the weight fragments of the NEXT tile are requested before this tile's MFMAs (a tile is one L2 round trip)
-        const unsigned short *wnext = Wo + (size_t)(min(nt + 1, 7) * 32 + frow) * 256 + fk;
-        bf16x8 wn[16];
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++) wn[ks] = *(const bf16x8 *)(wnext + ks * 16);
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bf[ks], acc, 0, 0, 0);
-        if (row_ok) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const size_t at = (row0 + frow) * 256 + nt * 32 + 8 * g + 4 * (lane >> 5);
-                const float4 xr = *(const float4 *)(x + at);
-                *(float4 *)(y + at) = make_float4(acc[4 * g] + xr.x, acc[4 * g + 1] + xr.y, acc[4 * g + 2] + xr.z, acc[4 * g + 3] + xr.w);
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ks++) wf[ks] = wn[ks];
-    }
-}
-
-// ---- the same step, second cut (round 4): what made the kernel above latency-bound was not its occupancy alone but FOUR
-// exposed memory round trips per unit -- the LayerNorm's row loads four at a time, the K|V DMA waited for at the start of
-// each half of the heads, and the residual loaded inside every output tile's epilogue.  Here all 32 rows of x are requested in
-// two batches before any arithmetic, the first half of K|V starts travelling before the Q projection and the second through
-// registers during the first half's attention, the weights are read in fragment order (pack_weight_frag_kernel: the row-major
-// fragments cost 64 L1 accesses per instruction and the first cut sat on the L1's access rate), and the residual is prefetched one
-// tile ahead like the weight fragments.  One wave per workgroup, 24 KB of LDS: six waves per CU.  In-place safe (x may alias y):
-// a wave reads all of its rows' x before the LayerNorm and re-reads a tile's residual before it stores that tile.
 // A [256, 256] bf16 weight (row = output feature, K contiguous) in the order group_attn_fused2_kernel's A-operand fragments are
 // read in: out[((nt * 16 + ks) * 64 + lane) * 8 + e] = W[nt * 32 + (lane & 31)][ks * 16 + 8 * (lane >> 5) + e].  Straight from
 // the row-major matrix a fragment instruction touches 32 rows x 32 bytes -- 64 separate L1 accesses, 23.6 k per wave and unit,

@@ -161,162 +161,56 @@ def _fill(struct, tensors, names):
     return struct
 
 
-class _VolTransFn(torch.autograd.Function):
-    """(image_feats [B, V = 4, C, D, H, W], eps_block, eps_final, R, out_dim, pos_embed, norm.w, norm.b, deconv.w,
-    deconv.b, 15 tensors per layer ...) -> [B, 2R, 2R, 2R, out_dim]"""
-
-    @staticmethod
-    def forward(ctx, image_feats, eps_block, eps_final, R, out_dim, pos_embed, norm_w, norm_b, deconv_w, deconv_b, *layer_params):
-        if not image_feats.is_cuda:
-            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
-        lib = _lib()
-        dev = image_feats.device
-        n_layers = len(layer_params) // _NLP
-        B, V, cond_dim = image_feats.shape[:3]
-        S = image_feats.shape[3] * image_feats.shape[4] * image_feats.shape[5]
-        M = B * R ** 3
-        # `b v c d h w -> (b d h w) v c` (network.py:145-150) and the bf16 cast in one pass: per scene, the
-        # [v c, d h w] matrix transposed
-        feats = image_feats.detach().float().contiguous()
-        cond_bf = torch.empty(B * S, V, cond_dim, dtype=torch.bfloat16, device=dev)
-        with torch.cuda.device(dev):
-            _check(lib.lara_batched_transpose(B, V * cond_dim, S, feats.data_ptr(), cond_bf.data_ptr(), 1, _stream(dev)),
-                   "lara_batched_transpose")
-        x = volume_to_tokens(pos_embed.detach().float()).repeat(B, 1)       # network.py:152
-        track = any(ctx.needs_input_grad)          # False under torch.no_grad(): plain in-place forward
-        keep = track and _keep_activations()
-        saved_x, saved_act, saved_w = [], [], []
-        nsave = lib.lara_groupblock_save_bytes(B, R)
-        if nsave < 0:
-            _check(int(nsave), "lara_groupblock_save_bytes")
-        ws = None if keep else _workspace(dev, "fwd", lib.lara_groupblock_workspace_bytes(B, R))
-        with torch.cuda.device(dev):
-            fs = [_layer_bf16([t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]]) for l in range(n_layers)]
-            for l in range(n_layers):
-                f = fs[l]
-                w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
-                w.eps = eps_block
-                if keep:   # out of place; the block's intermediates stay in HBM for the backward
-                    act = torch.empty(nsave, dtype=torch.uint8, device=dev)
-                    x_out = torch.empty_like(x)
-                    _check(lib.lara_groupblock_forward_train(B, R, cond_dim, x.data_ptr(), x_out.data_ptr(), cond_bf.data_ptr(),
-                                                             ctypes.byref(w), act.data_ptr(), _stream(dev)),
-                           "lara_groupblock_forward_train")
-                    saved_x.append(x)
-                    saved_act.append(act)
-                    saved_w.append(f)
-                    x = x_out
-                else:      # in place; the backward re-runs the block's forward from its input rows
-                    if track:
-                        saved_x.append(x.clone())
-                    _check(lib.lara_groupblock_forward(B, R, cond_dim, x.data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
-                                                       ws.data_ptr(), _stream(dev)), "lara_groupblock_forward")
-            wd = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).contiguous()
-            nw, nb, db = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous(), deconv_b.detach().float().contiguous()
-            out = torch.empty(B, 2 * R, 2 * R, 2 * R, out_dim, dtype=torch.float32, device=dev)
-            hws = _workspace(dev, "head", M * 512)
-            _check(lib.lara_voltrans_head_forward(B, R, x.data_ptr(), nw.data_ptr(), nb.data_ptr(), float(eps_final),
-                                                  wd.data_ptr(), db.data_ptr(), out_dim, out.data_ptr(), hws.data_ptr(),
-                                                  _stream(dev)), "lara_voltrans_head_forward")
-        if not track:
-            return out
-        ctx.save_for_backward(cond_bf, x, pos_embed, norm_w, norm_b, deconv_w, *saved_x, *layer_params)
-        ctx.meta = (float(eps_block), float(eps_final), R, out_dim, B, n_layers, cond_dim)
-        ctx.feat_shape, ctx.feat_dtype = tuple(image_feats.shape), image_feats.dtype
-        ctx.saved_act, ctx.saved_w = saved_act, saved_w   # raw scratch / bf16 weight copies, not graph tensors
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        lib = _lib()
-        eps_block, eps_final, R, out_dim, B, n_layers, cond_dim = ctx.meta
-        sv = ctx.saved_tensors
-        cond_bf, x_last, pos_embed, norm_w, norm_b, deconv_w = sv[:6]
-        saved_x = sv[6:6 + n_layers]
-        layer_params = sv[6 + n_layers:]
-        dev = cond_bf.device
-        M = B * R ** 3
-        f32 = dict(dtype=torch.float32, device=dev)
-        dout = dout.float().contiguous()
-        g = torch.empty(M, 256, **f32)
-        d_nw, d_nb = torch.zeros(256, **f32), torch.zeros(256, **f32)
-        d_wd, d_b8 = torch.zeros(8 * out_dim, 256, **f32), torch.zeros(8 * out_dim, **f32)
-        # every block leaves its dK|dV in its 512 columns of ONE buffer; dcond is one product after the sweep
-        # (the same cond feeds every layer) instead of a read-modify-write of the fp32 dcond per layer
-        lddkv = n_layers * 512
-        dkv_all = torch.empty(cond_bf.shape[0] * cond_bf.shape[1], lddkv, dtype=torch.bfloat16, device=dev)
-        dcond = torch.empty(cond_bf.shape, **f32)
-        grads = [None] * (n_layers * _NLP)
-        # every layer's 14 gradient accumulators carved from ONE zero-filled buffer (one fill, not 14 per layer)
-        shapes = {n: tuple(ctx.saved_w[0][n].shape) if ctx.saved_w else None for n in _GRAD_FIELDS}
-        if not ctx.saved_w:
-            f0 = _layer_bf16([t.detach() for t in layer_params[:_NLP]])
-            shapes = {n: tuple(f0[n].shape) for n in _GRAD_FIELDS}
-        offs, o = {}, 0
-        for n in _GRAD_FIELDS:
-            offs[n] = o
-            o += (math.prod(shapes[n]) + 63) // 64 * 64
-        per_layer = o
-        flat = torch.zeros(n_layers * per_layer, **f32)
-        with torch.cuda.device(dev):
-            wd_t = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).t().contiguous()
-            nw, nb = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous()
-            hws = _workspace(dev, "head_bwd", lib.lara_voltrans_head_backward_workspace_bytes(B, R, out_dim))
-            _check(lib.lara_voltrans_head_backward(B, R, x_last.data_ptr(), nw.data_ptr(), nb.data_ptr(), eps_final,
-                                                   wd_t.data_ptr(), out_dim, dout.data_ptr(), g.data_ptr(), d_nw.data_ptr(),
-                                                   d_nb.data_ptr(), d_wd.data_ptr(), d_b8.data_ptr(), hws.data_ptr(),
-                                                   _stream(dev)), "lara_voltrans_head_backward")
-            ws = _workspace(dev, "block_bwd", lib.lara_groupblock_backward_workspace_bytes(B, R))
-            for l in reversed(range(n_layers)):
-                p = [t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]]
-                f = ctx.saved_w[l] if ctx.saved_w else _layer_bf16(p)
-                ft = _layer_bf16_t(f)
-                w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
-                w.eps = eps_block
-                wt = _fill(_BlockWeightsT(), ft, ("wq_t", "wkv_t", "wo_t", "w1_t", "w2_t", "wconv_t"))
-                gd = {n: flat[l * per_layer + offs[n]:l * per_layer + offs[n] + math.prod(shapes[n])].view(shapes[n])
-                      for n in _GRAD_FIELDS}
-                dw = _fill(_BlockGrads(), gd, _GRAD_FIELDS)
-                act = ctx.saved_act[l].data_ptr() if ctx.saved_act else None
-                _check(lib.lara_groupblock_backward(B, R, cond_dim, saved_x[l].data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
-                                                    ctypes.byref(wt), act, g.data_ptr(), dcond.data_ptr(), ctypes.byref(dw),
-                                                    int(l != n_layers - 1), dkv_all.data_ptr() + l * 1024, lddkv,
-                                                    ws.data_ptr(), _stream(dev)), "lara_groupblock_backward")
-                grads[l * _NLP:(l + 1) * _NLP] = [
-                    gd["ln1_w"], gd["ln1_b"], gd["wq"], gd["wkv"][:256], gd["wkv"][256:], gd["wo"], gd["ln2_w"], gd["ln2_b"],
-                    gd["w1"], gd["b1"], gd["w2"], gd["b2"], gd["ln3_w"], gd["ln3_b"],
-                    gd["wconv"].view(256, 3, 3, 3, 256).permute(0, 4, 1, 2, 3)]
-            # dcond [rows, C] = dkv_all [rows, L * 512] . wkv_all [L * 512, C]
-            wkv_all_t = torch.cat([(ctx.saved_w[l] if ctx.saved_w else _layer_bf16(
-                [t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]]))["wkv"] for l in range(n_layers)], 0).t().contiguous()
-            _check(lib.lara_gemm_nt_bf16(dkv_all.shape[0], cond_dim, lddkv, dkv_all.data_ptr(), wkv_all_t.data_ptr(),
-                                         dcond.data_ptr(), 1, _stream(dev)), "lara_gemm_nt_bf16")
-            # the same positional rows enter every scene (network.py:152)
-            d_pos = tokens_to_volume(g.view(B, R ** 3, 256).sum(0), 1, R)
-            # dL/d(image_feats): the rearrangement's backward, [d h w, v c] -> [v c, d h w] per scene
-            Bf, V, C = ctx.feat_shape[:3]
-            S = dcond.shape[0] // Bf
-            d_feats = torch.empty(ctx.feat_shape, **f32)
-            _check(lib.lara_batched_transpose(Bf, S, V * C, dcond.data_ptr(), d_feats.data_ptr(), 0, _stream(dev)),
-                   "lara_batched_transpose")
-            if ctx.feat_dtype != torch.float32:
-                d_feats = d_feats.to(ctx.feat_dtype)
-        d_deconv_w = d_wd.view(2, 2, 2, out_dim, 256).permute(4, 3, 0, 1, 2)
-        d_deconv_b = d_b8.view(8, out_dim).sum(0)
-        return (d_feats, None, None, None, None, d_pos, d_nw, d_nb, d_deconv_w, d_deconv_b, *grads)
+def _forward_inference(image_feats, eps_block, eps_final, R, out_dim, pos_embed, norm_w, norm_b, deconv_w, deconv_b, *layer_params):
+    """The forward alone (torch.no_grad(): evaluation, network.py:455-532 under `model.eval()`), every block in place:
+    (image_feats [B, V = 4, C, D, H, W], ..., 15 tensors per layer ...) -> [B, 2R, 2R, 2R, out_dim].  (Round 2's single autograd
+    node for the whole transformer lived here; its backward is the per-block nodes below since round 3 and was removed in
+    round 5.)"""
+    if not image_feats.is_cuda:
+        raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+    lib = _lib()
+    dev = image_feats.device
+    n_layers = len(layer_params) // _NLP
+    B, V, cond_dim = image_feats.shape[:3]
+    S = image_feats.shape[3] * image_feats.shape[4] * image_feats.shape[5]
+    M = B * R ** 3
+    # `b v c d h w -> (b d h w) v c` (network.py:145-150) and the bf16 cast in one pass: per scene, the
+    # [v c, d h w] matrix transposed
+    feats = image_feats.detach().float().contiguous()
+    cond_bf = torch.empty(B * S, V, cond_dim, dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.lara_batched_transpose(B, V * cond_dim, S, feats.data_ptr(), cond_bf.data_ptr(), 1, _stream(dev)),
+               "lara_batched_transpose")
+    x = volume_to_tokens(pos_embed.detach().float()).repeat(B, 1)       # network.py:152
+    ws = _workspace(dev, "fwd", lib.lara_groupblock_workspace_bytes(B, R))
+    with torch.cuda.device(dev):
+        for l in range(n_layers):
+            f = _layer_bf16([t.detach() for t in layer_params[l * _NLP:(l + 1) * _NLP]])
+            w = _fill(_BlockWeights(), f, _GRAD_FIELDS)
+            w.eps = eps_block
+            _check(lib.lara_groupblock_forward(B, R, cond_dim, x.data_ptr(), cond_bf.data_ptr(), ctypes.byref(w),
+                                               ws.data_ptr(), _stream(dev)), "lara_groupblock_forward")
+        wd = deconv_w.detach().permute(2, 3, 4, 1, 0).reshape(8 * out_dim, 256).to(torch.bfloat16).contiguous()
+        nw, nb, db = norm_w.detach().float().contiguous(), norm_b.detach().float().contiguous(), deconv_b.detach().float().contiguous()
+        out = torch.empty(B, 2 * R, 2 * R, 2 * R, out_dim, dtype=torch.float32, device=dev)
+        hws = _workspace(dev, "head", M * 512)
+        _check(lib.lara_voltrans_head_forward(B, R, x.data_ptr(), nw.data_ptr(), nb.data_ptr(), float(eps_final),
+                                              wd.data_ptr(), db.data_ptr(), out_dim, out.data_ptr(), hws.data_ptr(),
+                                              _stream(dev)), "lara_voltrans_head_forward")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # The same forward / backward as ONE AUTOGRAD NODE PER BLOCK (the default): a block's 15 parameter gradients are
 # released the moment its backward returns, so torch DDP's reducer (train_lightning.py:68-81) fills and all-reduces
-# its buckets while the earlier blocks' backward is still running -- with `_VolTransFn` above every gradient appears
+# its buckets while the earlier blocks' backward is still running -- with one node for the whole transformer every gradient appears
 # only when the whole 12-layer sweep is over and no bucket can overlap it.  Same kernels, same order, same bits.
 #
 #   image_feats --_CondFn--> (cond_bf16, token) ;  (pos_embed, token) --_StartFn--> x0 --_BlockFn x L--> x_L --_HeadFn--> out
 #
 # `token` is a one-element tensor whose only job is graph order: _StartFn's backward (after block 0's) hands it a
 # gradient, which makes _CondFn's backward the LAST node to run -- it forms dL/d(image_feats) from the dK|dV every
-# block left in the sweep's shared buffer with ONE product (K = layers * 512), as `_VolTransFn.backward` does.
+# block left in the sweep's shared buffer with ONE product (K = layers * 512).
 # ---------------------------------------------------------------------------------------------------------------
 _ws_owner = {}     # device index -> (id of the sweep, layer) whose block backward used the "block_bwd" workspace last
 _block_bwd_log = None   # tests: set to a list to record (event, layer) as the sweep runs
@@ -522,13 +416,6 @@ def _forward_per_block(module, image_feats):
                          float(module.norm.eps), module.out_dim)
 
 
-def _monolithic() -> bool:
-    """LARA_ENCODER_MONOLITHIC=1: the whole transformer as one autograd node (`_VolTransFn`), as in round 2 -- for A/B
-    runs and the equivalence test; gradients are identical bit for bit."""
-    import os
-    return os.environ.get("LARA_ENCODER_MONOLITHIC", "0") == "1"
-
-
 class GroupAttBlock(nn.Module):
     """Parameter container with the reference's attribute names (network.py:57-79)."""
 
@@ -581,8 +468,8 @@ class VolTransformer(nn.Module):
         B, V, C, D = image_feats.shape[:4]
         if D != self.n_groups[0] or V != 4:
             raise RuntimeError("kernels are specialised for one image-feature voxel per group and 4 input views")
-        if torch.is_grad_enabled() and not _monolithic():
+        if torch.is_grad_enabled():
             return _forward_per_block(self, image_feats)
         flat = [p for layer in self.layers for p in layer.flat_params()]
-        return _VolTransFn.apply(image_feats, float(self.layers[0].norm1.eps), float(self.norm.eps), self.vol_low_res, self.out_dim,
+        return _forward_inference(image_feats, float(self.layers[0].norm1.eps), float(self.norm.eps), self.vol_low_res, self.out_dim,
                                  self.pos_embed, self.norm.weight, self.norm.bias, self.deconv.weight, self.deconv.bias, *flat)

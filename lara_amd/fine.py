@@ -18,6 +18,7 @@ arguments; bind it with ``Decoder.forward_fine = lara_amd.fine.forward_fine``.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -151,7 +152,14 @@ class _TakeRowsMulti(torch.autograd.Function):
     def forward(ctx, idx, *xs):
         if not xs[0].is_cuda:
             raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        if idx.dtype != torch.int64 or idx.device != xs[0].device or idx.dim() != 1:
+            raise RuntimeError(f"lara_amd: take_rows needs a 1-D int64 index tensor on {xs[0].device}, got {idx.dtype} on {idx.device}")
         idx = idx.contiguous()
+        if os.environ.get("LARA_DEBUG_CHECKS") == "1" and idx.numel():
+            # the backward scatters dst[idx[r]] = src[r]: duplicates would drop gradient instead of accumulating it (a mask's
+            # `nonzero()` is unique by construction); synchronises, so only on request
+            if int(idx.min()) < 0 or int(idx.max()) >= min(x.shape[0] for x in xs) or idx.unique().numel() != idx.numel():
+                raise RuntimeError("lara_amd: take_rows indices must be unique and in range")
         xs = [x.detach().float().contiguous() for x in xs]
         n = idx.numel()
         outs = [torch.empty((n,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device) for x in xs]

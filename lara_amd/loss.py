@@ -114,15 +114,17 @@ _band_cache = {}
 
 def _band(win, n_in, n_out, device, dtype):
     """[n_in, n_out] matrix B with B[j + i, j] = win[i]: x @ B = the 'valid' correlation of x's last dimension with win."""
-    key = (str(device), dtype, win.numel(), n_in, n_out, float(win[0]))
+    # keyed on the window TENSOR (no device value is read on a hit: `float(win[0])` here cost a host synchronisation per call,
+    # ~20 per step with MS-SSIM on both images); the entry keeps `win` alive, so its address cannot be reused by another window
+    key = (str(device), dtype, win.data_ptr(), win.numel(), n_in, n_out)
     if key not in _band_cache:
         k = win.numel()
         B = torch.zeros(n_in, n_out, dtype=dtype, device=device)
         j = torch.arange(n_out, device=device)
         for i in range(k):
             B[j + i, j] = win[i].to(dtype)
-        _band_cache[key] = B
-    return _band_cache[key]
+        _band_cache[key] = (B, win)
+    return _band_cache[key][0]
 
 
 def _blur(x, win, block=128):

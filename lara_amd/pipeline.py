@@ -254,7 +254,7 @@ class LaRaPipeline(nn.Module):
         """`n_views_sel`: the number of INPUT views, which the reference draws at random in {2, 3, 4} when
         ``cfg.train.use_rand_views`` is set (network.py:437-441).  The fused sampler / fine decoder and the encoder's K|V layout
         are built for ``self.n_views`` (4: configs/base.yaml); any other count is rejected here rather than mis-indexed --
-        run such a step through ``lara_amd.reference_style.network_forward``-style torch operators instead."""
+        run such a step through ``tools/reference_style.py: network_forward``-style torch operators instead."""
         if n_views_sel is not None and int(n_views_sel) != self.n_views:
             raise NotImplementedError(f"lara_amd.pipeline: built for {self.n_views} input views (configs/base.yaml n_views); got n_views_sel="
                                       f"{n_views_sel} (cfg.train.use_rand_views): not supported by the fused fine stage")
@@ -294,8 +294,10 @@ class LaRaPipeline(nn.Module):
         for s in sides:
             if s is not None:
                 s.wait_stream(cur)
-                # made on the caller's stream, read (and saved for the backward) on the scene streams
-                hand_over((g, inps, cams_of), s)
+                # made on the caller's stream, read (and saved for the backward) on the scene streams -- the batch's own tensors
+                # too: with a generator that frees the previous batch at the next iteration their safety would otherwise
+                # rest on the caller joining the streams before it drops the batch
+                hand_over((g, inps, cams_of, [batch[k] for k in ("tar_rays", "bg_color", "tar_w2c", "tar_ixt") if k in batch]), s)
 
         # per-scene tensors: one unbind per tensor (its backward is one stack; `x[i]` per use would cost a zero-filled
         # [B,P,C] buffer and an accumulation for every use)
@@ -326,10 +328,7 @@ class LaRaPipeline(nn.Module):
                     V, W = len(cams_of[i]), VW // len(cams_of[i])
                     # the five x[mask] of network.py:514-524 as one launch per direction
                     five = [sc["centers"][i], sc["shs"][i], sc["opacity"][i], sc["scaling"][i], sc["rotation"][i]]
-                    if os.environ.get("LARA_ROWS_ONE_BY_ONE") == "1":        # (A/B runs: one index_select per tensor, as before)
-                        centers_f, shs_sel, opacity_f, scaling_f, rotation_f = [take_rows(x, idx[i]) for x in five]
-                    else:
-                        centers_f, shs_sel, opacity_f, scaling_f, rotation_f = take_rows_multi(five, idx[i])
+                    centers_f, shs_sel, opacity_f, scaling_f, rotation_f = take_rows_multi(five, idx[i])
                     # the sampler reads the first n_sel views of the side-by-side maps in place (network.py:499 stacks them)
                     pf = sample_point_feats(centers_f, batch["tar_w2c"][i, :n_sel], batch["tar_ixt"][i, :n_sel], inps[i],
                                             co["image"], co["acc_map"], co["depth"], row_views=V)

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import warnings
 from typing import NamedTuple, Optional
 
 import torch
@@ -30,7 +31,7 @@ from torch import nn
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (LARA2DGS_LIB: another build of the same library -- kernel A/B experiments, tools/build_variant.sh; never a CPU path)
 LIB_PATH = os.environ.get("LARA2DGS_LIB") or os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class _View(ctypes.Structure):
@@ -86,15 +87,9 @@ def load_library():
     lib.lara2dgs_backward.restype = ctypes.c_int
     lib.lara2dgs_backward.argtypes = [ctypes.POINTER(_View)] + [vp] * 20
     lib.lara2dgs_forward_views.restype = ctypes.c_int
-    lib.lara2dgs_forward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 11 + [i64, vp, i64, i32, vp]
+    lib.lara2dgs_forward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 11 + [i64, vp, i64, vp]
     lib.lara2dgs_backward_views.restype = ctypes.c_int
-    lib.lara2dgs_backward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 10 + [i64, vp, i64, i32, vp, vp, vp]
-    lib.lara2dgs_set_view_lanes.restype = ctypes.c_int
-    lib.lara2dgs_set_view_lanes.argtypes = [i32]
-    lib.lara2dgs_set_forward_split.restype = ctypes.c_int
-    lib.lara2dgs_set_forward_split.argtypes = [i32]
-    lib.lara2dgs_set_views_batch_kernels.restype = ctypes.c_int
-    lib.lara2dgs_set_views_batch_kernels.argtypes = [i32]
+    lib.lara2dgs_backward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 10 + [i64, vp, i64, vp, vp]
     lib.lara2dgs_get_grad_layout.restype = ctypes.c_int
     lib.lara2dgs_get_grad_layout.argtypes = [i32, i32, i32, i32, i32, i32, ctypes.POINTER(GradLayout)]
     lib.lara2dgs_mark_visible.restype = ctypes.c_int
@@ -139,7 +134,9 @@ def set_cull_transparent(on: bool) -> bool:
 # workspace policy
 # ---------------------------------------------------------------------------------------------
 def _dup_factor() -> int:
-    return int(os.environ.get("LARA2DGS_DUP_FACTOR", "16"))
+    """Pairs per surfel the buffers start from before anything was measured (LARA2DGS_DUP_FACTOR; default 4: LaRa's init
+    distribution produces ~3).  Only the starting point: the capacity follows the measured pair counts (`binning_capacity`)."""
+    return int(os.environ.get("LARA2DGS_DUP_FACTOR", "4"))
 
 
 def _sizing_P(P: int) -> int:
@@ -154,16 +151,65 @@ def _sizing_P(P: int) -> int:
     return (P + 32767) // 65536 * 65536 + 32768
 
 
-def binning_capacity(P: int) -> int:
-    """(tile, surfel) pairs the buffers are sized for.  The real count is data dependent and
-    stays on the device (no host sync per view); LaRa's init distribution needs ~3 P, a 288 GB
-    part can afford 16 P (~36 B per pair) without thinking about it.  Override with
-    LARA2DGS_DUP_FACTOR.  Derived from the quantised surfel count (`_sizing_P`)."""
-    return min(max(_sizing_P(P) * _dup_factor(), 1 << 20), 0xFFFFFFFF)
+# The reference resizes geomBuffer / binningBuffer / imgBuffer after READING num_rendered on the host, once per view
+# (SURVEY.md section 8b): a call at renderer_2dgs.py:209-218 can therefore never fail on the number of (tile, surfel) pairs D,
+# and it pays a device->host synchronisation per view for it.  Here D stays on the device; the buffers are sized BEFORE the
+# call from what earlier calls of the same size class produced, and a call that does not fit is REPEATED at the size it
+# reported -- it is never an error (round 5; rounds 1-4 sized for 16 P and raised beyond it):
+#   * size class ("bucket") = (device, quantised surfel count, H, W); `_hwm` keeps the largest D any view of the class has
+#     reported (headers arrive through pinned memory, read when their event has completed: `check_pending`);
+#   * capacity of the next call = max(LARA2DGS_DUP_FACTOR * surfels, 2 * high-water mark), rounded up to the grid
+#     {2^k, 1.5 * 2^k} so that buffer sizes recur (the caching allocator then recycles the blocks);
+#   * the FIRST call of a class -- nothing measured yet -- and the 16 calls after a repeated one read D synchronously (what the
+#     reference does on every call): an overflow there is repaired before the call returns;
+#   * otherwise the check is lazy: an overflowing call (its D more than doubled against everything the class has seen) left
+#     NaN-poisoned outputs; at the next operator call / at its backward / in `check_pending` the SAME forward is enqueued again
+#     at the reported size, on its own stream, into the same output tensors, and a warning says which consumers may have read
+#     the poisoned values in between.  `debug=True` in the settings (the reference's own switch for synchronous error
+#     checking) makes every call synchronous.
+_hwm = {}      # bucket -> largest D seen
+_guard = {}    # bucket -> coming calls that read D synchronously
+_GUARD_CALLS = 16
+_reruns = 0    # forwards repeated at a larger capacity since the process started (tests, bench)
+
+
+def _bucket(device: torch.device, P: int, H: int, W: int):
+    return (device.index, _sizing_P(P), int(H), int(W))
+
+
+def _cap_grid(n: int) -> int:
+    """Smallest value of {2^k, 1.5 * 2^k} >= n, at least 2^20 (and at most the 32-bit pair index)."""
+    n = max(int(n), 1 << 20)
+    k = 1 << (n - 1).bit_length()
+    if k // 4 * 3 >= n:
+        k = k // 4 * 3
+    return min(k, 0xFFFFFFFF)
+
+
+def binning_capacity(P: int, H: int = 0, W: int = 0, device: Optional[torch.device] = None) -> int:
+    """(tile, surfel) pairs the buffers of the next call of this size class are sized for (see the policy above).  With
+    only `P`: the starting capacity of a class nothing was measured for."""
+    want = _sizing_P(P) * _dup_factor()
+    if device is not None:
+        want = max(want, 2 * _hwm.get(_bucket(device, P, H, W), 0))
+    return _cap_grid(want)
+
+
+def capacity_report() -> dict:
+    """{(device, sized surfels, H, W): {"D_max": high-water mark, "capacity": next call's}} + "reruns": forwards repeated."""
+    rep = {b: {"D_max": d, "capacity": _cap_grid(max(b[1] * _dup_factor(), 2 * d))} for b, d in _hwm.items()}
+    rep["reruns"] = _reruns
+    return rep
+
+
+def reset_capacity_history():
+    """Forget the measured pair counts (tests)."""
+    _hwm.clear()
+    _guard.clear()
 
 
 _scratch = {}   # (device index, stream id) -> uint8 tensor
-_pending = []   # [(event, pinned header, capacity)] of forwards not yet checked for overflow
+_pending = []   # [_Run] forwards whose pair counts have not been read yet
 
 
 _GUARD = 1 << 16   # poison mode: guard bytes on either side of a state / scratch buffer
@@ -208,26 +254,86 @@ def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
     return buf
 
 
-def _raise_overflow(hdr, cap):
-    raise RuntimeError(
-        f"lara_amd: binning capacity exceeded: the view produced {int(hdr[0])} (tile, surfel) pairs "
-        f"but buffers were sized for {cap}; its outputs were poisoned with NaN. Raise "
-        "LARA2DGS_DUP_FACTOR (pairs per surfel, default 16).")
+class _Run:
+    """One enqueued forward (a view, or the n views of a multi-view call): its state buffer(s), the pinned copy of the
+    64-byte header(s) and how to enqueue it again at a larger capacity."""
+    __slots__ = ("bucket", "cap", "state", "extra", "enqueue", "stream", "debug", "ev", "hdrs", "done", "n")
+
+    def __init__(self, bucket, cap, enqueue, stream, debug, n=1):
+        self.bucket, self.cap, self.enqueue, self.stream, self.debug, self.n = bucket, cap, enqueue, stream, debug, n
+        self.state = self.extra = self.ev = self.hdrs = None
+        self.done = False
+
+    def launch(self, cap):
+        """Enqueue the forward at `cap` on the current stream and start the asynchronous copy of its header(s)."""
+        self.cap = cap
+        self.state, hdr_dev, self.extra = self.enqueue(cap)
+        hdr = torch.empty(hdr_dev.shape, dtype=torch.int32, pin_memory=True)
+        hdr.copy_(hdr_dev, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+        self.hdrs = hdr.view(-1, 16)
+
+    def settle(self, lazy=False):
+        """Read the header(s) (waiting for them if need be); a forward that did not fit is enqueued again at the size it
+        reported, on its own stream, into the same outputs.  Afterwards `state` / `cap` are what the backward uses."""
+        global _reruns
+        if self.done:
+            return
+        while True:
+            self.ev.synchronize()
+            D = max(int(h[0]) & 0xFFFFFFFF for h in self.hdrs)
+            _hwm[self.bucket] = max(_hwm.get(self.bucket, 0), D)
+            if not any(int(h[1]) != 0 for h in self.hdrs):
+                break
+            cap = _cap_grid(max(2 * D, self.bucket[1] * _dup_factor()))
+            if cap <= self.cap:      # only at the 32-bit limit of the pair index
+                self.done = True
+                raise RuntimeError(
+                    f"lara_amd: a view produced {D} (tile, surfel) pairs, beyond the 32-bit pair index the buffers use "
+                    f"(capacity {self.cap}); its outputs were poisoned with NaN.")
+            if lazy:
+                warnings.warn(
+                    f"lara_amd: a rasteriser call produced {D} (tile, surfel) pairs for a capacity of {self.cap} (more than "
+                    "twice anything calls of this size had produced); its outputs held NaN until now and have been "
+                    "re-rendered in place.  Operators that consumed them in between saw NaN; the next "
+                    f"{_GUARD_CALLS} calls of this size read the pair count synchronously.", RuntimeWarning, stacklevel=3)
+                _guard[self.bucket] = _GUARD_CALLS
+            _reruns += 1
+            with torch.cuda.stream(self.stream):
+                self.launch(cap)
+        self.done = True
+        self.enqueue = None      # drops the references to inputs and outputs
+
+
+def _guarded(bucket, debug) -> bool:
+    """Does this call read its pair count synchronously?  (debug / first call of a size class / after a repeated call)"""
+    if debug or bucket not in _hwm:
+        return True
+    g = _guard.get(bucket, 0)
+    if g > 0:
+        _guard[bucket] = g - 1
+        return True
+    return False
 
 
 def check_pending(block: bool = False):
-    """Overflow check of earlier forwards, without stalling the stream unless ``block``."""
+    """Read the pair counts of earlier forwards -- without stalling any stream unless ``block`` -- and repeat the ones that
+    did not fit their buffers (see the workspace policy above).  Never raises for an overflow that a larger buffer cures."""
     global _pending
+    runs, _pending = _pending, []
     keep = []
-    for ev, hdr, cap in _pending:
-        if block:
-            ev.synchronize()
-        if block or ev.query():
-            if int(hdr[1]) != 0:
-                _pending = []
-                _raise_overflow(hdr, cap)
+    for i, run in enumerate(runs):
+        if run.done:
+            continue
+        if block or run.ev.query():
+            try:
+                run.settle(lazy=True)
+            except Exception:
+                _pending = keep + runs[i + 1:]
+                raise
         else:
-            keep.append((ev, hdr, cap))
+            keep.append(run)
     _pending = keep
 
 
@@ -317,24 +423,6 @@ def _validate(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_
     return device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c)
 
 
-def _watch_overflow(state_hdr_i32, cap, debug):
-    """Lazy overflow check: 64-byte header -> pinned host memory, no stall (unless debug)."""
-    hdr = torch.empty(state_hdr_i32.shape, dtype=torch.int32, pin_memory=True)
-    hdr.copy_(state_hdr_i32, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    hdrs = hdr.view(-1, 16)
-    if debug:
-        ev.synchronize()
-        for h in hdrs:
-            if int(h[1]) != 0:
-                _raise_overflow(h, cap)
-    else:
-        for h in hdrs:
-            _pending.append((ev, h, cap))
-    return ev, hdrs
-
-
 def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
     """Validate, allocate, enqueue the forward.  Returns everything backward / the tests need."""
     lib = load_library()
@@ -342,23 +430,33 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
         means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.sh_degree)
     H, W = int(rs.image_height), int(rs.image_width)
     check_pending()
-    cap = binning_capacity(P)
     with torch.cuda.device(device):
-        view, keep = _make_view(rs, P, M, cap, device)
-        stream = torch.cuda.current_stream(device).cuda_stream
+        view, keep = _make_view(rs, P, M, 0, device)
         color = torch.empty((3, H, W), dtype=torch.float32, device=device)
         allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
         radii = torch.empty((P,), dtype=torch.int32, device=device)
-        state = _alloc_bytes(lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap), device)
-        scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap))
-        rc = lib.lara2dgs_forward(ctypes.byref(view), _ptr(means3D_c), _ptr(sh_c), _ptr(col_c),
-                                  _ptr(opa_c), _ptr(sc_c), _ptr(rot_c), _ptr(tm_c),
-                                  color.data_ptr(), allmap.data_ptr(), radii.data_ptr(),
-                                  state.data_ptr(), scratch.data_ptr(), stream)
-        _check(rc, "lara2dgs_forward")
-        ev, hdrs = _watch_overflow(state[:64].view(torch.int32), cap, rs.debug)
-    return dict(color=color, radii=radii, allmap=allmap, state=state, cap=cap, M=M, ev=ev, hdr=hdrs[0],
-                keep=keep, inputs=(means3D_c, sh_c, col_c, sc_c, rot_c, tm_c))
+
+        def enqueue(cap):
+            view.capacity = cap
+            state = _alloc_bytes(lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap), device)
+            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap))
+            rc = lib.lara2dgs_forward(ctypes.byref(view), _ptr(means3D_c), _ptr(sh_c), _ptr(col_c),
+                                      _ptr(opa_c), _ptr(sc_c), _ptr(rot_c), _ptr(tm_c),
+                                      color.data_ptr(), allmap.data_ptr(), radii.data_ptr(),
+                                      state.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
+            _check(rc, "lara2dgs_forward")
+            return state, state[:64].view(torch.int32), None
+
+        bucket = _bucket(device, P, H, W)
+        run = _Run(bucket, 0, enqueue, torch.cuda.current_stream(device), bool(rs.debug))
+        guarded = _guarded(bucket, rs.debug)
+        run.launch(binning_capacity(P, H, W, device))
+        if guarded:
+            run.settle()
+        else:
+            _pending.append(run)
+    return dict(color=color, radii=radii, allmap=allmap, run=run, M=M, keep=keep,
+                inputs=(means3D_c, sh_c, col_c, sc_c, rot_c, tm_c))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -367,15 +465,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cov3Ds_precomp, raster_settings):
         rs = raster_settings
         r = _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs)
-        color, radii, allmap, state, cap, M = r["color"], r["radii"], r["allmap"], r["state"], r["cap"], r["M"]
-        ev, hdr, keep = r["ev"], r["hdr"], r["keep"]
+        color, radii, allmap, M, keep = r["color"], r["radii"], r["allmap"], r["M"], r["keep"]
         means3D_c, sh_c, col_c, sc_c, rot_c, tm_c = r["inputs"]
 
         ctx.raster_settings = rs
-        ctx.cap = cap
         ctx.M = M
         ctx.prefiltered_bits = int(bool(rs.prefiltered)) | (2 if _cull_transparent else 0)   # as the forward ran
-        ctx.hdr = (ev, hdr)
+        ctx.run = r["run"]      # holds `state` (replaced if the forward had to be repeated at a larger capacity)
         ctx.flags = (sh_c is not None, col_c is not None, sc_c is not None, tm_c is not None)
         ctx.shapes = (sh.shape if sh_c is not None else None, opacities.shape)
         empty = means3D_c.new_empty(0)
@@ -385,23 +481,22 @@ class _RasterizeGaussians(torch.autograd.Function):
                               sc_c if sc_c is not None else empty,
                               rot_c if rot_c is not None else empty,
                               tm_c if tm_c is not None else empty,
-                              radii, state, *keep)
+                              radii, *keep)
         ctx.mark_non_differentiable(radii)
         return color, radii, allmap
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
         lib = load_library()
-        (means3D, sh, col, sc, rot, tm, radii, state, bg, vm, pm, cp) = ctx.saved_tensors
+        (means3D, sh, col, sc, rot, tm, radii, bg, vm, pm, cp) = ctx.saved_tensors
         has_sh, has_col, has_sr, has_tm = ctx.flags
         rs = ctx.raster_settings
         device = means3D.device
         P = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
-        ev, hdr = ctx.hdr
-        ev.synchronize()  # long done by the time autograd gets here
-        if int(hdr[1]) != 0:
-            _raise_overflow(hdr, ctx.cap)
+        run = ctx.run
+        run.settle(lazy=True)  # the header is long there by the time autograd gets here
+        state, cap = run.state, run.cap
         with torch.cuda.device(device):
             if grad_color is None:
                 grad_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
@@ -411,7 +506,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_allmap = _prep(grad_allmap, "grad_allmap", device)
             view = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
                          float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)),
-                         ctx.cap, bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
+                         cap, bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
             new = lambda *s: torch.empty(s, dtype=torch.float32, device=device)
             g_means3D = new(P, 3)
             g_means2D = new(P, 3)
@@ -421,7 +516,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_sc = new(P, 2) if has_sr else None
             g_rot = new(P, 4) if has_sr else None
             g_tm = new(P, 9) if has_tm else None
-            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, ctx.cap))
+            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap))
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = lib.lara2dgs_backward(
                 ctypes.byref(view), _ptr(means3D), _ptr(sh if has_sh else None),
@@ -441,35 +536,6 @@ class _RasterizeGaussians(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # opt-in: all views of a scene in one call
 # ---------------------------------------------------------------------------------------------
-_lanes = None   # lanes of the multi-view calls; None = LARA2DGS_VIEW_STREAMS (default 2), read per call
-
-
-def set_view_lanes(n):
-    """Lanes (streams) a multi-view call spreads its views over: 2 pays when one stream feeds the device, 1 when the
-    application already issues from two streams (one per scene).  None returns to LARA2DGS_VIEW_STREAMS."""
-    global _lanes
-    _lanes = None if n is None else max(1, min(8, int(n)))
-
-
-def set_forward_split(on: bool) -> bool:
-    """Opt-in: composite tile lists beyond 2048 entries as depth segments on several workgroups (include/lara2dgs.h:
-    lara2dgs_set_forward_split; off by default -- measured slower at LaRa's statistics).  Returns the previous setting."""
-    return bool(load_library().lara2dgs_set_forward_split(int(bool(on))))
-
-
-def set_views_batch_kernels(on: bool) -> bool:
-    """Multi-view calls: binning + composite of all views as ONE launch per kernel (default on) or per view on the lanes
-    (include/lara2dgs.h: lara2dgs_set_views_batch_kernels).  Same results bit for bit.  Returns the previous setting."""
-    return bool(load_library().lara2dgs_set_views_batch_kernels(int(bool(on))))
-
-
-def _view_lanes() -> int:
-    n = _lanes if _lanes is not None else max(1, min(8, int(os.environ.get("LARA2DGS_VIEW_STREAMS", "2"))))
-    lib = load_library()
-    lib.lara2dgs_set_view_lanes(n)
-    return n
-
-
 def _views_array(settings, P, M, cap, device, prefiltered_bits=None):
     arr = (_View * len(settings))()
     keep = []
@@ -484,8 +550,8 @@ def _views_array(settings, P, M, cap, device, prefiltered_bits=None):
 
 class _RasterizeViews(torch.autograd.Function):
     """ONE autograd node for the n views of a scene: same surfels, n cameras (the reference's loop at
-    lightning/network.py:486-497 issues n nodes).  Per-camera state is carved from one allocation; the library runs
-    the views on its side streams and returns the gradient already summed over the views."""
+    lightning/network.py:486-497 issues n nodes).  Per-camera state is carved from one allocation; every kernel is one
+    launch over the cameras and the gradient comes back already summed over the views."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
@@ -502,46 +568,53 @@ class _RasterizeViews(torch.autograd.Function):
             means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs0.sh_degree)
         H, W = int(rs0.image_height), int(rs0.image_width)
         check_pending()
-        cap = binning_capacity(P)
-        lanes = min(n, _view_lanes())
+        debug = any(rs.debug for rs in settings)
         with torch.cuda.device(device):
-            views, keep = _views_array(settings, P, M, cap, device)
-            stream = torch.cuda.current_stream(device).cuda_stream
+            views, keep = _views_array(settings, P, M, 0, device)
             color = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
             allmap = torch.empty((n, 7, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((n, P), dtype=torch.int32, device=device)
-            sb = (lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
-            qb = (lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
-            state = _alloc_bytes(n * sb, device)
-            # a scratch buffer per VIEW: the library then preprocesses all cameras in one launch (the surfels' inputs are
-            # read once); with fewer it falls back to one preprocess launch per view on the lanes
-            # (LARA2DGS_VIEWS_BATCH_PREPROCESS=0 keeps one scratch per lane: the memory-lean path)
-            n_scr = n if os.environ.get("LARA2DGS_VIEWS_BATCH_PREPROCESS", "1") != "0" else lanes
-            scratch = _get_scratch(device, n_scr * qb)
-            rc = lib.lara2dgs_forward_views(n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c),
-                                            _ptr(sc_c), _ptr(rot_c), _ptr(tm_c), color.data_ptr(), allmap.data_ptr(),
-                                            radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb, n_scr, stream)
-            _check(rc, "lara2dgs_forward_views")
-            ev, hdrs = _watch_overflow(state.view(n, sb)[:, :64].contiguous().view(torch.int32), cap,
-                                       any(rs.debug for rs in settings))
+
+            def enqueue(cap):
+                for i in range(n):
+                    views[i].capacity = cap
+                sb = (lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
+                qb = (lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
+                state = _alloc_bytes(n * sb, device)
+                scratch = _get_scratch(device, n * qb)      # a scratch buffer per view: every kernel is one launch over the cameras
+                rc = lib.lara2dgs_forward_views(n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c),
+                                                _ptr(sc_c), _ptr(rot_c), _ptr(tm_c), color.data_ptr(), allmap.data_ptr(),
+                                                radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb,
+                                                torch.cuda.current_stream(device).cuda_stream)
+                _check(rc, "lara2dgs_forward_views")
+                return state, state.view(n, sb)[:, :64].contiguous().view(torch.int32), (sb, qb)
+
+            bucket = _bucket(device, P, H, W)
+            run = _Run(bucket, 0, enqueue, torch.cuda.current_stream(device), debug, n)
+            guarded = _guarded(bucket, debug)
+            run.launch(binning_capacity(P, H, W, device))
+            if guarded:
+                run.settle()
+            else:
+                _pending.append(run)
         ctx.settings = settings
-        ctx.cap, ctx.M, ctx.sb, ctx.qb = cap, M, sb, qb
+        ctx.M = M
         ctx.prefiltered_bits = int(bool(rs0.prefiltered)) | (2 if _cull_transparent else 0)
-        ctx.hdr = (ev, hdrs)
+        ctx.run = run
         ctx.flags = (sh_c is not None, col_c is not None, sc_c is not None, tm_c is not None)
         ctx.shapes = (sh.shape if sh_c is not None else None, opacities.shape)
         empty = means3D_c.new_empty(0)
         ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else empty, col_c if col_c is not None else empty,
                               sc_c if sc_c is not None else empty, rot_c if rot_c is not None else empty,
-                              tm_c if tm_c is not None else empty, radii, state, *keep)
+                              tm_c if tm_c is not None else empty, radii, *keep)
         ctx.mark_non_differentiable(radii)
         return color, radii, allmap
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
         lib = load_library()
-        means3D, sh, col, sc, rot, tm, radii, state = ctx.saved_tensors[:8]
-        cams = ctx.saved_tensors[8:]
+        means3D, sh, col, sc, rot, tm, radii = ctx.saved_tensors[:7]
+        cams = ctx.saved_tensors[7:]
         has_sh, has_col, has_sr, has_tm = ctx.flags
         settings = ctx.settings
         n = len(settings)
@@ -549,11 +622,9 @@ class _RasterizeViews(torch.autograd.Function):
         device = means3D.device
         P = means3D.shape[0]
         H, W = int(rs0.image_height), int(rs0.image_width)
-        ev, hdrs = ctx.hdr
-        ev.synchronize()
-        for h in hdrs:
-            if int(h[1]) != 0:
-                _raise_overflow(h, ctx.cap)
+        run = ctx.run
+        run.settle(lazy=True)
+        state, cap, (sb, qb) = run.state, run.cap, run.extra
         G = GradLayout()
         _check(lib.lara2dgs_get_grad_layout(P, ctx.M, int(has_sh), int(has_col), int(has_sr), int(has_tm), ctypes.byref(G)),
                "lara2dgs_get_grad_layout")
@@ -568,23 +639,18 @@ class _RasterizeViews(torch.autograd.Function):
             for i, rs in enumerate(settings):
                 bg, vm, pm, cp = cams[4 * i:4 * i + 4]
                 views[i] = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
-                                 float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)), ctx.cap,
+                                 float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)), cap,
                                  bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
-            lanes = min(n, _view_lanes())
             out = torch.empty((max(G.total, 4),), dtype=torch.float32, device=device)
-            # a scratch buffer per VIEW: each view's gradient rows stay put until ONE preprocess_bwd launch folds the n
-            # views into the summed gradient (no per-view gradient tensors); with one per lane the library writes a
-            # gradient slice per view into `tmp` and sums the slices
-            batched = os.environ.get("LARA2DGS_VIEWS_BATCH_PREPROCESS", "1") != "0"
-            n_scr = n if batched else lanes
-            tmp = None if batched else torch.empty((n * max(G.total, 4),), dtype=torch.float32, device=device)
-            scratch = _get_scratch(device, n_scr * ctx.qb)
+            # each view's gradient rows stay in its own scratch buffer until ONE preprocess_bwd launch folds the n views into
+            # the summed gradient (no per-view gradient tensors)
+            scratch = _get_scratch(device, n * qb)
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = lib.lara2dgs_backward_views(
                 n, views, _ptr(means3D), _ptr(sh if has_sh else None), _ptr(col if has_col else None),
                 _ptr(sc if has_sr else None), _ptr(rot if has_sr else None), _ptr(tm if has_tm else None),
-                radii.data_ptr(), grad_color.data_ptr(), grad_allmap.data_ptr(), state.data_ptr(), ctx.sb,
-                scratch.data_ptr(), ctx.qb, n_scr, _ptr(tmp), out.data_ptr(), stream)
+                radii.data_ptr(), grad_color.data_ptr(), grad_allmap.data_ptr(), state.data_ptr(), sb,
+                scratch.data_ptr(), qb, out.data_ptr(), stream)
             _check(rc, "lara2dgs_backward_views")
 
         def sec(off, k, shape):
@@ -711,6 +777,8 @@ def forward_with_state(raster_settings, means3D, opacities, shs=None, colors_pre
     with torch.no_grad():
         r = _forward_impl(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                           raster_settings)
+    r["run"].settle()       # synchronises; a forward that did not fit has been repeated by now
+    r["state"], r["cap"] = r["run"].state, r["run"].cap
     P = means3D.shape[0]
     r["views"] = state_views(r["state"], P, int(raster_settings.image_height),
                              int(raster_settings.image_width), r["cap"])

@@ -55,14 +55,13 @@ def test_invalid_arguments_return_error_codes_not_crashes(hip_lib):
     assert hip_lib.lara2dgs_mark_visible(4, None, None, None, None, None) == -1
 
 
-def test_view_lanes_setting_round_trips(hip_lib):
-    """The one process-wide setting of the library: lanes of the multi-view calls, clamped to 1..8; the setter returns
-    the previous value (host-side state only, no GPU needed)."""
-    prev = hip_lib.lara2dgs_set_view_lanes(3)
-    assert 1 <= prev <= 8
-    assert hip_lib.lara2dgs_set_view_lanes(100) == 3
-    assert hip_lib.lara2dgs_set_view_lanes(0) == 8
-    assert hip_lib.lara2dgs_set_view_lanes(prev) == 1
+def test_library_exports_no_setters(hip_lib):
+    """the library keeps no global state.  Rounds 2-4 shipped three process-wide setters (view lanes,
+    forward split, per-view launches) for A/B runs; they are gone with the paths they selected."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", rasterizer.LIB_PATH], capture_output=True, text=True).stdout
+    assert "lara2dgs_forward_views" in syms
+    assert not [l for l in syms.splitlines() if "lara" in l and "_set_" in l.split()[-1].replace("l2d_set_hip_error", "")], syms
 
 
 def test_operator_refuses_cpu_tensors_and_has_no_fallback(hip_lib):
@@ -111,3 +110,33 @@ def test_buffer_sizes_are_quantised_in_the_surfel_count(hip_lib):
         assert q >= P and cap == rasterizer.binning_capacity(q)
         assert hip_lib.lara2dgs_state_bytes(q, 512, 512, cap) >= hip_lib.lara2dgs_state_bytes(P, 512, 512, cap)
         assert hip_lib.lara2dgs_scratch_bytes(q, 512, 512, cap) >= hip_lib.lara2dgs_scratch_bytes(P, 512, 512, cap)
+
+
+def test_capacity_policy_follows_the_measured_pair_counts(monkeypatch):
+    """Host logic of the workspace policy (rasterizer.py): capacities sit on the grid {2^k, 1.5 * 2^k}, start from
+    LARA2DGS_DUP_FACTOR pairs per (quantised) surfel, and follow twice the largest count a size class has reported; the first
+    call of a class, debug calls and the calls after a repeated one read the count synchronously."""
+    import torch
+    from lara_amd import rasterizer as rz
+    monkeypatch.delenv("LARA2DGS_DUP_FACTOR", raising=False)
+    rz.reset_capacity_history()
+    assert [rz._cap_grid(n) for n in (1, 1 << 20, (1 << 20) + 1, 3 << 19, (3 << 19) + 1, 3_090_000, 1 << 40)] == \
+        [1 << 20, 1 << 20, 3 << 19, 3 << 19, 1 << 21, 3 << 20, 0xFFFFFFFF]
+    dev = torch.device("cuda", 0)
+    P, H, W = 524288, 512, 512
+    b = rz._bucket(dev, P, H, W)
+    assert b == (0, 557056, 512, 512) == rz._bucket(dev, 524000, H, W)
+    assert rz.binning_capacity(P) == rz.binning_capacity(P, H, W, dev) == 3 << 20      # 4 x 557 056 -> 3 Mi
+    assert rz._guarded(b, False) and rz._guarded(b, True)          # nothing measured: synchronous
+    rz._hwm[b] = 1_545_000                                          # LaRa's init distribution
+    assert rz.binning_capacity(P, H, W, dev) == 3 << 20 and not rz._guarded(b, False) and rz._guarded(b, True)
+    rz._hwm[b] = 4_600_000                                          # surfels e x larger (SURVEY section 8a R4)
+    assert rz.binning_capacity(P, H, W, dev) == 3 << 22
+    assert rz.binning_capacity(P, 1024, 1024, dev) == 3 << 20      # another size class: its own history
+    rz._guard[b] = 2
+    assert rz._guarded(b, False) and rz._guarded(b, False) and not rz._guarded(b, False)
+    rep = rz.capacity_report()
+    assert rep[b] == {"D_max": 4_600_000, "capacity": 3 << 22} and "reruns" in rep
+    monkeypatch.setenv("LARA2DGS_DUP_FACTOR", "16")
+    assert rz.binning_capacity(P) == 3 << 22
+    rz.reset_capacity_history()

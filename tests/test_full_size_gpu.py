@@ -36,10 +36,10 @@ def test_multi_view_launch_at_benchmark_size_equals_the_per_view_operator_and_th
     inp = leaves()
     color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
                                                      scales=inp["scales"], rotations=inp["rotations"])
-    node = color.grad_fn
-    state, sb, cap = node.saved_tensors[7], node.sb, node.cap
+    run = color.grad_fn.run     # the forward's state buffer and capacity (final once the backward has read the pair counts)
     ((color * dc).sum() + (allmap * da).sum()).backward()
     torch.cuda.synchronize()
+    state, (sb, _), cap = run.state, run.extra, run.cap
 
     want = None
     for i, rs in enumerate(settings):

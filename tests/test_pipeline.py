@@ -284,11 +284,11 @@ def test_pipeline_reproduces_the_references_own_network_forward(hip_lib, n_strea
 
 @pytest.mark.gpu
 def test_reference_style_network_forward_matches_the_fused_pipeline(hip_lib):
-    """`lara_amd.reference_style.network_forward` -- the reference's own sequence of torch operators around the drop-in
+    """`tools.reference_style.network_forward` -- the reference's own sequence of torch operators around the drop-in
     rasteriser (what bench.py times as `drop_in_step`) -- against the opt-in pipeline on the same parameters: the coarse maps to
     fp32 rounding (same rasteriser kernels, post-processing as torch operators instead of the fused kernel), the fine maps to the
     bf16 rounding of `Decoder.forward_fine` under autocast (the fused fine decoder runs its products in fp32)."""
-    from lara_amd import reference_style
+    from tools import reference_style
     dev = torch.device("cuda:0")
     pipe, batch, feat_vol = _small_problem(dev)
     pipe.fine_mask = "plain"

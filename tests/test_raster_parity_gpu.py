@@ -288,7 +288,9 @@ def test_backward_work_items_are_ordered_dearest_first(hip_lib):
     inp = {k: v.to(DEV).requires_grad_(True) for k, v in act.items()}
     color, _, allmap = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
                                               scales=inp["scales"], rotations=inp["rotations"])
-    state, cap = color.grad_fn.saved_tensors[7], color.grad_fn.cap
+    run = color.grad_fn.run
+    run.settle()
+    state, cap = run.state, run.cap
     P = act["means3D"].shape[0]
     v = rasterizer.state_views(state, P, 64, 64, cap)
     torch.cuda.synchronize()
@@ -312,64 +314,27 @@ def test_backward_work_items_are_ordered_dearest_first(hip_lib):
     assert buckets[0] > buckets[-1]
 
 
-@pytest.fixture
-def forward_split():
-    from lara_amd import rasterizer
-    prev = rasterizer.set_forward_split(True)
-    yield
-    rasterizer.set_forward_split(prev)
-
-
-def test_forward_split_of_long_lists_keeps_every_parity_class(hip_lib, forward_split):
-    """Opt-in `set_forward_split`: lists beyond 2048 entries are composited as depth segments by several workgroups (a
-    transmittance prepass gives each segment its starting T, M1, M2).  Same bars as the one-workgroup walk: integers exact,
-    contributor records under the explained-threshold rule, images and gradients within their bars -- forward (lists up
-    to > 2048, ragged image), and backward through lists several segments deep (the checkpoint rows of a split tile get the
-    earlier segments' sums added by the combine kernel)."""
-    from lara_amd import cameras
-    act, cams = small_scene(grid=12, size=150, seed=5, scale_boost=6.0, opacity_boost=-2.0)
-    cam = cameras.make_cameras(cameras.turntable_c2w(4)[2:3], 150, 90, 0.75, 0.6, 0.5, 2.5)[0]
-    ref = run_oracle(oracle_view(cam, (0.2, 0.4, 0.6)), to_numpy(act))
-    assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 2048
-    r = _gpu_forward(raster_settings(cam, (0.2, 0.4, 0.6), device=DEV), act)
-    _check_forward(r, ref, 90, 150)
-    act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)
-    ref = run_oracle(oracle_view(cams[1], (1.0, 1.0, 1.0)), to_numpy(act))
-    assert (ref.ranges[:, 1] - ref.ranges[:, 0]).max() > 3 * 1024 and ref.n_contrib[0].max() > 2 * 1024 + 100
-    _grad_check(act, cams[1], (1.0, 1.0, 1.0))
-    # and against the one-workgroup walk of the same frame: the same image to rounding
-    from lara_amd import rasterizer
-    rs = raster_settings(cams[1], (1.0, 1.0, 1.0), device=DEV)
-    a = _gpu_forward(rs, act)
-    rasterizer.set_forward_split(False)
-    b = _gpu_forward(rs, act)
-    rasterizer.set_forward_split(True)
-    assert float((a["color"] - b["color"]).abs().max()) <= 2e-6 and float((a["allmap"] - b["allmap"]).abs().max()) <= 2e-5
-
-
-def test_backward_when_checkpoint_rows_run_out(hip_lib, monkeypatch):
-    """Checkpoint rows are a fixed slab (capacity / 1024 + 1): with the pair capacity barely above the real
-    count, about half of the deep tiles do not get rows and must run their backward unsegmented -- same
-    gradients, and the work items of their segments are marked unused."""
+def test_backward_with_the_capacity_barely_above_the_pair_count(hip_lib, monkeypatch):
+    """With the capacity following the measured pair count, frames between half the capacity and all of it are the normal
+    case: the checkpoint slab holds capacity / 512 + 1 rows, so EVERY tile keeps its segmented backward (rounds 1-4 sized the
+    slab for half of that and ran the tiles beyond it unsegmented) -- same gradients."""
     from lara_amd import rasterizer
     act, cams = small_scene(grid=24, size=64, seed=8, scale_boost=3.0, opacity_boost=-1.0)
     cam, bg = cams[1], (1.0, 1.0, 1.0)
     ref = run_oracle(oracle_view(cam, bg), to_numpy(act))
     cap = int(ref.num_rendered) + 64
-    monkeypatch.setattr(rasterizer, "binning_capacity", lambda P: cap)
+    monkeypatch.setattr(rasterizer, "binning_capacity", lambda P, *a: cap)
     r = _gpu_forward(raster_settings(cam, bg, sh_degree=1, device=DEV), act)
     v = r["views"]
-    assert int(v["header"][1]) == 0
+    assert int(v["header"][1]) == 0 and r["cap"] == cap
     want = (np.maximum(ref.ranges[:, 1].astype(np.int64) - ref.ranges[:, 0] - 1, 0) // 512)
     used = v["seg_cnt"].cpu().numpy()
     base = v["seg_base"].cpu().numpy()
     assert np.array_equal(base[:-1], np.cumsum(want) - want) and base[-1] == want.sum()
-    fits = base[:-1] + want <= cap // 1024 + 1
-    assert np.array_equal(used, np.where(fits, want, 0))
-    assert (used < want).any() and (used > 0).any(), "the case must mix segmented and unsegmented tiles"
+    assert np.array_equal(used, want) and want.sum() > cap // 1024 + 1, "the case must need more rows than the old slab had"
     items = v["bwd_items"].cpu().numpy().view(np.uint32)[: int(want.sum())]
     assert int(v["header"][3]) == want.sum()
-    assert (items[:, 0] == 0xFFFFFFFF).sum() == want[~fits].sum()
+    assert sorted(map(tuple, items.tolist())) == sorted((t, q) for t in range(len(want)) for q in range(int(want[t])))
     _grad_check(act, cam, bg)
 
 
@@ -422,20 +387,94 @@ def test_empty_and_tiny_inputs(hip_lib):
     np.testing.assert_allclose(r["color"].cpu().numpy(), ref.color, atol=1e-6)
 
 
-def test_capacity_overflow_is_loud(hip_lib, monkeypatch):
-    from lara_amd import GaussianRasterizer, rasterizer
+def _ramp_scene():
     act, cams = small_scene(grid=16, size=128, seed=0, scale_boost=3.0)
-    monkeypatch.setenv("LARA2DGS_DUP_FACTOR", "1")
-    monkeypatch.setattr(rasterizer, "binning_capacity", lambda P: P)  # far too small on purpose
+    return act, cams
+
+
+def _call(rs, t, **kw):
+    from lara_amd import GaussianRasterizer
+    return GaussianRasterizer(rs)(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), shs=t["shs"],
+                                  opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], **kw)
+
+
+def test_a_call_that_outgrows_its_buffers_is_repeated_not_fatal(hip_lib, monkeypatch):
+    """The reference sizes its buffers AFTER reading num_rendered: a call at renderer_2dgs.py:209-218 never
+    fails on the pair count.  Here the buffers are sized before the call from what earlier calls produced; when the surfels
+    grow (scales ramped, as a training run ramps them) the capacity follows, and a call that does not fit is repeated at the
+    size it reported.  No exception at any point; every image, radius and gradient equal to a run whose buffers were
+    generous from the start, bit for bit."""
+    import warnings
+    from lara_amd import rasterizer
+    act, cams = _ramp_scene()
     rs = raster_settings(cams[0], (1, 1, 1), device=DEV)
+    P = act["means3D"].shape[0]
+    ramp = [0.2, 0.5, 1.0, 2.0, 6.0, 1.0]        # scale factors: the 2.0 -> 6.0 step more than doubles the pair count
+
+    def run_ramp(factor):
+        monkeypatch.setenv("LARA2DGS_DUP_FACTOR", str(factor))
+        monkeypatch.setattr(rasterizer, "_cap_grid", lambda n: min(max(int(n), 1024), 0xFFFFFFFF))   # tiny scenes: no 2^20 floor
+        rasterizer.reset_capacity_history()
+        out = []
+        for f in ramp:
+            t = {k: v.to(DEV).clone().requires_grad_(True) for k, v in act.items()}
+            with torch.no_grad():
+                t["scales"].mul_(f)
+            color, radii, allmap = _call(rs, t)
+            (color.sum() + allmap[:2].sum()).backward()
+            torch.cuda.synchronize()
+            run = color.grad_fn.run
+            out.append((color.detach().clone(), radii.clone(), allmap.detach().clone(),
+                        {k: v.grad.clone() for k, v in t.items()}, int(run.hdrs[0][0]), run.cap))
+        return out
+
+    before = rasterizer._reruns
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tight = run_ramp(1)
+    lazy_reruns = rasterizer._reruns - before
+    generous = run_ramp(512)
+    assert rasterizer._reruns - before == lazy_reruns, "the generous run must never repeat a call"
+    assert lazy_reruns >= 2 and any("re-rendered in place" in str(x.message) for x in w)
+    Ds = [o[4] for o in tight]
+    assert max(Ds) > 16 * P and Ds[4] > 2 * Ds[3], "the ramp must leave the old 16 P behind and jump by more than 2x once"
+    for (c0, r0, a0, g0, D0, cap0), (c1, r1, a1, g1, D1, cap1) in zip(tight, generous):
+        assert D0 == D1 and D0 <= cap0 and not torch.isnan(c0).any()
+        assert torch.equal(c0, c1) and torch.equal(r0, r1) and torch.equal(a0, a1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+    # the capacity followed the measurements: after the ramp the next call of this size class gets >= 2 x the largest count
+    assert rasterizer.binning_capacity(P, 128, 128, torch.device(DEV)) >= 2 * max(Ds)
+    rasterizer.reset_capacity_history()
+
+
+def test_first_call_and_debug_calls_read_the_pair_count_synchronously(hip_lib, monkeypatch):
+    """Nothing measured yet for a size class (and `debug=True`, the reference's own switch for synchronous checking): the
+    call reads D before it returns, as the reference does on every call -- an overflow is repaired before anyone can see a
+    poisoned value, without a warning."""
+    import warnings
+    from lara_amd import rasterizer
+    act, cams = _ramp_scene()
+    monkeypatch.setenv("LARA2DGS_DUP_FACTOR", "1")
+    monkeypatch.setattr(rasterizer, "_cap_grid", lambda n: min(max(int(n), 1024), 0xFFFFFFFF))
     t = {k: v.to(DEV) for k, v in act.items()}
-    color, radii, allmap = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]),
-                                                  shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
-                                                  rotations=t["rotations"])
-    torch.cuda.synchronize()
-    assert torch.isnan(color).all() and torch.isnan(allmap).all()  # loud in the data
-    with pytest.raises(RuntimeError, match="capacity exceeded"):
-        rasterizer.check_pending(block=True)
+    ref = None
+    for debug in (False, True):
+        rasterizer.reset_capacity_history()
+        rs = raster_settings(cams[0], (1, 1, 1), device=DEV)._replace(debug=debug)
+        before = rasterizer._reruns
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            color, radii, allmap = _call(rs, t)        # first call of the class: synchronous
+            assert rasterizer._reruns == before + 1 and not rasterizer._pending
+            assert not torch.isnan(color).any()          # (no synchronisation needed: the repeat was enqueued before the return)
+            if debug:                                    # a later call, far beyond what the class has seen: still synchronous
+                big = dict(t, scales=t["scales"] * 8)
+                c2, _, _ = _call(rs, big)
+                assert rasterizer._reruns == before + 2 and not rasterizer._pending and not torch.isnan(c2).any()
+        ref = color if ref is None else ref
+        assert torch.equal(ref, color)
+    rasterizer.reset_capacity_history()
 
 
 def test_mark_visible_and_argument_errors(hip_lib):

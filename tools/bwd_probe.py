@@ -25,11 +25,11 @@ for regime in ('init', 'trained', 'fine'):  # 'fine': the opacity > 0.005 subset
             color, radii, allmap = GaussianRasterizer(rs)(means3D=act["means3D"], means2D=torch.zeros_like(act["means3D"]),
                                                           shs=act["shs"], opacities=act["opacities"],
                                                           scales=act["scales"], rotations=act["rotations"])
-            state = [t for t in color.grad_fn.saved_tensors if t is not None and t.dtype == torch.uint8 and t.numel() > 1 << 20][0]
+            run = color.grad_fn.run
             torch.autograd.backward([color, allmap], [gc, ga])
             torch.cuda.synchronize()
         P = act["means3D"].shape[0]
-        cap = rasterizer.binning_capacity(P)
+        state, cap = run.state, run.cap
         h = rasterizer.state_views(state, P, 512, 512, cap)["header"].cpu().numpy().astype('uint32')
         span = (int(h[11]) - (~int(h[10]) & 0xffffffff)) & 0xffffffff
         v = rasterizer.state_views(state, P, 512, 512, cap)

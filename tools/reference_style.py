@@ -21,7 +21,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from .rasterizer import GaussianRasterizer
+from lara_amd.rasterizer import GaussianRasterizer
 
 
 def render_img(renderer, cam, rays, centers, shs, opacity, scales, rotations, device, prex="", depth_ratio=0.0):
