@@ -93,6 +93,10 @@ def parse():
                     help="learning rate of the AdamW update inside the timed step (--step pipeline).  Default 0: every kernel of the "
                          "update runs and the parameters' version counters advance (the bf16 operand caches of the HIP modules are "
                          "rebuilt every step, as in training) while the values, and with them the synthetic workload, stay put")
+    ap.add_argument("--accumulate", type=int, default=1,
+                    help="--step pipeline: micro-batches per optimiser step.  2 = the reference's cadence (train_lightning.py:73 "
+                         "accumulate_grad_batches=2: loss / 2, DDP `no_sync()` on the first micro-batch, all-reduce + clip + AdamW on the "
+                         "second); 1 (default, the headline) reduces and updates on EVERY timed step -- the dearer definition")
     ap.add_argument("--no-optimizer", action="store_true", help="--step pipeline: forward + loss + backward only (rounds 1-3's step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -1207,8 +1211,9 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
         from lara_amd import dp
-        model = DDP(pipe, device_ids=[device.index], find_unused_parameters=True, bucket_cap_mb=dp.DDP_BUCKET_MB)   # train_lightning.py:72
+        model = DDP(pipe, device_ids=[device.index], **dp.DDP_KW)   # train_lightning.py:72
         info["grad_allreduce"] = {"bytes_per_step": 4 * n_par, "bucket_cap_MB": dp.DDP_BUCKET_MB, "buckets": None,
+                                  "gradient_as_bucket_view": True, "every_n_steps": max(1, args.accumulate),
                                   "backend": os.environ.get("LARA_BENCH_BACKEND", "nccl"),
                                   "what": "torch DistributedDataParallel over the VolTransformer + decoder parameters (fp32 master "
                                           "gradients); the encoder's backward is one autograd node per block, so a bucket's all-reduce "
@@ -1218,8 +1223,10 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     opt = None if args.no_optimizer else reference_optimizer(pipe, args.lr)
     info["optimizer"] = None if opt is None else {
         "what": "AdamW as system.py:78-106 builds it (LayerNorm parameters and biases without weight decay, betas 0.9 / 0.95, weight decay "
-                "0.05, fused multi-tensor kernels) behind clip_grad_norm_(0.5) (train_lightning.py:75), EVERY step (the reference steps every "
-                "second batch: accumulate_grad_batches=2)", "lr": args.lr, "parameters": n_par,
+                "0.05, fused multi-tensor kernels) behind clip_grad_norm_(0.5) (train_lightning.py:75), " +
+                ("EVERY step (the reference steps every second batch: accumulate_grad_batches=2; --accumulate 2 runs that cadence)"
+                 if args.accumulate <= 1 else f"every {args.accumulate} steps (train_lightning.py:73), loss / {args.accumulate}, DDP no_sync() in between"),
+        "lr": args.lr, "parameters": n_par, "accumulate_grad_batches": max(1, args.accumulate),
         "note": "lr 0: all of the update's kernels run and every parameter's version advances, so the HIP modules re-derive their bf16 / "
                 "transposed operands each step as they do in training; the values stay, so all K steps time the same synthetic workload"}
 
@@ -1236,13 +1243,24 @@ def make_pipeline_step(args, device, rank, world, plumbing):
         feat_vol.grad = None
     info["update"] = update
     info["opt"] = opt
+    info["model"] = model
 
-    def full_step(ms_ssim=args.ms_ssim):
-        out = model(batch, feat_vol, with_fine=with_fine)
-        loss, _ = lara_loss(batch, out, 2000, ms_ssim=ms_ssim)       # past iteration 1000: distortion + normal terms are on (loss.py:48)
-        loss.backward()
+    info["micro_batch"] = 0
+
+    def full_step(ms_ssim=args.ms_ssim, model=None, accumulate=None):
+        model = info.get("model") if model is None else model
+        acc = max(1, args.accumulate if accumulate is None else accumulate)
+        last = info["micro_batch"] % acc == acc - 1      # train_lightning.py:73: reduce + update on every acc-th micro-batch
+        info["micro_batch"] += 1
+        with (model.no_sync() if (not last and hasattr(model, "no_sync")) else contextlib.nullcontext()):
+            out = model(batch, feat_vol, with_fine=with_fine)
+            loss, _ = lara_loss(batch, out, 2000, ms_ssim=ms_ssim)       # past iteration 1000: distortion + normal terms are on (loss.py:48)
+            (loss if acc == 1 else loss / acc).backward()
         pipe.join_streams()
-        update()
+        if last:
+            update()
+        else:
+            feat_vol.grad = None
         if poison:      # debugging mode: every state / scratch buffer 0xFF-filled between guard zones; checked (and released) per step
             bad = rasterizer.check_poison_guards()
             if bad:
@@ -1281,28 +1299,45 @@ def ddp_single_rank_leg(info, args, device):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     try:
-        model = DDP(pipe, device_ids=[device.index], find_unused_parameters=True, bucket_cap_mb=dp.DDP_BUCKET_MB)
-
-        def one():
-            loss, _ = lara_loss(batch, model(batch, feat_vol, with_fine=not args.no_fine), 2000, ms_ssim=False)
-            loss.backward()
-            pipe.join_streams()
-            info["update"]()
-        for _ in range(3):
-            one()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.steps
+        model = DDP(pipe, device_ids=[device.index], **dp.DDP_KW)
+        full_step = info["pipeline"][3]
+        res = {}
+        for name, acc in (("every_step", 1), ("accumulate_2", 2)):
+            info["micro_batch"] = 0
+            for _ in range(4):
+                full_step(ms_ssim=False, model=model, accumulate=acc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps + args.steps % acc):
+                full_step(ms_ssim=False, model=model, accumulate=acc)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / (args.steps + args.steps % acc)
+            res[name] = {"ms_per_step": round(1e3 * dt, 3), "value": round(info["frames_per_rank_step"] / dt, 3)}
+        # the same two cadences WITHOUT the wrapper, back to back on the same box: the local cost of the exchange step is the difference
+        for name, acc in (("every_step", 1), ("accumulate_2", 2)):
+            info["micro_batch"] = 0
+            for _ in range(2):
+                full_step(ms_ssim=False, model=pipe, accumulate=acc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps + args.steps % acc):
+                full_step(ms_ssim=False, model=pipe, accumulate=acc)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / (args.steps + args.steps % acc)
+            res[name]["ms_per_step_without_ddp"] = round(1e3 * dt, 3)
+            res[name]["ddp_overhead_ms"] = round(res[name]["ms_per_step"] - 1e3 * dt, 3)
+        info["micro_batch"] = 0
         try:
             sizes = [int(x) for x in str(model._get_ddp_logging_data().get("bucket_sizes", "")).split(",") if x.strip()]
         except Exception:
             sizes = None
-        return {"ms_per_step": round(1e3 * dt, 3), "value": round(info["frames_per_rank_step"] / dt, 3), "unit": "frames/s", "buckets": sizes,
-                "what": "the same step wrapped in DistributedDataParallel, backend nccl (RCCL), world size 1: reducer hooks, bucket copies "
-                        "and one-member all-reduces included"}
+        return {"ms_per_step": res["every_step"]["ms_per_step"], "value": res["every_step"]["value"], "unit": "frames/s", "buckets": sizes,
+                "every_step": res["every_step"], "accumulate_2": res["accumulate_2"], "gradient_as_bucket_view": True,
+                "what": "the same step wrapped in DistributedDataParallel, backend nccl (RCCL), world size 1: reducer hooks, gradients "
+                        "written straight into the buckets (gradient_as_bucket_view) and one-member all-reduces included; `every_step` "
+                        "reduces and updates on every micro-batch (the headline's definition), `accumulate_2` is the reference's cadence "
+                        "(train_lightning.py:73: no_sync() on the first micro-batch, all-reduce + clip + AdamW on the second); "
+                        "`ddp_overhead_ms` = against the same cadence without the wrapper, same box, back to back"}
     finally:
         dist.destroy_process_group()
 
@@ -1388,7 +1423,8 @@ class _PlumbingEncoder(torch.nn.Module):
 def make_training_step(args, device, rank, world, plumbing):
     """Returns (full_step, info): the per-rank step described in the module docstring."""
     info = {"grad_allreduce": None, "encoder": None}
-    ddp_kw = dict(find_unused_parameters=True, bucket_cap_mb=25)     # train_lightning.py:72 + torch's default bucket
+    from lara_amd import dp as _dp
+    ddp_kw = dict(_dp.DDP_KW)     # train_lightning.py:72 + torch's default bucket, gradients as bucket views
     if plumbing:
         torch.manual_seed(0)
         enc = _PlumbingEncoder().to(device)
@@ -1805,6 +1841,25 @@ def main():
             roof["valu_useful_frac"] = round(pairs * USEFUL_FMA_PER_PAIR[roof["kernel"]] / (roof["valu_insts_per_launch"] * 64.0), 4)
             roof["valu_useful_what"] = (f"{pairs} blended (pixel, splat) pairs of view 0 (counted by the CPU oracle in this run) x "
                                         f"{USEFUL_FMA_PER_PAIR[roof['kernel']]} FMA-equivalents / (SQ_INSTS_VALU x 64 lanes: {roof['valu_insts_source']})")
+    # the north star's second target (attention / encoder on the matrix cores) inside `roofline`, where a reader who keeps only
+    # `roofline` and `cpu_baseline` of the line still finds it (the stand-alone objects stay for their details)
+    roof = out.get("roofline")
+    if roof is not None:
+        mf = {}
+        for key in ("attention", "encoder", "encoder_train"):
+            o = out.get(key)
+            if isinstance(o, dict) and "frac" in o:
+                mf[key] = {"bound": "mfma", "achieved": o.get("achieved"), "peak": o.get("peak"), "unit": o.get("unit"), "frac": o.get("frac"),
+                           **{k: o[k] for k in ("us_per_layer", "ms_per_forward", "ms_per_step", "conv3d_us", "conv3d_TFLOPs") if k in o}}
+        if mf:
+            roof["mfma"] = mf
+            roof["mfma_what"] = ("the encoder's kernels against the dense bf16 matrix-core peak (2.5 PFLOP/s): `attention` = one GroupAttBlock "
+                                 "attention step (network.py:88-93), `encoder` / `encoder_train` = VolTransformer forward / forward + backward; "
+                                 "model FLOPs / HIP-event time")
+        if roof.get("valu_issue_frac") is not None and roof.get("valu_useful_frac") is not None:
+            roof["valu_roof_frac"] = round(float(roof["valu_issue_frac"]) * float(roof["valu_useful_frac"]), 4)
+            roof["valu_roof_what"] = ("the roof that binds the dominant kernel: vector-ALU issue slots used (valu_issue_frac) x the share of "
+                                      "issued lane-operations that are the algorithm's own arithmetic (valu_useful_frac)")
     if world > 1:
         dist.destroy_process_group()
     sys.stdout.flush()

@@ -119,15 +119,19 @@ def explain_contrib_mismatches(ref, n_contrib_hip, W, tol_alpha=1e-3, tol_T=5e-3
             # (T at list position n is a product of n factors, each off by a few ulp between the two implementations: the T
             # thresholds get 1e-6 per position on top of the one-alpha-flip allowance -- 3e-3 at the 3000th entry of a
             # full-size list, nothing at the tens of entries of the small cases)
+            # every entry IN FRONT of the two answers whose alpha sits on the 1/255 threshold may have been blended by one side
+            # only: each such flip moves all later T by a factor 1 - 1/255 (tol_T covers one; a 2 000-entry list of a 1024^2
+            # frame can hold two)
+            flips_before = int((w["alpha"][:lo0] <= tol_alpha).sum())
             if ma <= tol_alpha:
                 out["by_alpha_flip"] += 1
                 out["worst_alpha_margin"] = max(out["worst_alpha_margin"], ma)
-            elif mt <= tol_T + 1e-6 * hi:
+            elif mt <= tol_T + 1e-6 * hi + max(flips_before - 1, 0) / 255.0:
                 out["by_T_flip"] += 1
                 out["worst_T_margin"] = max(out["worst_T_margin"], mt)
             else:
                 ok = False
                 out["unexplained_detail"].append({"px": int(px), "py": int(py), "channel": ch, "hip": a, "oracle": b,
-                                                  "min_alpha_margin": ma, "min_T_margin": mt})
+                                                  "min_alpha_margin": ma, "min_T_margin": mt, "alpha_flips_in_front": flips_before})
         out["unexplained"] += 0 if ok else 1
     return out

@@ -5,7 +5,10 @@ scene streams), held to the same bars as the small cases:
   of `ckpt` / `pair_mask` and the one-launch `preprocess_bwd_views` fold only meet their real sizes here) against the
   per-view operator: outputs and summed gradients bit for bit, one view against the CPU oracle;
 * `LaRaPipeline` (lightning/network.py:473-527) with two scene streams against one stream over 50 training steps whose
-  fine subsets change size every step.
+  fine subsets change size every step;
+* the two other BASELINE configurations at their real size (round 5): the "trained-like" regime of SURVEY section 8d (the
+  one the second bench line is quoted on) through the multi-view launch, and configs[4]'s 1024 x 1024 eval views over all
+  524 288 surfels (D ~ 6 M pairs) through the per-view operator -- forward surface and gradients against the oracle.
 """
 import os
 
@@ -62,6 +65,90 @@ def test_multi_view_launch_at_benchmark_size_equals_the_per_view_operator_and_th
     D = _check_forward(r, run_oracle(oracle_view(cams[v], bgs[v]), to_numpy(act)), S, S)
     assert 1_000_000 < D < 3_000_000
     rasterizer.check_pending(block=True)
+
+
+def test_trained_like_regime_at_benchmark_size_multi_view_launch_against_the_oracle(hip_lib):
+    """SURVEY section 8d's second regime (opaque thin shell, everything else transparent: pixels saturate after tens of
+    surfels, most backward work items end on `tile_maxc`, the work items differ widely in cost) at P = 524 288 / 8 views /
+    512^2, through the multi-view launch: one view's integer surface, images and contributor records against the oracle, and
+    its gradients -- the upstream gradients of the other seven views are zero, so the call's summed gradient IS that view's --
+    under the full-size gradient bar."""
+    from lara_amd import cameras, rasterize_gaussians_views, rasterizer, synthetic
+    from tests.test_raster_parity_gpu import _check_forward, oracle_conditioned_gradient_check
+    P, n, S, v = 524288, 8, 512, 6
+    act = synthetic.activate(synthetic.make_scene(grid=64, K=2, seed=0, regime="trained"))
+    cams = cameras.make_cameras(cameras.turntable_c2w(n), S, S, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8)
+    bgs = [(1.0, 1.0, 1.0)] * 4 + [(0.0, 0.0, 0.0), (0.5, 0.5, 0.5), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)]   # gobjverse.py:103-106
+    settings = [raster_settings(c, bg, device=DEV) for c, bg in zip(cams, bgs)]
+    g = np.random.default_rng(3)
+    dc = g.normal(size=(3, S, S)).astype(np.float32)
+    da = (0.1 * g.normal(size=(7, S, S))).astype(np.float32)
+    gc = torch.zeros(n, 3, S, S, device=DEV); gc[v] = torch.from_numpy(dc).to(DEV)
+    ga = torch.zeros(n, 7, S, S, device=DEV); ga[v] = torch.from_numpy(da).to(DEV)
+    inp = {k: t.to(DEV).clone().requires_grad_(True) for k, t in act.items()}
+    color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+    run = color.grad_fn.run
+    ((color * gc).sum() + (allmap * ga).sum()).backward()
+    torch.cuda.synchronize()
+    state, (sb, _), cap = run.state, run.extra, run.cap
+    views = rasterizer.state_views(state.view(n, sb)[v], P, S, S, cap)
+    r = {"views": views, "radii": radii[v], "color": color[v].detach(), "allmap": allmap[v].detach()}
+    D = _check_forward(r, run_oracle(oracle_view(cams[v], bgs[v]), to_numpy(act)), S, S)
+    assert 1_000_000 < D < 3_000_000
+    # the regime is what it claims: the walk ends early almost everywhere inside the silhouette
+    nc = views["n_contrib"][0].cpu().numpy()
+    lens = (views["ranges"][:, 1] - views["ranges"][:, 0]).cpu().numpy().reshape(S // 16, S // 16)
+    inside = allmap[v, 1].detach().cpu().numpy() > 0.99
+    lens_px = np.repeat(np.repeat(lens, 16, 0), 16, 1)
+    assert inside.mean() > 0.1 and (nc[inside] < lens_px[inside]).mean() > 0.95 and np.median(nc[inside]) < 0.75 * np.median(lens_px[inside])
+    rep = oracle_conditioned_gradient_check(to_numpy(act), cams[v], bgs[v], dc, da, {k: t.grad.cpu().numpy() for k, t in inp.items()})
+    print("trained-like, full size, view %d: D = %d; (rel-L2 HIP, rel-L2 oracle +1ulp, surfels > 1e-3 HIP, oracle): %s" % (
+        v, D, {k: (round(a, 6), round(b, 6), c, d) for k, (a, b, c, d) in rep.items()}))
+    rasterizer.check_pending(block=True)
+
+
+def test_eval_resolution_at_full_surfel_count_against_the_oracle(hip_lib):
+    """BASELINE.json configs[4] at its real size: a 1024 x 1024 novel view (4096 tiles) of all 524 288 surfels, as
+    `eval_all.py` / the mesh extractor render them -- D = 3.1 M (tile, surfel) pairs, twice the training frame's, ~4 k full
+    backward segments.  The per-view operator (what `render_img` calls), forward surface and gradients against the oracle.
+    The frame sits at the very top of the capacity a new size class starts from (4 pairs per quantised surfel -> 3 Mi pairs;
+    rounds 1-4 ran such a frame -- more than half the capacity -- with unsegmented backward tiles): the first call of the class
+    reads D before it returns, and repeats itself if it has to (rasterizer.py, workspace policy)."""
+    from lara_amd import GaussianRasterizer, cameras, rasterizer, synthetic
+    from tests.test_raster_parity_gpu import _check_forward, oracle_conditioned_gradient_check
+    rasterizer.reset_capacity_history()
+    P, S = 524288, 1024
+    act = synthetic.activate(synthetic.make_scene(grid=64, K=2, seed=0))
+    cam = cameras.make_cameras(cameras.turntable_c2w(8)[5:6], S, S, 0.75, 0.75, 0.5, 2.5)[0]     # GSO near / far (google_scanned_objects.py:114)
+    bg = (1.0, 1.0, 1.0)
+    g = np.random.default_rng(4)
+    dc = g.normal(size=(3, S, S)).astype(np.float32)
+    da = (0.1 * g.normal(size=(7, S, S))).astype(np.float32)
+    inp = {k: t.to(DEV).clone().requires_grad_(True) for k, t in act.items()}
+    reruns = rasterizer._reruns
+    color, radii, allmap = GaussianRasterizer(raster_settings(cam, bg, device=DEV))(
+        means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]), shs=inp["shs"], opacities=inp["opacities"],
+        scales=inp["scales"], rotations=inp["rotations"])
+    run = color.grad_fn.run
+    assert run.done, "the first call of a size class settles its capacity before it returns"
+    ((color * torch.from_numpy(dc).to(DEV)).sum() + (allmap * torch.from_numpy(da).to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    views = rasterizer.state_views(run.state, P, S, S, run.cap)
+    r = {"views": views, "radii": radii, "color": color.detach(), "allmap": allmap.detach()}
+    D = _check_forward(r, run_oracle(oracle_view(cam, bg), to_numpy(act)), S, S)
+    assert D > 2_500_000 and run.cap >= D > run.cap // 2 and int(views["header"][3]) > 2500      # pairs; full 512-entry segments
+    assert rasterizer._reruns - reruns == (1 if D > rasterizer.binning_capacity(P) else 0)
+    assert np.array_equal(views["seg_cnt"].cpu().numpy(), np.maximum(ranges_len(views) - 1, 0) // 512), "every tile keeps its segments"
+    rep = oracle_conditioned_gradient_check(to_numpy(act), cam, bg, dc, da, {k: t.grad.cpu().numpy() for k, t in inp.items()})
+    print("1024^2, P = 524 288: D = %d, capacity %d; (rel-L2 HIP, rel-L2 oracle +1ulp, surfels > 1e-3 HIP, oracle): %s" % (
+        D, run.cap, {k: (round(a, 6), round(b, 6), c, d) for k, (a, b, c, d) in rep.items()}))
+    rasterizer.reset_capacity_history()
+
+
+def ranges_len(views):
+    rg = views["ranges"].cpu().numpy().astype(np.int64)
+    return rg[:, 1] - rg[:, 0]
 
 
 def _full_size_pipeline(dev, layers=2):

@@ -88,7 +88,9 @@ def _check_forward(r, ref, H, W):
     nc = views["n_contrib"].cpu().numpy().view(np.uint32)
     ex = explain_contrib_mismatches(ref, nc, W)
     _CONTRIB_LOG.append({"HxW": f"{H}x{W}", "D": D, **ex})
-    assert ex["unexplained"] == 0, ex
+    if ex["unexplained"]:
+        print("unexplained contributor mismatches:", ex["unexplained_detail"])
+    assert ex["unexplained"] == 0, ex["unexplained_detail"]
     assert ex["mismatching_pixels"] <= 1e-3 * H * W, ex
     return D
 
@@ -571,33 +573,22 @@ def test_full_size_properties_and_oracle(hip_lib):
         assert float((lin - z).abs().max()) <= 1e-3 * float(z.abs().max())
 
 
-def test_full_size_gradients_within_the_oracles_own_conditioning(hip_lib):
-    """BASELINE.json size, gradients: with 524 288 surfels a handful are steep, large and nearly edge-on -- their
-    alpha is ill-conditioned in fp32 and the fp32 oracle's OWN gradient moves by percent of max when every input
-    moves by one ulp.  So the yardstick at this size is that sensitivity: the HIP-vs-oracle difference (L2 and
-    number of surfels beyond 1e-3 of max) must not exceed the oracle-vs-perturbed-oracle difference by more than
-    3x (measured 0.3-2x: tools/grad_probe.py), on top of an absolute bound of 2e-2 relative L2."""
-    from lara_amd import GaussianRasterizer, synthetic, cameras
-    act = synthetic.activate(synthetic.make_scene(grid=64, K=2, seed=0))
-    cam = cameras.make_cameras(cameras.turntable_c2w(8)[0:1], 512, 512, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8)[0]
-    bg = (1.0, 1.0, 1.0)
-    g = np.random.default_rng(0)
-    dc = g.normal(size=(3, 512, 512)).astype(np.float32)
-    da = (0.1 * g.normal(size=(7, 512, 512))).astype(np.float32)
-    a0 = to_numpy(act)
+def oracle_conditioned_gradient_check(a0, cam, bg, dc, da, hip_grads):
+    """Gradients at BASELINE size.  With 524 288 surfels a handful are steep, large and nearly edge-on -- their alpha is
+    ill-conditioned in fp32 and the fp32 oracle's OWN gradient moves by percent of max when every input moves by one ulp.
+    So the yardstick at this size is that sensitivity: the HIP-vs-oracle difference (L2 and number of surfels beyond 1e-3 of
+    max) must not exceed the oracle-vs-perturbed-oracle difference by more than 3x (measured 0.3-2x: tools/grad_probe.py),
+    on top of an absolute bound of 2e-2 relative L2.  (Arbitrated against fp64: tests/test_grad_arbitration_gpu.py.)
+    `a0`: numpy inputs; `hip_grads`: {name: numpy gradient}."""
     rng = np.random.default_rng(1)
     a1 = {k: (v * (1 + (rng.integers(0, 2, v.shape) * 2 - 1) * 2.0 ** -23)).astype(np.float32) for k, v in a0.items()}
     g0 = oracle.backward(run_oracle(oracle_view(cam, bg), a0), dc, da)
     g1 = oracle.backward(run_oracle(oracle_view(cam, bg), a1), dc, da)
-    inp = {k: val.to(DEV).requires_grad_(True) for k, val in act.items()}
-    color, _, allm = GaussianRasterizer(raster_settings(cam, bg, device=DEV))(
-        means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]), shs=inp["shs"], opacities=inp["opacities"],
-        scales=inp["scales"], rotations=inp["rotations"])
-    ((color * torch.from_numpy(dc).to(DEV)).sum() + (allm * torch.from_numpy(da).to(DEV)).sum()).backward()
+    report = {}
     for k in ("means3D", "opacities", "scales", "rotations", "shs"):
         ref = g0[k].astype(np.float64)
         P = ref.shape[0]
-        hip = inp[k].grad.cpu().numpy().reshape(ref.shape).astype(np.float64)
+        hip = hip_grads[k].reshape(ref.shape).astype(np.float64)
         per = g1[k].astype(np.float64)
         nrm, mx = np.sqrt((ref ** 2).sum()), np.abs(ref).max()
         l2_hip, l2_per = np.sqrt(((hip - ref) ** 2).sum()) / nrm, np.sqrt(((per - ref) ** 2).sum()) / nrm
@@ -606,6 +597,25 @@ def test_full_size_gradients_within_the_oracles_own_conditioning(hip_lib):
         assert np.isfinite(hip).all()
         assert l2_hip <= 2e-2 and l2_hip <= 3 * l2_per + 1e-4, (k, l2_hip, l2_per)
         assert n_hip <= 3 * n_per + 8, (k, n_hip, n_per)
+        report[k] = (l2_hip, l2_per, n_hip, n_per)
+    return report
+
+
+def test_full_size_gradients_within_the_oracles_own_conditioning(hip_lib):
+    """BASELINE.json size, init regime, 512^2, the per-view operator."""
+    from lara_amd import GaussianRasterizer, synthetic, cameras
+    act = synthetic.activate(synthetic.make_scene(grid=64, K=2, seed=0))
+    cam = cameras.make_cameras(cameras.turntable_c2w(8)[0:1], 512, 512, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8)[0]
+    bg = (1.0, 1.0, 1.0)
+    g = np.random.default_rng(0)
+    dc = g.normal(size=(3, 512, 512)).astype(np.float32)
+    da = (0.1 * g.normal(size=(7, 512, 512))).astype(np.float32)
+    inp = {k: val.to(DEV).requires_grad_(True) for k, val in act.items()}
+    color, _, allm = GaussianRasterizer(raster_settings(cam, bg, device=DEV))(
+        means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]), shs=inp["shs"], opacities=inp["opacities"],
+        scales=inp["scales"], rotations=inp["rotations"])
+    ((color * torch.from_numpy(dc).to(DEV)).sum() + (allm * torch.from_numpy(da).to(DEV)).sum()).backward()
+    oracle_conditioned_gradient_check(to_numpy(act), cam, bg, dc, da, {k: v.grad.cpu().numpy() for k, v in inp.items()})
 
 
 def test_quad_reduce_scatter_selftest(hip_lib):

@@ -27,7 +27,7 @@ ap.add_argument("--top", type=int, default=70)
 a = ap.parse_args()
 args = argparse.Namespace(gpus=1, steps=3, warmup=1, scenes=4, views=8, res=512, grid=64, regime="init", step="pipeline",
                           no_fine=False, encoder_layers=12, raster_api="views", streams=1, no_cpu_baseline=True, no_roofline=True,
-                          no_side_legs=True, fine_mask="reference")
+                          no_side_legs=True, fine_mask="reference", lr=0.0, ms_ssim=False, no_optimizer=False, accumulate=1)
 dev = torch.device("cuda:0")
 full_step, info = bench.make_pipeline_step(args, dev, 0, 1, False)
 for _ in range(3):

@@ -86,7 +86,7 @@ def network_forward(pipe, batch, feat_vol, with_fine=True):
     """`Network.forward` from the image-feature volume on (network.py:455-532) the way the reference issues it; `pipe` is a
     `LaRaPipeline` (its encoder, decoder and constants).  The encoder stays `pipe.vol_decoder` (this package's HIP
     VolTransformer or the reference's module, whichever the pipeline holds); everything behind it is the reference's sequence."""
-    from .pipeline import check_mask, decode_coarse
+    from lara_amd.pipeline import check_mask, decode_coarse
     vol = pipe.vol_decoder(feat_vol)
     offset, shs, scaling, rotation, opacity = decode_coarse(pipe.decoder, vol, pipe.opacity_shift, pipe.scaling_shift, autocast=True)
     if pipe.opacity_bias is not None:
