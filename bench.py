@@ -1578,7 +1578,7 @@ def main():
         "data": "synthetic" if not plumbing else "PLUMBING SELF-TEST (no GPU work; not a measurement)",
         "config": {
             "workload": (
-                (f"configs[2]: the whole data-dependent LaRa training step (lightning/network.py:455-532 + loss.py {'WITH its MS-SSIM term (torch operators)' if args.ms_ssim else 'minus MS-SSIM'}), per GPU "
+                (f"configs[2]: the whole data-dependent LaRa training step (lightning/network.py:455-532 + loss.py {'WITH its MS-SSIM term' if args.ms_ssim else 'minus MS-SSIM'}), per GPU "
                  f"{args.scenes} scenes: VolTransformer ({enc['layers']} layers, {enc['parameters'] / 1e6:.2f} M parameters) -> coarse decoder MLP "
                  f"-> {args.views} coarse views/scene -> " + ("" if args.no_fine else f"_check_mask ({args.fine_mask}) -> point sampler on 4 input views -> "
                  f"forward_fine -> {args.views} fine views/scene -> ") + f"loss -> ONE backward through all of it"
@@ -1620,8 +1620,9 @@ def main():
         d1 = time.perf_counter() - t1
         out["step_with_ms_ssim"] = {"value": round(frames_per_step * args.steps / d1, 3), "unit": "frames/s",
                                     "ms_per_step": round(1e3 * d1 / args.steps, 3),
-                                    "what": "the headline step + 0.5 (1 - MS_SSIM) for the coarse and the fine image (lara_amd.loss.ms_ssim: "
-                                            "torch matmul / pooling operators, fp32, no HIP kernel of this repo)"}
+                                    "what": "the headline step + 0.5 (1 - MS_SSIM) for the coarse and the fine image = the reference's whole loss "
+                                            "(loss.py:28-58); the MS-SSIM term as HIP kernels (lara_amd.loss.ms_ssim_fused, csrc/msssim.hip; "
+                                            "rounds 3-4: torch operators, +31 ms)"}
     if solo and args.step == "pipeline" and not args.no_side_legs and info.get("optimizer") is not None and args.lr == 0.0:
         # The same step with the reference's learning rate (configs/base.yaml: 4e-4) instead of 0: the parameters now MOVE, i.e. the
         # Gaussians the network emits -- and with them the raster's workload -- drift from step to step; the figure shows that the

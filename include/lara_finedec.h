@@ -24,9 +24,10 @@
  * reference permutes it to [n,4,8] with an einsum, network.py:515); sh [n,12].
  *
  * Backward: d_sh [n,12] -> d_xn [n,80], d_pf [4][8][n], plus the four per-point factor arrays the weight gradients are
- * GEMMs of (caller allocates [n,64] each; the wrapper runs the GEMMs with the library BLAS):
+ * products of over the point axis (caller allocates [n,64] each):
  *     U, HID (post-ReLU), DH = dL/d(pre-ReLU), DT = dL/dt:
- *     dWqk = DT^T xn,  dW1ov = DH^T U,  db1 = colsum(DH),  dW2 = d_sh^T HID,  db2 = colsum(d_sh).
+ *     dWqk = DT^T xn,  dW1ov = DH^T U,  db1 = colsum(DH),  dW2 = d_sh^T HID,  db2 = colsum(d_sh)
+ * -- lara_fine_decoder_wgrad below (fp32 matrix-core products over 512-row slabs + an ordered sum: reproducible).
  * Returns 0 or a negative LARA2DGS_E_* code; work is enqueued on `stream`, no host synchronisation.
  * Only the reference's sizes are built (80 / 8 heads x 10 / 4 views x 8 channels / 64 / 12).
  */
@@ -45,6 +46,13 @@ int lara_fine_decoder_forward(int32_t n, const float *xn, const float *pf, const
 int lara_fine_decoder_backward(int32_t n, const float *xn, const float *pf, const float *Wqk, const float *W1ov,
                                const float *b1, const float *W2, const float *b2, const float *d_sh, float *d_xn,
                                float *d_pf, float *U, float *HID, float *DH, float *DT, void *stream);
+
+/* The five parameter gradients from the factor arrays the backward left: out = [dWqk 64x80 | dW1ov 64x64 | db1 64 | dW2 12x64 |
+ * db2 12] (lara_fine_wgrad_floats() = 10 060 floats, fully overwritten); workspace: lara_fine_decoder_wgrad_workspace_bytes(n). */
+int32_t lara_fine_wgrad_floats(void);
+int64_t lara_fine_wgrad_workspace_bytes(int32_t n);
+int lara_fine_decoder_wgrad(int32_t n, const float *xn, const float *U, const float *HID, const float *DH, const float *DT,
+                            const float *d_sh, float *out, void *workspace, void *stream);
 
 /* The LayerNorm in front (network.py:281, `self.norm`): rows of 80 features are too short for torch's row-per-
  * workgroup kernels (0.55 ms forward / 0.9 ms backward for 524 288 rows); here one thread owns a row.

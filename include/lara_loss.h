@@ -40,6 +40,35 @@ int lara_loss_terms_backward(int32_t B, int32_t V, int32_t H, int32_t W, const f
                              const float *acc_map, const float *g_terms, float *d_image, float *d_image_fine,
                              float *d_rend_dist, float *d_rend_normal, float *d_depth_normal, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * The MS-SSIM term (lightning/loss.py:15, :42-45: `0.5 * (1 - MS_SSIM(data_range=1.0, size_average=True, channel=3)(img, tar))`),
+ * forward and backward, on the images where they lie.  `pytorch_msssim` is a third-party dependency absent from /root/reference
+ * and from this image (version not pinned by the reference): the algorithm is restated from its published form in
+ * oracle/msssim_ref.py (five scales, 11-tap sigma-1.5 Gaussian 'valid' filters, K = (0.01, 0.03), 2 x 2 average pooling with odd
+ * sides padded) -- PARITY UNPINNED by the reference; the kernels are held to that restatement.
+ *
+ * An image batch is addressed through a view: value(n, c, y, x) = p[n sN + c sC + y sY + (x / Wv) sV + (x % Wv) sX] (element
+ * strides), which covers the renderer's side-by-side output [B, H, V*W, 3] (sN = H V W 3, sC = 1, sY = V W 3, sV = W 3, sX = 3,
+ * Wv = W), the targets [B, V, H, W, 3] seen side by side (sN = V H W 3, sC = 1, sY = W 3, sV = H W 3, sX = 3, Wv = W) and
+ * planar [N, C, H, W] tensors (sV = 0, Wv = W): no permuted copies.
+ *
+ * forward : means[5][N*C][2] = per scale and (image, channel) the mean of the SSIM map and of its contrast-structure factor.
+ *           MS-SSIM = mean over (n, c) of prod_l relu(m_l)^w_l with m_l = cs mean (l < 4) / ssim mean (l = 4): five numbers per
+ *           image and channel, combined by the caller (torch, with autograd).
+ * backward: d_means (same shape) -> dX through the view `dX` (fully overwritten; Y is a target and gets no gradient).
+ * `workspace` (lara_ms_ssim_workspace_floats floats) carries the pooled pyramid from forward to backward.  `window11`: the 11
+ * filter taps (HOST pointer).  Requires min(H, W) > 160.  Work is enqueued on `stream`; no atomics (reproducible). */
+typedef struct lara_image_view {
+    float *p;
+    int64_t sN, sC, sY, sV, sX;
+    int32_t Wv;
+} lara_image_view;
+int64_t lara_ms_ssim_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W);
+int lara_ms_ssim_forward(int32_t N, int32_t C, int32_t H, int32_t W, const lara_image_view *X, const lara_image_view *Y,
+                         const float *window11, float *means, float *workspace, void *stream);
+int lara_ms_ssim_backward(int32_t N, int32_t C, int32_t H, int32_t W, const lara_image_view *X, const lara_image_view *Y,
+                          const float *window11, const float *d_means, const lara_image_view *dX, float *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

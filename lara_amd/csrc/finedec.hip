@@ -427,6 +427,132 @@ fine_ln_bwd_kernel(const int n, const float *__restrict__ x_g, const float *__re
             ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
 
+// ---- the five parameter gradients of the folded decoder: products of the factor arrays over the point axis ------------------
+//   dWqk [64,80] = DT^T xn,  dW1ov [64,64] = DH^T U,  db1 [64] = colsum(DH),  dW2 [12,64] = d_sh^T HID,  db2 [12] = colsum(d_sh)
+// (rounds 2-4 ran them through the BLAS library as batched GEMMs over 1024-row slabs + torch reductions: 79 launches and 1.1 ms
+// per step of someone else's kernels on a path that claims its own).  Reductions over n = 10^5..10^6 rows with 12..80 columns on
+// either side are streams, not GEMMs: a workgroup of two waves takes a slab of FW_SLAB rows -- wave 0 dWqk, wave 1 the rest -- on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products and sums) with the operands straight from global memory: the instruction wants
+// A[i = lane % 32][k = lane / 32] = X[row + lane / 32][i], so a half-wave reads ONE row, and since the order of the rows / columns
+// of an outer product is free, lane c fetches 2 or 4 CONSECUTIVE columns with one 8- / 16-byte load and feeds component e to the
+// e-th MFMA block (block e then holds columns {2c + e} / {4c + e}): whole rows per instruction instead of 128-byte pieces
+// (the first version, one dword per lane and block, streamed at 2.1 TB/s).  A second launch adds the slabs in a fixed order (no
+// atomics: reproducible).
+constexpr int FW_SLAB = 512;
+constexpr int FW_OUT = 64 * 80 + 64 * 64 + 64 + 12 * 64 + 12;     // floats per slab: dWqk | dW1ov | db1 | dW2 | db2
+constexpr int FW_O_W1 = 64 * 80, FW_O_B1 = FW_O_W1 + 64 * 64, FW_O_W2 = FW_O_B1 + 64, FW_O_B2 = FW_O_W2 + 12 * 64;
+
+// acc[ea][eb] holds out[AV * rA + ea][BV * cB + eb] with rA = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), cB = lane & 31
+template <int AV, int BV>
+__device__ __forceinline__ void fw_store(float *__restrict__ out, const int ldo, const int i_rows, const int j_cols, const int lane,
+                                         const f32x16 (&acc)[AV][BV]) {
+    const int cB = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int ea = 0; ea < AV; ea++)
+#pragma unroll
+        for (int eb = 0; eb < BV; eb++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int i = AV * ((e & 3) + 8 * (e >> 2) + 4 * kh) + ea, j = BV * cB + eb;
+                if (i < i_rows && j < j_cols) out[(size_t)i * ldo + j] = acc[ea][eb][e];
+            }
+}
+
+__global__ void __launch_bounds__(128)
+fine_wgrad_kernel(const int n, const float *__restrict__ xn, const float *__restrict__ U, const float *__restrict__ HID_,
+                  const float *__restrict__ DH, const float *__restrict__ DT, const float *__restrict__ d_sh,
+                  float *__restrict__ part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * FW_SLAB, rows = min(FW_SLAB, n - row0);
+    float *out = part + (size_t)blockIdx.x * FW_OUT;
+    const int kk = lane >> 5, c = lane & 31;
+    constexpr int UN = 4;      // K steps (of two rows) whose loads are in flight together
+    if (wave == 0) {           // dWqk: A = DT (64 columns: float2 per lane), B = xn (80 columns: float4 per lane, lanes c < 20)
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[a][b][e] = 0.f;
+        const bool b_ok = c < FD / 4;
+        for (int r = 0; r < rows; r += 2 * UN) {
+            float2 av[UN];
+            float4 bv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const int rr = r + 2 * u + kk;
+                const bool in = rr < rows;
+                av[u] = in ? *(const float2 *)(DT + (size_t)(row0 + rr) * 64 + 2 * c) : make_float2(0.f, 0.f);
+                bv[u] = (in && b_ok) ? *(const float4 *)(xn + (size_t)(row0 + rr) * FD + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const float a2[2] = {av[u].x, av[u].y}, b4[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) acc[a][b] = mfma2(a2[a], b4[b], acc[a][b]);
+            }
+        }
+        fw_store<2, 4>(out, FD, 64, FD, lane, acc);
+    } else {                   // dW1ov + db1 (A = DH, B = U: float2 each) and dW2 + db2 (A = d_sh: one float, lanes c < 12; B = HID: float2)
+        f32x16 acc1[2][2], acc2[1][2];
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) { acc1[0][b][e] = 0.f; acc1[1][b][e] = 0.f; acc2[0][b][e] = 0.f; }
+        float cs1x = 0.f, cs1y = 0.f, cs2 = 0.f;
+        const bool s_ok = c < SH;
+        for (int r = 0; r < rows; r += 2 * UN) {
+            float2 dh[UN], uu[UN], hh[UN];
+            float ds[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const int rr = r + 2 * u + kk;
+                const bool in = rr < rows;
+                const size_t row = (size_t)(row0 + rr);
+                dh[u] = in ? *(const float2 *)(DH + row * HID + 2 * c) : make_float2(0.f, 0.f);
+                uu[u] = in ? *(const float2 *)(U + row * 64 + 2 * c) : make_float2(0.f, 0.f);
+                hh[u] = in ? *(const float2 *)(HID_ + row * HID + 2 * c) : make_float2(0.f, 0.f);
+                ds[u] = (in && s_ok) ? d_sh[row * SH + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                cs1x += dh[u].x; cs1y += dh[u].y; cs2 += ds[u];
+                acc1[0][0] = mfma2(dh[u].x, uu[u].x, acc1[0][0]);
+                acc1[0][1] = mfma2(dh[u].x, uu[u].y, acc1[0][1]);
+                acc1[1][0] = mfma2(dh[u].y, uu[u].x, acc1[1][0]);
+                acc1[1][1] = mfma2(dh[u].y, uu[u].y, acc1[1][1]);
+                acc2[0][0] = mfma2(ds[u], hh[u].x, acc2[0][0]);
+                acc2[0][1] = mfma2(ds[u], hh[u].y, acc2[0][1]);
+            }
+        }
+        fw_store<2, 2>(out + FW_O_W1, 64, 64, 64, lane, acc1);
+        fw_store<1, 2>(out + FW_O_W2, HID, SH, HID, lane, acc2);
+        cs1x += __shfl_xor(cs1x, 32, 64); cs1y += __shfl_xor(cs1y, 32, 64); cs2 += __shfl_xor(cs2, 32, 64);
+        if (lane < 32) { out[FW_O_B1 + 2 * c] = cs1x; out[FW_O_B1 + 2 * c + 1] = cs1y; }
+        if (lane < SH) out[FW_O_B2 + lane] = cs2;
+    }
+}
+
+// out[k] = sum over the slabs, in slab order, four independent chains per thread
+__global__ void __launch_bounds__(256)
+fine_wgrad_reduce_kernel(const float *__restrict__ part, const int slabs, float *__restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= FW_OUT) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= slabs; s += 4) {
+        a0 += part[(size_t)s * FW_OUT + k];
+        a1 += part[(size_t)(s + 1) * FW_OUT + k];
+        a2 += part[(size_t)(s + 2) * FW_OUT + k];
+        a3 += part[(size_t)(s + 3) * FW_OUT + k];
+    }
+    for (; s < slabs; s++) a0 += part[(size_t)s * FW_OUT + k];
+    out[k] = (a0 + a1) + (a2 + a3);
+}
+
 unsigned fd_grid(int n) {
     const unsigned tiles = (unsigned)((n + 127) / 128);
     return tiles < 1024u ? tiles : 1024u;
@@ -468,6 +594,29 @@ int lara_fine_decoder_backward(int32_t n, const float *xn, const float *pf, cons
         }
         hipLaunchKernelGGL(fine_decoder_bwd_kernel, dim3(fd_grid(n) < 512u ? fd_grid(n) : 512u), dim3(256), L_BWD_END * 4, s, n, xn, pf,
                            Wqk, W1ov, b1, W2, b2, d_sh, d_xn, d_pf, U, HID_, DH, DT);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
+
+int32_t lara_fine_wgrad_floats(void) { return FW_OUT; }
+int64_t lara_fine_wgrad_workspace_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)((n + FW_SLAB - 1) / FW_SLAB) * FW_OUT * 4; }
+
+int lara_fine_decoder_wgrad(int32_t n, const float *xn, const float *U, const float *HID_, const float *DH, const float *DT,
+                            const float *d_sh, float *out, void *workspace, void *stream) {
+    if (n < 0 || !out) return LARA2DGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)FW_OUT * 4, s);
+        if (e != hipSuccess) { l2d_set_hip_error(e); return LARA2DGS_E_LAUNCH; }
+        return LARA2DGS_OK;
+    }
+    if (!xn || !U || !HID_ || !DH || !DT || !d_sh || !workspace) return LARA2DGS_E_INVALID;
+    const int slabs = (n + FW_SLAB - 1) / FW_SLAB;
+    {
+        L2D_PROF("fine_decoder_wgrad", s);
+        hipLaunchKernelGGL(fine_wgrad_kernel, dim3((unsigned)slabs), dim3(128), 0, s, n, xn, U, HID_, DH, DT, d_sh, (float *)workspace);
+        hipLaunchKernelGGL(fine_wgrad_reduce_kernel, dim3((FW_OUT + 255) / 256), dim3(256), 0, s, (const float *)workspace, slabs, out);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

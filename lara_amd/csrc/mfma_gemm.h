@@ -504,6 +504,13 @@ gemm_ring_kernel(const GemmP p) {
     // kt+1 sits BETWEEN the two steps of tile kt: by then every fragment of tile kt is in registers (lgkmcnt(0) is free,
     // its reads were issued a step ago), so tile kt's buffer is refilled with tile kt+4 right after the barrier --
     // three tiles stay in flight -- and the matrix cores always have a step's worth of issued work behind them.
+    // (Round 5 measured the CDNA guides' staggered form of this loop on the same box: TWO barriers per K tile -- "tile kt+1 landed" /
+    // "nobody reads tile kt any more" -- with wave row 1 one barrier behind wave row 0 (every SIMD holds one wave of each row, so one
+    // is inside a step's MFMAs while the other sits in its waits) and s_setprio(1) around the MFMA runs.  Parity-green on the first
+    // build -- and slower: convolution 476-485 us against 435-437, its input gradient 452 against 426.  The lock-step is not what
+    // idles the matrix pipe: with two waves per SIMD each already waits for the other's MFMAs ~40 % of its cycles (SQ_WAIT_INST_ANY /
+    // SQ_WAVE_CYCLES), the pipe is busy 58 % of the SIMD's cycles at the clock the part sustains under this load, and a second
+    // barrier per tile costs more than the stagger returns.  DESIGN.md section 3.4.)
     bf16x8 fa[2][4], fb[2][2];
     auto fetch = [&](const int set, const int kt, const int step) {
         const unsigned char *buf = ring + (kt % RING) * RTILE;

@@ -46,6 +46,11 @@ def _lib():
         lib.lara_fine_decoder_forward.argtypes = [i32] + [vp] * 9
         lib.lara_fine_decoder_backward.restype = ctypes.c_int
         lib.lara_fine_decoder_backward.argtypes = [i32] + [vp] * 15
+        lib.lara_fine_wgrad_floats.restype = i32
+        lib.lara_fine_wgrad_workspace_bytes.restype = ctypes.c_int64
+        lib.lara_fine_wgrad_workspace_bytes.argtypes = [i32]
+        lib.lara_fine_decoder_wgrad.restype = ctypes.c_int
+        lib.lara_fine_decoder_wgrad.argtypes = [i32] + [vp] * 9
         lib.lara_fine_ln_blocks.restype = i32
         lib.lara_fine_ln_blocks.argtypes = [i32]
         lib.lara_fine_ln_forward.restype = ctypes.c_int
@@ -257,8 +262,23 @@ class _FineDecoder(torch.autograd.Function):
                                                      DH.data_ptr(), DT.data_ptr(),
                                                      torch.cuda.current_stream(xn.device).cuda_stream),
                    "lara_fine_decoder_backward")
-        # the weight gradients are plain GEMMs over the points (library BLAS): [64,n] x [n,80] etc.
-        return (d_xn, d_pf, _tn_over_points(DT, xn), _tn_over_points(DH, U), DH.sum(0), _tn_over_points(d_sh, H), d_sh.sum(0))
+            # the five parameter gradients: reductions of the factor arrays over the points, one launch + an ordered sum
+            # (include/lara_finedec.h: lara_fine_decoder_wgrad; rounds 2-4: batched BLAS GEMMs + torch reductions, 79 launches)
+            lib = _lib()
+            dw = new(lib.lara_fine_wgrad_floats())
+            ws = torch.empty(max(lib.lara_fine_wgrad_workspace_bytes(n), 16), dtype=torch.uint8, device=xn.device)
+            _check(lib.lara_fine_decoder_wgrad(n, xn.data_ptr(), U.data_ptr(), H.data_ptr(), DH.data_ptr(), DT.data_ptr(),
+                                               d_sh.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                               torch.cuda.current_stream(xn.device).cuda_stream), "lara_fine_decoder_wgrad")
+        o = 0
+        out = []
+        for shape in ((_NH * _CD, _FD), (_HID, _NH * _CD), (_HID,), (_SH, _HID), (_SH,)):
+            k = 1
+            for d in shape:
+                k *= d
+            out.append(dw[o:o + k].view(shape))
+            o += k
+        return (d_xn, d_pf, *out)
 
 
 def _tn_over_points(a, b, chunk=1024):

@@ -6,6 +6,11 @@ operators (the package the reference imports, `pytorch_msssim`, is absent from t
 ``ms_ssim`` restates its published algorithm and is tested against an independent float64 restatement, tests/test_loss_cpu.py:
 parity with the package itself is unpinned).  ``lara_loss(batch, output, it)`` has the signature and return value of
 ``Losses.forward``: (loss, scalar_stats).  The fused pixel terms have no CPU path: tensors must live on the GPU.
+
+Round 5: on the GPU the MS-SSIM term runs as HIP kernels too (``ms_ssim_fused``, csrc/msssim.hip, include/lara_loss.h: the five
+scales' filters, maps, means and their backward on the images where they lie -- 31 ms of torch operators per training step
+before); ``ms_ssim`` stays as the torch formulation that ``pipeline.lara_loss`` and the CPU tests use, and as what the kernels
+are held to.
 """
 from __future__ import annotations
 
@@ -19,6 +24,10 @@ _configured = False
 _weights = {}
 
 
+class _ImgView(ctypes.Structure):      # include/lara_loss.h: lara_image_view (element strides)
+    _fields_ = [("p", ctypes.c_void_p)] + [(n, ctypes.c_int64) for n in ("sN", "sC", "sY", "sV", "sX")] + [("Wv", ctypes.c_int32)]
+
+
 def _lib():
     global _configured
     lib = load_library()
@@ -30,6 +39,13 @@ def _lib():
         lib.lara_loss_terms_forward.argtypes = [i32, i32, i32, i32] + [vp] * 10
         lib.lara_loss_terms_backward.restype = ctypes.c_int
         lib.lara_loss_terms_backward.argtypes = [i32, i32, i32, i32] + [vp] * 13
+        lib.lara_ms_ssim_workspace_floats.restype = i64
+        lib.lara_ms_ssim_workspace_floats.argtypes = [i32, i32, i32, i32]
+        lib.lara_ms_ssim_forward.restype = ctypes.c_int
+        lib.lara_ms_ssim_forward.argtypes = [i32, i32, i32, i32, ctypes.POINTER(_ImgView), ctypes.POINTER(_ImgView), vp, vp, vp, vp]
+        lib.lara_ms_ssim_backward.restype = ctypes.c_int
+        lib.lara_ms_ssim_backward.argtypes = [i32, i32, i32, i32, ctypes.POINTER(_ImgView), ctypes.POINTER(_ImgView), vp, vp,
+                                              ctypes.POINTER(_ImgView), vp, vp]
         _configured = True
     return lib
 
@@ -181,14 +197,91 @@ def ms_ssim(X, Y, data_range=1.0, win_size=11, win_sigma=1.5, weights=MS_SSIM_WE
     return torch.prod(torch.stack(vals, 0) ** w.view(-1, 1, 1), dim=0).mean()
 
 
-def ms_ssim_terms(batch, output, prexes=("", "_fine")):
-    """loss.py:36-45 for the images present: ({prex: 0.5 * (1 - MS_SSIM)}, {psnr / ssim statistics})."""
+_win_host = {}
+
+
+def _window_host(size=11, sigma=1.5):
+    """The filter taps as a ctypes array (the same fp32 numbers `_gauss_window` puts on the device)."""
+    key = (size, sigma)
+    if key not in _win_host:
+        w = _gauss_window("cpu", size, sigma)
+        _win_host[key] = (ctypes.c_float * size)(*[float(v) for v in w])
+    return _win_host[key]
+
+
+class _MsSsimMeans(torch.autograd.Function):
+    """(image [B,H,V*W,3] as `Network.forward` stacks it, tar_rgb [B,V,H,W,3]) -> means [5, B*3, 2]: per scale and (image,
+    channel) the mean of the SSIM map and of its contrast-structure factor (include/lara_loss.h: lara_ms_ssim_forward).  Both
+    images are read where they lie (the reference permutes them to [B,3,H,V*W], loss.py:24-25)."""
+
+    @staticmethod
+    def forward(ctx, image, tar):
+        if not image.is_cuda:
+            raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
+        image, tar = image.detach().float().contiguous(), tar.detach().float().contiguous()
+        B, V, H, W = tar.shape[:4]
+        if tar.shape != (B, V, H, W, 3) or image.shape != (B, H, V * W, 3):
+            raise RuntimeError("expected tar_rgb [B,V,H,W,3] and image [B,H,V*W,3]")
+        lib = _lib()
+        nws = int(lib.lara_ms_ssim_workspace_floats(B, 3, H, V * W))
+        if nws < 0:
+            raise ValueError(f"ms_ssim: the smaller image side must exceed {(11 - 1) * 2 ** 4} (four 2x downsamplings)")
+        ws = torch.empty(nws, dtype=torch.float32, device=image.device)
+        means = torch.empty(5, B * 3, 2, dtype=torch.float32, device=image.device)
+        xv = _ImgView(image.data_ptr(), H * V * W * 3, 1, V * W * 3, W * 3, 3, W)
+        yv = _ImgView(tar.data_ptr(), V * H * W * 3, 1, W * 3, H * W * 3, 3, W)
+        with torch.cuda.device(image.device):
+            _check(lib.lara_ms_ssim_forward(B, 3, H, V * W, ctypes.byref(xv), ctypes.byref(yv), _window_host(), means.data_ptr(),
+                                            ws.data_ptr(), torch.cuda.current_stream(image.device).cuda_stream), "lara_ms_ssim_forward")
+        ctx.dims = (B, V, H, W)
+        ctx.save_for_backward(image, tar, ws)
+        return means
+
+    @staticmethod
+    def backward(ctx, d_means):
+        image, tar, ws = ctx.saved_tensors
+        B, V, H, W = ctx.dims
+        d_means = d_means.float().contiguous()
+        d_image = torch.empty_like(image)
+        xv = _ImgView(image.data_ptr(), H * V * W * 3, 1, V * W * 3, W * 3, 3, W)
+        yv = _ImgView(tar.data_ptr(), V * H * W * 3, 1, W * 3, H * W * 3, 3, W)
+        dv = _ImgView(d_image.data_ptr(), H * V * W * 3, 1, V * W * 3, W * 3, 3, W)
+        with torch.cuda.device(image.device):
+            _check(_lib().lara_ms_ssim_backward(B, 3, H, V * W, ctypes.byref(xv), ctypes.byref(yv), _window_host(), d_means.data_ptr(),
+                                                ctypes.byref(dv), ws.data_ptr(), torch.cuda.current_stream(image.device).cuda_stream),
+                   "lara_ms_ssim_backward")
+        return d_image, None
+
+
+def ms_ssim_fused(image, tar_rgb, weights=MS_SSIM_WEIGHTS):
+    """MS-SSIM of the stacked render `image` [B,H,V*W,3] against `batch['tar_rgb']` [B,V,H,W,3] -- the value `ms_ssim` gives for
+    the two tensors permuted to [B,3,H,V*W] (loss.py:24-25, :42) -- with the filters, maps, means and their backward as HIP
+    kernels; the five means per (image, channel) are combined here (relu, published weights, product, mean: [5, 3 B] numbers)."""
+    means = _MsSsimMeans.apply(image, tar_rgb)
+    vals = torch.cat([means[:4, :, 1], means[4:, :, 0]], 0)        # contrast-structure means of scales 0-3, SSIM mean of the last
+    key = (means.device, tuple(weights))
+    if key not in _weights:
+        _weights[key] = torch.tensor(weights, dtype=torch.float32, device=means.device).view(-1, 1)
+    return torch.prod(torch.relu(vals) ** _weights[key], dim=0).mean()
+
+
+def ms_ssim_terms(batch, output, prexes=("", "_fine"), fused=None):
+    """loss.py:36-45 for the images present: ({prex: 0.5 * (1 - MS_SSIM)}, {psnr / ssim statistics}).  `fused`: the HIP kernels
+    (default on the GPU) or the torch formulation."""
     B, V, H, W = batch["tar_rgb"].shape[:-1]
-    tar = batch["tar_rgb"].permute(0, 2, 1, 3, 4).reshape(B, H, V * W, 3).permute(0, 3, 1, 2).float()
+    tar = None
     terms, stats = {}, {}
     for prex in prexes:
         if f"image{prex}" not in output or (prex == "_fine" and "acc_map_fine" not in output):
             continue
+        if output[f"image{prex}"].is_cuda if fused is None else fused:          # HIP kernels on the tensors where they lie
+            with torch.autocast(device_type="cuda", enabled=False):
+                val = ms_ssim_fused(output[f"image{prex}"], batch["tar_rgb"])
+            terms[prex] = 0.5 * (1 - val)
+            stats[f"ssim{prex}"] = val.detach()
+            continue
+        if tar is None:
+            tar = batch["tar_rgb"].permute(0, 2, 1, 3, 4).reshape(B, H, V * W, 3).permute(0, 3, 1, 2).float()
         img = output[f"image{prex}"].permute(0, 3, 1, 2).float()
         with torch.autocast(device_type=img.device.type, enabled=False):
             val = ms_ssim(img, tar)

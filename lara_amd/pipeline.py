@@ -377,7 +377,7 @@ def lara_loss(batch, output, it=10000, ms_ssim=True):
         stats[f"mse{prex}"] = mse.detach()
         stats[f"psnr{prex}"] = -10.0 * torch.log10(mse.detach())               # loss.py:36-39
         if ms_ssim:
-            extra, st = ms_ssim_terms(batch, output, (prex,))
+            extra, st = ms_ssim_terms(batch, output, (prex,), fused=False)       # (this function is the torch formulation)
             loss = loss + extra[prex]                                           # loss.py:41-45
             stats.update(st)
         if f"rend_dist{prex}" in output and it > 1000 and prex != "_fine":
