@@ -17,14 +17,17 @@ def _pair(B, V, H, W, seed, noise=0.1):
     return img.to(DEV), tar.to(DEV)
 
 
-def _torch_value_and_grad(img, tar):
+def _torch_value_and_grad(img, tar, on_cpu_in_float64=False):
+    """The torch formulation on the same tensors: on the GPU in fp32, or on the CPU in float64 (small cases)."""
     from lara_amd.loss import ms_ssim
     B, V, H, W = tar.shape[:4]
+    if on_cpu_in_float64:
+        img, tar = img.cpu().double(), tar.cpu().double()
     x = img.clone().requires_grad_(True)
     t = tar.permute(0, 2, 1, 3, 4).reshape(B, H, V * W, 3).permute(0, 3, 1, 2)
     val = ms_ssim(x.permute(0, 3, 1, 2), t)
     val.backward()
-    return val.detach(), x.grad
+    return val.detach().float().to(DEV), x.grad.float().to(DEV)
 
 
 @pytest.mark.parametrize("B,V,H,W", [(1, 2, 176, 96), (2, 1, 191, 163), (1, 3, 200, 67), (1, 1, 333, 170)])
@@ -33,7 +36,10 @@ def test_fused_ms_ssim_matches_the_torch_formulation(hip_lib, B, V, H, W):
     the view boundaries of the stacked image, as in the reference), ragged tiles: value to 2e-6, gradient to 2e-4 of its maximum."""
     from lara_amd.loss import ms_ssim_fused
     img, tar = _pair(B, V, H, W, seed=H + W)
-    want, gwant = _torch_value_and_grad(img, tar)
+    want, gwant = _torch_value_and_grad(img, tar, on_cpu_in_float64=True)
+    w32, g32 = _torch_value_and_grad(img, tar)
+    print("torch fp32 on the GPU vs torch float64 on the CPU: value", float(w32 - want), "gradient (of max)",
+          float((g32 - gwant).abs().max() / gwant.abs().max()))
     x = img.clone().requires_grad_(True)
     got = ms_ssim_fused(x, tar)
     got.backward()
