@@ -431,7 +431,8 @@ fine_ln_bwd_kernel(const int n, const float *__restrict__ x_g, const float *__re
 //   dWqk [64,80] = DT^T xn,  dW1ov [64,64] = DH^T U,  db1 [64] = colsum(DH),  dW2 [12,64] = d_sh^T HID,  db2 [12] = colsum(d_sh)
 // (rounds 2-4 ran them through the BLAS library as batched GEMMs over 1024-row slabs + torch reductions: 79 launches and 1.1 ms
 // per step of someone else's kernels on a path that claims its own).  Reductions over n = 10^5..10^6 rows with 12..80 columns on
-// either side are streams, not GEMMs: a workgroup of two waves takes a slab of FW_SLAB rows -- wave 0 dWqk, wave 1 the rest -- on
+// either side are streams, not GEMMs: a workgroup of three waves takes a slab of FW_SLAB rows -- waves 0 / 1 the two column halves
+// of dWqk, wave 2 the rest -- on
 // v_mfma_f32_32x32x2_f32 (exact fp32 products and sums) with the operands straight from global memory: the instruction wants
 // A[i = lane % 32][k = lane / 32] = X[row + lane / 32][i], so a half-wave reads ONE row, and since the order of the rows / columns
 // of an outer product is free, lane c fetches 2 or 4 CONSECUTIVE columns with one 8- / 16-byte load and feeds component e to the
@@ -458,7 +459,7 @@ __device__ __forceinline__ void fw_store(float *__restrict__ out, const int ldo,
             }
 }
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(192)
 fine_wgrad_kernel(const int n, const float *__restrict__ xn, const float *__restrict__ U, const float *__restrict__ HID_,
                   const float *__restrict__ DH, const float *__restrict__ DT, const float *__restrict__ d_sh,
                   float *__restrict__ part) {
@@ -466,36 +467,44 @@ fine_wgrad_kernel(const int n, const float *__restrict__ xn, const float *__rest
     const int row0 = blockIdx.x * FW_SLAB, rows = min(FW_SLAB, n - row0);
     float *out = part + (size_t)blockIdx.x * FW_OUT;
     const int kk = lane >> 5, c = lane & 31;
-    constexpr int UN = 4;      // K steps (of two rows) whose loads are in flight together
-    if (wave == 0) {           // dWqk: A = DT (64 columns: float2 per lane), B = xn (80 columns: float4 per lane, lanes c < 20)
-        f32x16 acc[2][4];
+    constexpr int UN = 8;      // K steps (of two rows) whose loads are in flight together
+    if (wave < 2) {            // dWqk: A = DT (64 columns: float2 per lane), B = xn columns {4c + 2 wave, + 1} (80 columns: lanes c < 20)
+        f32x16 acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++)
+            for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[a][b][e] = 0.f;
         const bool b_ok = c < FD / 4;
         for (int r = 0; r < rows; r += 2 * UN) {
-            float2 av[UN];
-            float4 bv[UN];
+            float2 av[UN], bv[UN];
 #pragma unroll
             for (int u = 0; u < UN; u++) {
                 const int rr = r + 2 * u + kk;
                 const bool in = rr < rows;
                 av[u] = in ? *(const float2 *)(DT + (size_t)(row0 + rr) * 64 + 2 * c) : make_float2(0.f, 0.f);
-                bv[u] = (in && b_ok) ? *(const float4 *)(xn + (size_t)(row0 + rr) * FD + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[u] = (in && b_ok) ? *(const float2 *)(xn + (size_t)(row0 + rr) * FD + 4 * c + 2 * wave) : make_float2(0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < UN; u++) {
-                const float a2[2] = {av[u].x, av[u].y}, b4[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++) acc[a][b] = mfma2(a2[a], b4[b], acc[a][b]);
+                acc[0][0] = mfma2(av[u].x, bv[u].x, acc[0][0]);
+                acc[0][1] = mfma2(av[u].x, bv[u].y, acc[0][1]);
+                acc[1][0] = mfma2(av[u].y, bv[u].x, acc[1][0]);
+                acc[1][1] = mfma2(av[u].y, bv[u].y, acc[1][1]);
             }
         }
-        fw_store<2, 4>(out, FD, 64, FD, lane, acc);
+        // acc[ea][eb] = dWqk[2 rA + ea][4 cB + 2 wave + eb]
+        const int kh = lane >> 5;
+#pragma unroll
+        for (int ea = 0; ea < 2; ea++)
+#pragma unroll
+            for (int eb = 0; eb < 2; eb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int i = 2 * ((e & 3) + 8 * (e >> 2) + 4 * kh) + ea, j = 4 * c + 2 * wave + eb;
+                    if (j < FD) out[(size_t)i * FD + j] = acc[ea][eb][e];
+                }
     } else {                   // dW1ov + db1 (A = DH, B = U: float2 each) and dW2 + db2 (A = d_sh: one float, lanes c < 12; B = HID: float2)
         f32x16 acc1[2][2], acc2[1][2];
 #pragma unroll
@@ -537,20 +546,24 @@ fine_wgrad_kernel(const int n, const float *__restrict__ xn, const float *__rest
 }
 
 // out[k] = sum over the slabs, in slab order, four independent chains per thread
+// (64 outputs x 4 slab phases per workgroup: a thread walks every fourth slab -- a quarter of the dependent chain -- and the four
+// phases of an output are added in phase order through LDS)
 __global__ void __launch_bounds__(256)
 fine_wgrad_reduce_kernel(const float *__restrict__ part, const int slabs, float *__restrict__ out) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= FW_OUT) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= slabs; s += 4) {
-        a0 += part[(size_t)s * FW_OUT + k];
-        a1 += part[(size_t)(s + 1) * FW_OUT + k];
-        a2 += part[(size_t)(s + 2) * FW_OUT + k];
-        a3 += part[(size_t)(s + 3) * FW_OUT + k];
+    __shared__ float ph[4][64];
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f;
+    if (k < FW_OUT) {
+        int s = q;
+        for (; s + 4 < slabs; s += 8) {
+            a0 += part[(size_t)s * FW_OUT + k];
+            a1 += part[(size_t)(s + 4) * FW_OUT + k];
+        }
+        if (s < slabs) a0 += part[(size_t)s * FW_OUT + k];
     }
-    for (; s < slabs; s++) a0 += part[(size_t)s * FW_OUT + k];
-    out[k] = (a0 + a1) + (a2 + a3);
+    ph[q][threadIdx.x & 63] = a0 + a1;
+    __syncthreads();
+    if (q == 0 && k < FW_OUT) out[k] = (ph[0][threadIdx.x] + ph[1][threadIdx.x]) + (ph[2][threadIdx.x] + ph[3][threadIdx.x]);
 }
 
 unsigned fd_grid(int n) {
@@ -615,8 +628,8 @@ int lara_fine_decoder_wgrad(int32_t n, const float *xn, const float *U, const fl
     const int slabs = (n + FW_SLAB - 1) / FW_SLAB;
     {
         L2D_PROF("fine_decoder_wgrad", s);
-        hipLaunchKernelGGL(fine_wgrad_kernel, dim3((unsigned)slabs), dim3(128), 0, s, n, xn, U, HID_, DH, DT, d_sh, (float *)workspace);
-        hipLaunchKernelGGL(fine_wgrad_reduce_kernel, dim3((FW_OUT + 255) / 256), dim3(256), 0, s, (const float *)workspace, slabs, out);
+        hipLaunchKernelGGL(fine_wgrad_kernel, dim3((unsigned)slabs), dim3(192), 0, s, n, xn, U, HID_, DH, DT, d_sh, (float *)workspace);
+        hipLaunchKernelGGL(fine_wgrad_reduce_kernel, dim3((FW_OUT + 63) / 64), dim3(256), 0, s, (const float *)workspace, slabs, out);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

@@ -34,6 +34,14 @@ __device__ __forceinline__ size_t ms_at(const MsView &v, const int n, const int 
     return (size_t)(n * v.sN + c * v.sC + y * v.sY + xv * v.sV + xr * v.sX);
 }
 
+// the same for x >= x_base where v_base = x_base / Wv was divided once (per tile): at most a few view crossings inside a tile
+__device__ __forceinline__ size_t ms_at_from(const MsView &v, const int n, const int c, const int y, const int x, const int v_base,
+                                             const int x_of_v_base) {
+    int xv = v_base, xr = x - x_of_v_base;
+    while (xr >= v.Wv) { xr -= v.Wv; xv++; }
+    return (size_t)(n * v.sN + c * v.sC + y * v.sY + xv * v.sV + xr * v.sX);
+}
+
 // out[i][j] = 1/4 sum over a, b of in[2i + a - py][2j + b - px] (zero outside): avg_pool2d(kernel 2, padding (H % 2, W % 2))
 __global__ void __launch_bounds__(256)
 msssim_pool_kernel(const MsView X, const MsView Y, const int C, const int H, const int W, const int Ho, const int Wo,
@@ -61,32 +69,56 @@ msssim_pool_kernel(const MsView X, const MsView Y, const int C, const int H, con
 // MODE 0: per-workgroup partial sums of the ssim and cs maps -> partial[nc][tile][2]
 // MODE 1: the gradient maps G[3][nc][Hb][Wb] = dL/d(mu_x), dL/d(filtered x^2), dL/d(filtered x y) given dmeans[nc][2] = dL/d(mean
 //         ssim), dL/d(mean cs)
+// Both filter passes are register-blocked: a thread produces FOUR adjacent outputs from 14 inputs it reads once (16-byte LDS reads
+// along the row; one column, four rows down the column), a third of the LDS reads of one output per thread -- the first version
+// spent more issue slots on ds_read_b32 than on the filter's multiply-adds (level 0: 375 us per launch; this form: see DESIGN 3.15).
+constexpr int MS_SW = MS_IN + 2, MS_HW = MS_T + 4;     // LDS row lengths (floats): 44 and 36, multiples of 4 (aligned float4 rows)
 template <int MODE>
 __global__ void __launch_bounds__(256)
 msssim_maps_kernel(const MsView X, const MsView Y, const int C, const int H, const int W, const MsWin win, const float C1,
                    const float C2, float *__restrict__ partial, const float *__restrict__ dmeans, float *__restrict__ G) {
-    __shared__ float sx[MS_IN][MS_IN + 1], sy[MS_IN][MS_IN + 1];
-    __shared__ float hh[5][MS_IN][MS_T + 1];
+    __shared__ __attribute__((aligned(16))) float sx[MS_IN][MS_SW], sy[MS_IN][MS_SW];
+    __shared__ __attribute__((aligned(16))) float hh[5][MS_IN][MS_HW];
     __shared__ float red[2][4];
     const int tid = threadIdx.x, nc = blockIdx.z, n = nc / C, c = nc - n * C;
     const int ty0 = blockIdx.y * MS_T, tx0 = blockIdx.x * MS_T;
     const int Hb = H - (MS_WIN - 1), Wb = W - (MS_WIN - 1);
-    for (int idx = tid; idx < MS_IN * MS_IN; idx += 256) {
-        const int r = idx / MS_IN, cc = idx - r * MS_IN, y = ty0 + r, x = tx0 + cc;
+    const int vb = tx0 / X.Wv, vbx = vb * X.Wv;      // (X, Y and their gradient share Wv)
+    for (int idx = tid; idx < MS_IN * MS_SW; idx += 256) {
+        const int r = idx / MS_SW, cc = idx - r * MS_SW, y = ty0 + r, x = tx0 + cc;
         const bool in = y < H && x < W;
-        sx[r][cc] = in ? X.p[ms_at(X, n, c, y, x)] : 0.f;
-        sy[r][cc] = in ? Y.p[ms_at(Y, n, c, y, x)] : 0.f;
+        sx[r][cc] = in ? X.p[ms_at_from(X, n, c, y, x, vb, vbx)] : 0.f;
+        sy[r][cc] = in ? Y.p[ms_at_from(Y, n, c, y, x, vb, vbx)] : 0.f;
     }
     __syncthreads();
-    for (int idx = tid; idx < MS_IN * MS_T; idx += 256) {      // along the row
-        const int r = idx / MS_T, cc = idx - r * MS_T;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    for (int item = tid; item < MS_IN * (MS_T / 4); item += 256) {      // along the row: 4 outputs from 14 inputs
+        const int r = item >> 3, c0 = (item & 7) * 4;
+        float xv[16], yv[16];
 #pragma unroll
-        for (int t = 0; t < MS_WIN; t++) {
-            const float xv = sx[r][cc + t], yv = sy[r][cc + t], w = win.w[t];
-            a0 += w * xv; a1 += w * yv; a2 += w * (xv * xv); a3 += w * (yv * yv); a4 += w * (xv * yv);
+        for (int q = 0; q < 4; q++) {
+            const float4 a = *(const float4 *)&sx[r][c0 + 4 * q], b = *(const float4 *)&sy[r][c0 + 4 * q];
+            xv[4 * q] = a.x; xv[4 * q + 1] = a.y; xv[4 * q + 2] = a.z; xv[4 * q + 3] = a.w;
+            yv[4 * q] = b.x; yv[4 * q + 1] = b.y; yv[4 * q + 2] = b.z; yv[4 * q + 3] = b.w;
         }
-        hh[0][r][cc] = a0; hh[1][r][cc] = a1; hh[2][r][cc] = a2; hh[3][r][cc] = a3; hh[4][r][cc] = a4;
+        float o[5][4];
+#pragma unroll
+        for (int m = 0; m < 5; m++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[m][e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            const float x1 = xv[k], y1 = yv[k], xx = x1 * x1, yy = y1 * y1, xy = x1 * y1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int t = k - e;
+                if (t >= 0 && t < MS_WIN) {
+                    const float w = win.w[t];
+                    o[0][e] += w * x1; o[1][e] += w * y1; o[2][e] += w * xx; o[3][e] += w * yy; o[4][e] += w * xy;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 5; m++) *(float4 *)&hh[m][r][c0] = make_float4(o[m][0], o[m][1], o[m][2], o[m][3]);
     }
     __syncthreads();
     float s_ssim = 0.f, s_cs = 0.f;
@@ -96,35 +128,45 @@ msssim_maps_kernel(const MsView X, const MsView Y, const int C, const int H, con
         gS = dmeans[2 * nc] * inv;
         gC = dmeans[2 * nc + 1] * inv;
     }
+    {                                                                   // down the column: 4 outputs from 14 rows, per map
+        const int cc = tid & 31, r0 = (tid >> 5) * 4;
+        float v[5][4];
 #pragma unroll
-    for (int k = 0; k < (MS_T * MS_T) / 256; k++) {            // down the column
-        const int idx = tid + 256 * k, r = idx / MS_T, cc = idx - r * MS_T;
-        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 5; m++) {
+            float hv[14];
 #pragma unroll
-        for (int t = 0; t < MS_WIN; t++) {
-            const float w = win.w[t];
+            for (int k = 0; k < 14; k++) hv[k] = hh[m][r0 + k][cc];
 #pragma unroll
-            for (int m = 0; m < 5; m++) v[m] += w * hh[m][r + t][cc];
+            for (int e = 0; e < 4; e++) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < MS_WIN; t++) a += win.w[t] * hv[e + t];
+                v[m][e] = a;
+            }
         }
-        const bool valid = ty0 + r < Hb && tx0 + cc < Wb;
-        const float mu1 = v[0], mu2 = v[1];
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float A2 = 2.0f * (v[4] - mu12) + C2, B2 = (v[2] - mu1_sq) + (v[3] - mu2_sq) + C2;
-        const float A1 = 2.0f * mu12 + C1, B1 = mu1_sq + mu2_sq + C1;
-        const float cs = A2 / B2, L = A1 / B1;
-        if (MODE == 0) {
-            s_cs += valid ? cs : 0.f;
-            s_ssim += valid ? L * cs : 0.f;
-        } else if (valid) {
-            const float iB2 = 1.0f / B2, iB1 = 1.0f / B1;
-            const float g_cs = gC + gS * L, g_L = gS * cs;
-            const float dcs_dmu1 = (2.0f * mu1 * A2 - 2.0f * mu2 * B2) * (iB2 * iB2);
-            const float dL_dmu1 = (2.0f * mu2 * B1 - 2.0f * mu1 * A1) * (iB1 * iB1);
-            const size_t plane = (size_t)Hb * Wb, o = (size_t)nc * plane + (size_t)(ty0 + r) * Wb + (tx0 + cc);
-            const size_t all = (size_t)gridDim.z * plane;
-            G[o] = g_L * dL_dmu1 + g_cs * dcs_dmu1;
-            G[all + o] = g_cs * (-A2 * (iB2 * iB2));
-            G[2 * all + o] = g_cs * (2.0f * iB2);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int r = r0 + e;
+            const bool valid = ty0 + r < Hb && tx0 + cc < Wb;
+            const float mu1 = v[0][e], mu2 = v[1][e];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float A2 = 2.0f * (v[4][e] - mu12) + C2, B2 = (v[2][e] - mu1_sq) + (v[3][e] - mu2_sq) + C2;
+            const float A1 = 2.0f * mu12 + C1, B1 = mu1_sq + mu2_sq + C1;
+            const float cs = A2 / B2, L = A1 / B1;
+            if (MODE == 0) {
+                s_cs += valid ? cs : 0.f;
+                s_ssim += valid ? L * cs : 0.f;
+            } else if (valid) {
+                const float iB2 = 1.0f / B2, iB1 = 1.0f / B1;
+                const float g_cs = gC + gS * L, g_L = gS * cs;
+                const float dcs_dmu1 = (2.0f * mu1 * A2 - 2.0f * mu2 * B2) * (iB2 * iB2);
+                const float dL_dmu1 = (2.0f * mu2 * B1 - 2.0f * mu1 * A1) * (iB1 * iB1);
+                const size_t plane = (size_t)Hb * Wb, o = (size_t)nc * plane + (size_t)(ty0 + r) * Wb + (tx0 + cc);
+                const size_t all = (size_t)gridDim.z * plane;
+                G[o] = g_L * dL_dmu1 + g_cs * dcs_dmu1;
+                G[all + o] = g_cs * (-A2 * (iB2 * iB2));
+                G[2 * all + o] = g_cs * (2.0f * iB2);
+            }
         }
     }
     if (MODE == 0) {
@@ -153,52 +195,75 @@ msssim_means_kernel(const float *__restrict__ partial, const int tiles, const fl
     if (lane == 0) { means[2 * nc] = a * inv_count; means[2 * nc + 1] = b * inv_count; }
 }
 
-// dx[p] = sum_ij w_i w_j (G0 + 2 x G1 + y G2)[p - (i, j)] + 1/4 dnext[(p + pad) / 2]; tile 32 x 32 of the level's image
+// dx[p] = sum_ij w_i w_j (G0 + 2 x G1 + y G2)[p - (i, j)] + 1/4 dnext[(p + pad) / 2]; tile 32 x 32 of the level's image; the same
+// register blocking as the forward filter
 __global__ void __launch_bounds__(256)
 msssim_back_kernel(const MsView X, const MsView Y, const MsView DX, const int C, const int H, const int W, const MsWin win,
                    const float *__restrict__ G, const float *__restrict__ dnext, const int Hn, const int Wn) {
-    __shared__ float sg[3][MS_IN][MS_IN + 1];
-    __shared__ float th[3][MS_IN][MS_T + 1];
+    __shared__ __attribute__((aligned(16))) float sg[3][MS_IN][MS_SW];
+    __shared__ __attribute__((aligned(16))) float th[3][MS_IN][MS_HW];
     const int tid = threadIdx.x, nc = blockIdx.z, n = nc / C, c = nc - n * C;
     const int ty0 = blockIdx.y * MS_T, tx0 = blockIdx.x * MS_T;
     const int Hb = H - (MS_WIN - 1), Wb = W - (MS_WIN - 1);
     const size_t plane = (size_t)Hb * Wb, all = (size_t)gridDim.z * plane;
     // filtered-domain positions q = p - 10 .. p: local (r, cc) <-> q = (ty0 - 10 + r, tx0 - 10 + cc)
-    for (int idx = tid; idx < MS_IN * MS_IN; idx += 256) {
-        const int r = idx / MS_IN, cc = idx - r * MS_IN, qy = ty0 - (MS_WIN - 1) + r, qx = tx0 - (MS_WIN - 1) + cc;
-        const bool in = (unsigned)qy < (unsigned)Hb && (unsigned)qx < (unsigned)Wb;
+    for (int idx = tid; idx < MS_IN * MS_SW; idx += 256) {
+        const int r = idx / MS_SW, cc = idx - r * MS_SW, qy = ty0 - (MS_WIN - 1) + r, qx = tx0 - (MS_WIN - 1) + cc;
+        const bool in = cc < MS_IN && (unsigned)qy < (unsigned)Hb && (unsigned)qx < (unsigned)Wb;
         const size_t o = (size_t)nc * plane + (size_t)(in ? qy : 0) * Wb + (in ? qx : 0);
         sg[0][r][cc] = in ? G[o] : 0.f;
         sg[1][r][cc] = in ? G[all + o] : 0.f;
         sg[2][r][cc] = in ? G[2 * all + o] : 0.f;
     }
     __syncthreads();
-    for (int idx = tid; idx < MS_IN * MS_T; idx += 256) {      // along the row: p column cc gathers q columns cc + 10 - t
-        const int r = idx / MS_T, cc = idx - r * MS_T;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int item = tid; item < MS_IN * (MS_T / 4); item += 256) {      // along the row: p column c0 + e gathers q columns c0 + e + 10 - t
+        const int r = item >> 3, c0 = (item & 7) * 4;
 #pragma unroll
-        for (int t = 0; t < MS_WIN; t++) {
-            const float w = win.w[t];
-            a0 += w * sg[0][r][cc + (MS_WIN - 1) - t]; a1 += w * sg[1][r][cc + (MS_WIN - 1) - t]; a2 += w * sg[2][r][cc + (MS_WIN - 1) - t];
+        for (int m = 0; m < 3; m++) {
+            float gv[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 a = *(const float4 *)&sg[m][r][c0 + 4 * q];
+                gv[4 * q] = a.x; gv[4 * q + 1] = a.y; gv[4 * q + 2] = a.z; gv[4 * q + 3] = a.w;
+            }
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < MS_WIN; t++) a += win.w[t] * gv[e + (MS_WIN - 1) - t];
+                o[e] = a;
+            }
+            *(float4 *)&th[m][r][c0] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        th[0][r][cc] = a0; th[1][r][cc] = a1; th[2][r][cc] = a2;
     }
     __syncthreads();
     const int py = H & 1, px = W & 1;
+    const int cc = tid & 31, r0 = (tid >> 5) * 4, x = tx0 + cc;
+    float out[3][4];
 #pragma unroll
-    for (int k = 0; k < (MS_T * MS_T) / 256; k++) {
-        const int idx = tid + 256 * k, r = idx / MS_T, cc = idx - r * MS_T, y = ty0 + r, x = tx0 + cc;
-        if (y >= H || x >= W) continue;
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    for (int m = 0; m < 3; m++) {
+        float tv[14];
 #pragma unroll
-        for (int t = 0; t < MS_WIN; t++) {
-            const float w = win.w[t];
-            o0 += w * th[0][r + (MS_WIN - 1) - t][cc]; o1 += w * th[1][r + (MS_WIN - 1) - t][cc]; o2 += w * th[2][r + (MS_WIN - 1) - t][cc];
+        for (int k = 0; k < 14; k++) tv[k] = th[m][r0 + k][cc];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < MS_WIN; t++) a += win.w[t] * tv[e + (MS_WIN - 1) - t];
+            out[m][e] = a;
         }
-        const float xv = X.p[ms_at(X, n, c, y, x)], yv = Y.p[ms_at(Y, n, c, y, x)];
-        float d = o0 + 2.0f * xv * o1 + yv * o2;
+    }
+    if (x >= W) return;
+    const int vb = x / X.Wv, vbx = vb * X.Wv;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int y = ty0 + r0 + e;
+        if (y >= H) continue;
+        const float xv = X.p[ms_at_from(X, n, c, y, x, vb, vbx)], yv = Y.p[ms_at_from(Y, n, c, y, x, vb, vbx)];
+        float d = out[0][e] + 2.0f * xv * out[1][e] + yv * out[2][e];
         if (dnext) d += 0.25f * dnext[((size_t)nc * Hn + ((y + py) >> 1)) * Wn + ((x + px) >> 1)];
-        DX.p[ms_at(DX, n, c, y, x)] = d;
+        DX.p[ms_at_from(DX, n, c, y, x, vb, vbx)] = d;
     }
 }
 
