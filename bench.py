@@ -86,9 +86,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent scenes of a step are spread over (1 = the reference's sequential loop)")
     ap.add_argument("--ms-ssim", action="store_true",
-                    help="add the reference's 0.5 (1 - MS_SSIM) term (loss.py:41-45) to the timed step's loss: lara_amd.loss.ms_ssim, plain "
-                         "torch operators (outside SURVEY.md section 8; the package the reference imports is absent).  Default: the "
-                         "step is timed WITHOUT it (the workload string says so) and `step_with_ms_ssim` reports the step with it")
+                    help="add the reference's 0.5 (1 - MS_SSIM) term (loss.py:41-45) to the timed step's loss = its whole loss: "
+                         "lara_amd.loss.ms_ssim_fused (HIP kernels, csrc/msssim.hip; the package the reference imports is absent: held to "
+                         "the restatement).  Default: the step is timed WITHOUT it (the workload string says so; the definition of "
+                         "rounds 1-4) and `step_with_ms_ssim` reports the step with it in the same run")
     ap.add_argument("--lr", type=float, default=0.0,
                     help="learning rate of the AdamW update inside the timed step (--step pipeline).  Default 0: every kernel of the "
                          "update runs and the parameters' version counters advance (the bf16 operand caches of the HIP modules are "
