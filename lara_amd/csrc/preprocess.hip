@@ -127,9 +127,10 @@ surfel_forward(const ViewDev &v, const int idx, const float *__restrict__ means3
                const float *__restrict__ opacities, const float2 *__restrict__ scales,
                const float4 *__restrict__ rotations, const float *__restrict__ transmat_precomp,
                float4 *__restrict__ geom, float4 *__restrict__ cullbox,
-               int32_t *__restrict__ radii) {
+               int32_t *__restrict__ radii, float &depth_out) {
     const ushort4 culled = make_ushort4(0, 0, 0, 0);
     radii[idx] = 0;
+    depth_out = 0.f;
 
     const float p[3] = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     float p_view[3];
@@ -243,6 +244,7 @@ surfel_forward(const ViewDev &v, const int idx, const float *__restrict__ means3
     g[3] = make_float4(normal[0], normal[1], normal[2], p_view[2]);
     g[4] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(clamp_bits));
     radii[idx] = max_radius;
+    depth_out = p_view[2];
     return make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
                         (unsigned short)ry1);
 }
@@ -267,9 +269,10 @@ preprocess_fwd_block(const ViewDev &v, const int block, const float *__restrict_
         __syncthreads();
     }
     ushort4 r = make_ushort4(0, 0, 0, 0);
+    float view_depth = 0.f;
     if (idx < v.P)
         r = surfel_forward<DEG>(v, idx, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                transmat_precomp, geom, cullbox, radii);
+                                transmat_precomp, geom, cullbox, radii, view_depth);
     // exclusive scan of the tiles touched inside the workgroup: surfel-major pair numbering, used by
     // the backward to gather a surfel's per-tile gradient rows without atomics
     const uint32_t tt = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
@@ -289,7 +292,10 @@ preprocess_fwd_block(const ViewDev &v, const int block, const float *__restrict_
     if (threadIdx.x == 255) block_tot[block] = woff + incl;
     if (idx < v.P) {
         // tile rectangle + depth key bits + local pair offset, 16 B per surfel, for the scatter pass
-        const float depth = tt ? geom[(size_t)idx * 5 + 3].w : 0.f;
+        // (the depth the record holds, from the register: reading it back from `geom` missed the L2 -- the record's stores do not
+        // allocate there -- and cost a 64-byte fetch per surfel: FETCH_SIZE said 92 MB for this kernel's 46 MB of inputs in rounds
+        // 1-4; tools/ubench/traffic_calib.hip's surfel88 / rec80_write patterns rule the other explanations out)
+        const float depth = tt ? view_depth : 0.f;
         rect_out[idx] = make_uint4((uint32_t)r.x | ((uint32_t)r.y << 16), (uint32_t)r.z | ((uint32_t)r.w << 16),
                                    __float_as_uint(depth), woff + incl - tt);
     }

@@ -66,6 +66,16 @@ __global__ void surfel88(const float *__restrict__ means, const float2 *__restri
     const float4 q = rot[i], a = shs[3 * i], b = shs[3 * i + 1], c = shs[3 * i + 2];
     out[i] = means[3 * i] + means[3 * i + 1] + means[3 * i + 2] + s.x + s.y + q.x + q.w + opa[i] + a.x + b.y + c.z;
 }
+// thread i WRITES record i = five float4 at an 80-byte stride (how preprocess_fwd writes `geom`): each store instruction leaves
+// 16-byte pieces in 64 different lines -- does the L2 fetch the lines it is asked to write partially?
+__global__ void rec80_write(float4 *__restrict__ rec, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 *r = rec + i * 5;
+    const float f = (float)(i & 255);
+    r[0] = make_float4(f, 1.f, 2.f, 3.f); r[1] = make_float4(f, 4.f, 5.f, 6.f); r[2] = make_float4(f, 7.f, 8.f, 9.f);
+    r[3] = make_float4(f, 1.f, 3.f, 5.f); r[4] = make_float4(f, 2.f, 4.f, 6.f);
+}
 __global__ void stream16_small(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { float4 v = in[i]; v.x += 1.0f; out[i] = v; }
@@ -102,6 +112,7 @@ int main() {
         hipLaunchKernelGGL(rec80_seq, grid(N), dim3(blk), 0, 0, (const float4 *)big, out, N);
         hipLaunchKernelGGL(rec80_gather, grid(N), dim3(blk), 0, 0, idx, (const float4 *)big, out, N);
         hipLaunchKernelGGL(line128_gather, grid(N), dim3(blk), 0, 0, idx, (const float4 *)big, out, N);
+        hipLaunchKernelGGL(rec80_write, grid(N), dim3(blk), 0, 0, (float4 *)big, N);                                         // 0 in, 1.34 GB out
         hipLaunchKernelGGL(aos12, grid(N * 4), dim3(blk), 0, 0, big, big + N * 16, N * 4);                                    // 805 MB in, 268 MB out
         // five arrays laid one after the other in `big`: 12 + 8 + 16 + 4 + 48 = 88 bytes per surfel, N surfels
         hipLaunchKernelGGL(surfel88, grid(N), dim3(blk), 0, 0, big, (const float2 *)(big + N * 3), (const float4 *)(big + N * 5 + 0),
@@ -121,13 +132,13 @@ int main() {
            "\"rec80_seq\": {\"read\": %zu, \"write\": %zu}, "
            "\"rec80_gather\": {\"read\": %zu, \"read_unique_bytes\": %zu, \"write\": %zu}, "
            "\"line128_gather\": {\"read\": %zu, \"write\": %zu}, "
-           "\"aos12\": {\"read\": %zu, \"write\": %zu}, \"surfel88\": {\"read\": %zu, \"write\": %zu}, "
+           "\"rec80_write\": {\"read\": %zu, \"write\": %zu}, \"aos12\": {\"read\": %zu, \"write\": %zu}, \"surfel88\": {\"read\": %zu, \"write\": %zu}, "
            "\"stream16_small\": {\"read\": %zu, \"write\": %zu}, "
            "\"rec80_gather_small\": {\"read_unique_bytes\": %zu, \"read\": %zu, \"write\": %zu}}}\n",
            // a gathered 80-byte record = 1.5 lines of 128 bytes (+ its 4-byte index): what must cross the L2's memory side when no
            // line is reused (a permutation over 1.3 GB; at the small size every reference still misses the 4 MB L2)
            N, N * 64, N * 64, N * 64, N * 64, N * 80, N * 4, N * 4 + N * 192, N * 84, N * 4, N * 132, N * 4,
-           N * 48, N * 16, N * 88, N * 4,
+           (size_t)1, N * 80, N * 48, N * 16, N * 88, N * 4,
            NS * 16, NS * 16, NR * 80 + NG * 4, NG * 4 + NG * 192, NG * 4);
     return 0;
 }
