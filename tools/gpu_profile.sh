@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 if [ "${ONLY_RASTER:-0}" != "1" ]; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_train -o stats -- \
     python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats_train.log 2>&1
-# (a') the pipeline step on ONE stream and one view lane: every kernel of the step, torch's included, serialised
+# (a') the pipeline step on ONE stream: every kernel of the step, torch's included, serialised
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats_pipe1 -o stats -- \
     python $REPO/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-side-legs --no-roofline $EXTRA > $OUT/prof_${TAG}_stats_pipe1.log 2>&1
 fi
