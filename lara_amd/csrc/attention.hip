@@ -57,7 +57,8 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
         unsigned short *wqp = (unsigned short *)workspace, *wop = wqp + 65536;
         hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, wq, wqp);
         hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, wo, wop);
-        hipLaunchKernelGGL(group_attn_fused2_kernel, dim3(units), dim3(64), 0, s, x, ln_weight, ln_bias, eps, wqp, kvf, wop, y, G);
+        hipLaunchKernelGGL(group_attn_fused2_kernel<false>, dim3(units), dim3(64), 0, s, x, ln_weight, ln_bias, eps, wqp, kvf, wop, y, G,
+                           (unsigned short *)nullptr, (unsigned short *)nullptr, (unsigned short *)nullptr);
     }
     L2D_CHECK_LAUNCH();
     return LARA2DGS_OK;

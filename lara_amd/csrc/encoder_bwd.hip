@@ -911,7 +911,7 @@ void gemm_nt(const unsigned short *A, const unsigned short *W, void *C, int M, i
 // start of the block's save area: 7.2 KB per token row, 0.94 GB per layer at 4 scenes x 32^3 -- 11 GB for the
 // 12 layers, which a 288 GB part holds without thinking (recomputing them instead costs 0.6 ms per layer).
 struct SaveWs {
-    size_t xn1, q, kv, o, x1, xn2, z, h, x2, xn3, stats, total;
+    size_t xn1, q, kv, o, x1, xn2, z, h, x2, xn3, stats, wpack, total;
 };
 SaveWs save_layout(int64_t M) {
     SaveWs w{};
@@ -922,6 +922,7 @@ SaveWs save_layout(int64_t M) {
     w.x1 = take(f256); w.xn2 = take(b256); w.z = take(b512); w.h = take(b512); w.x2 = take(f256);
     w.xn3 = take(b256 + 512);  // + the zeroed row (index M) the gathers read outside the volume
     w.stats = take((size_t)M * 8);
+    w.wpack = take(2 * 256 * 256 * 2);   // W_q and W_o in the fused attention kernel's fragment order
     w.total = o;
     return w;
 }
@@ -955,15 +956,21 @@ int block_forward_keep(int M, int cond_dim, const float *x_in, const unsigned sh
     unsigned short *o = (unsigned short *)(save + L.o), *xn2 = (unsigned short *)(save + L.xn2), *z = (unsigned short *)(save + L.z);
     unsigned short *h = (unsigned short *)(save + L.h), *xn3 = (unsigned short *)(save + L.xn3);
     float *x1 = (float *)(save + L.x1), *x2 = (float *)(save + L.x2);
-    hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x_in, w->ln1_w, w->ln1_b, w->eps, xn1, (float2 *)nullptr, M);
-    gemm_nt<0>(xn1, w->wq, q, M, 256, 256, nullptr, nullptr, s);
+    // the attention step: the K|V projection + ONE fused kernel (LayerNorm, Q projection, attention, output projection +
+    // residual) that also leaves LN(x), Q and the attention's output for the backward (group_attn_fused2_kernel<true>; until
+    // round 5 the training forward ran the five separate launches because only they kept those rows: 284 -> ~240 us per layer)
     {
         GemmP p{};
         p.A = cond_bf16; p.W = w->wkv; p.C = kv; p.M = Mkv; p.N = 512; p.K = cond_dim;
         if (launch_gemm_ring<0, 0>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     }
-    hipLaunchKernelGGL(group_attn_kernel, dim3((G + 15) / 16), dim3(256), 0, s, q, kv, o, G);
-    gemm_nt<1>(o, w->wo, x1, M, 256, 256, x_in, nullptr, s);
+    {
+        unsigned short *wqp = (unsigned short *)(save + L.wpack), *wop = wqp + 65536;
+        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, w->wq, wqp);
+        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, w->wo, wop);
+        hipLaunchKernelGGL(group_attn_fused2_kernel<true>, dim3((G + 3) / 4), dim3(64), 0, s, x_in, w->ln1_w, w->ln1_b, w->eps, wqp, kv, wop,
+                           x1, G, xn1, q, o);
+    }
     hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x1, w->ln2_w, w->ln2_b, w->eps, xn2, (float2 *)nullptr, M);
     {
         GemmP p{};
