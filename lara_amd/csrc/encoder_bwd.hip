@@ -193,7 +193,11 @@ gemm_bf16_tn_kernel(const TnP p) {
 // barrier per stage (8 MFMAs per wave).
 // Needs M % 32 == 0 and 16-byte aligned rows (lda, ldb, N, Kc multiples of 8); the host falls back to the
 // direct kernel otherwise.  Same workgroup -> (tile, split) mapping, same partial-tile output.
+// (Round 5 measured deeper rings under a counted vmcnt on the same box -- four 16-row stages in the same 32 KB: 754 us, the barrier
+// per four MFMAs costs more than the prefetch returns; three / four 32-row stages at three / two workgroups per CU: 897 / 843 us, the
+// 864 workgroups no longer fit the device at once -- against 498-517 us for this form: two stages, four workgroups per CU.)
 constexpr int TL_ROWS = 32, TL_STAGES = 2, TL_TILE = TL_ROWS * 256, TL_STAGE = 2 * TL_TILE;
+constexpr int TL_WROWS = TL_ROWS / 4, TL_PIECES = TL_WROWS / 4;      // rows a wave moves per stage, as 4-row pieces
 
 template <bool GATHER>
 __global__ void __launch_bounds__(256)
@@ -222,17 +226,20 @@ gemm_bf16_tn_lds_kernel(const TnGroup grp) {
     const int dchunk = (lane & 15) ^ (drow << 2);
     const uint32_t acol2 = (uint32_t)min(nt * 128 + dchunk * 8, p.N - 8) * 2u;
     const uint32_t bcol2 = (uint32_t)min(kc0 + dchunk * 8, p.Kc - 8) * 2u;
-    int tn[8];  // GATHER: byte offsets of this wave's 8 B rows of the next stage to be issued
+    int tn[TL_WROWS];  // GATHER: byte offsets of this wave's B rows of the next stage to be issued
     auto table = [&](const int st) {
-        const int *t = nb + min(m_start + st * TL_ROWS, p.M - TL_ROWS) + 8 * wave;
+        // (a provably wave-uniform address in the constant address space: the table arrives by s_load instead of a vector load whose
+        // vmcnt(0) the compiler put in front of every use -- round 5: the convolution's weight gradient 537-580 -> 498-517 us)
+        const int *t = nb + __builtin_amdgcn_readfirstlane(min(m_start + st * TL_ROWS, p.M - TL_ROWS) + TL_WROWS * wave);
+        const __attribute__((address_space(4))) int *t4 = (const __attribute__((address_space(4))) int *)t;   // read-only table: constant address space -> s_load
 #pragma unroll
-        for (int e = 0; e < 8; e++) tn[e] = t[e];
+        for (int e = 0; e < TL_WROWS; e++) tn[e] = t4[e];
     };
     auto issue = [&](const int st) {  // this wave's four pieces of stage st
         unsigned char *buf = lds + (st % TL_STAGES) * TL_STAGE;
-        const uint32_t row0 = (uint32_t)(m_start + st * TL_ROWS + 8 * wave);
+        const uint32_t row0 = (uint32_t)(m_start + st * TL_ROWS + TL_WROWS * wave);
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < TL_PIECES; q++) {
             const uint32_t arow = row0 + 4 * q + drow;
             uint32_t boff;
             if (GATHER) {
@@ -242,9 +249,9 @@ gemm_bf16_tn_lds_kernel(const TnGroup grp) {
                 boff = arow * ldb2;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ab + (arow * lda2 + acol2)),
-                                             (__attribute__((address_space(3))) void *)(buf + (2 * wave + q) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(buf + (TL_PIECES * wave + q) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Bb + (boff + bcol2)),
-                                             (__attribute__((address_space(3))) void *)(buf + TL_TILE + (2 * wave + q) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(buf + TL_TILE + (TL_PIECES * wave + q) * 1024), 16, 0, 0);
         }
     };
 
@@ -275,7 +282,7 @@ gemm_bf16_tn_lds_kernel(const TnGroup grp) {
         }
         const unsigned char *buf = lds + (st % TL_STAGES) * TL_STAGE;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
+        for (int s2 = 0; s2 < TL_ROWS / 16; s2++) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
