@@ -1843,6 +1843,20 @@ def main():
             roof["valu_useful_frac"] = round(pairs * USEFUL_FMA_PER_PAIR[roof["kernel"]] / (roof["valu_insts_per_launch"] * 64.0), 4)
             roof["valu_useful_what"] = (f"{pairs} blended (pixel, splat) pairs of view 0 (counted by the CPU oracle in this run) x "
                                         f"{USEFUL_FMA_PER_PAIR[roof['kernel']]} FMA-equivalents / (SQ_INSTS_VALU x 64 lanes: {roof['valu_insts_source']})")
+    # the other definitions of the step measured in this same run, inside `config` (a reader that keeps `config` but only the NAMES of
+    # the side objects still sees what the headline is and is not): frames/s, ms per step
+    also = {}
+    for key, label in (("step_with_ms_ssim", "with_the_references_ms_ssim_term_its_whole_loss"),
+                       ("step_with_reference_lr", "with_the_references_learning_rate_4e-4_for_the_timed_steps"),
+                       ("trained_like_step", "trained_like_regime"), ("drop_in_step", "as_an_unmodified_lara_issues_it_around_the_shim"),
+                       ("ddp_single_rank_rccl", "under_single_rank_rccl_ddp")):
+        o = out.get(key)
+        if isinstance(o, dict) and "value" in o:
+            also[label] = {"frames_per_s": o["value"], "ms_per_step": o.get("ms_per_step")}
+    if also:
+        out["config"]["headline_is"] = ("init regime (random-init network: the raster's worst case), AdamW at learning rate 0 (every kernel of the "
+                                        "update runs, the workload stays fixed), loss " + ("with" if args.ms_ssim else "WITHOUT") + " the MS-SSIM term")
+        out["config"]["same_run_other_definitions"] = also
     # the north star's second target (attention / encoder on the matrix cores) inside `roofline`, where a reader who keeps only
     # `roofline` and `cpu_baseline` of the line still finds it (the stand-alone objects stay for their details)
     roof = out.get("roofline")
