@@ -570,12 +570,218 @@ gemm_ring_kernel(const GemmP p) {
     ring_epilogue<EPI>(p, acc, ring, wave, lane, bm0, bn0, wr, wc);
 }
 
+// ---- the ring kernel, finely interleaved --------------------------------------------------------------
+// Same tiles, ring, swizzle and epilogues as gemm_ring_kernel; what changes is WHEN a wave issues its non-matrix
+// instructions.  Two waves share a SIMD's matrix pipe and alternate on it, so each has a ~32-cycle hole behind every MFMA
+// it issues; a K tile's 12 fragment reads and 4 LDS-DMA pieces (each tens of cycles of issue) fit in those holes only when
+// they are dealt one per MFMA -- gemm_ring_kernel issues them in two clumps (6 reads; 4 pieces + 6 reads) behind which both
+// waves of a SIMD, in lock-step after the barrier, leave the pipe idle.  Here
+//   * the K loop is unrolled over the ring (4 tiles): ring slots, LDS offsets and the DMA destinations are literals -- no
+//     address arithmetic on the vector ALU, M0 is a scalar move (the wave index is read into an SGPR once), a piece's global
+//     address is SGPR base + a lane offset that moves once per four tiles + the instruction's offset field;
+//   * tile kt+3 is issued DURING tile kt, a piece at a time between MFMAs, into the slot tile kt-1 left at the last barrier
+//     (two tiles and a half in flight instead of three); each wave waits for its pieces of tile kt+1 with a counted vmcnt;
+//   * fragment reads of the next K step are dealt one per MFMA in the order the next step consumes them, under the
+//     compiler's counted lgkmcnt waits.
+// Round 5, same box, LaRa's convolution (M = 131072, N = 256, K = 6912): gemm_ring_kernel 432-445 us -> 396-409 with the
+// interleave -> 401-402 with the two wave rows issuing in different K steps (its input gradient 425-435 -> 399-405).  Timing-only
+// builds of this loop (results invalid) place the rest: MFMAs alone 278 us (1.67 PF: the clock the part sustains), + fragment
+// reads 312, + pieces 362 (no barrier), + the barrier 408 -- the barrier costs nothing without the pieces (306): what it costs is
+// the waves' different luck at issuing them; frozen source addresses (everything from L1 / L2) change nothing (405).
+// Needs K % 128 == 0 (and Cin % 128 == 0 for the convolution); launch_gemm_ring falls back to gemm_ring_kernel otherwise.
+template <int AMODE, int EPI>
+__global__ void __launch_bounds__(512)
+gemm_ring2_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // RING * RTILE bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, N = p.N, K = p.K, Cin = AMODE ? p.Cin : 0;
+    int rt_, ct_;
+    xcd_tile(rt_, ct_);
+    const int bm0 = rt_ * RT, bn0 = ct_ * RT;
+    const int wr = wave >> 2, wc = wave & 3;  // wave tile: rows wr*128.., columns wc*64..
+    const int r = lane & 31, kh = lane >> 5;
+    const char *Ab = (const char *)p.A, *Wb = (const char *)p.W;
+
+    // staging (as gemm_ring_kernel): wave w moves pieces {2w, 2w+1} of the A panel and of the W panel
+    int srow[2];
+    uint32_t woff[2], noff[2];
+    int vb[2], vd[2], vh[2], vw[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        srow[q] = 32 * wave + 16 * q + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((srow[q] >> 2) & 3);
+        woff[q] = (uint32_t)min(bn0 + srow[q], N - 1) * (uint32_t)(K * 2) + chunk * 16;
+        if (AMODE == 1) {
+            token_to_voxel(min(bm0 + srow[q], M - 1), p.R, vb[q], vd[q], vh[q], vw[q]);
+            noff[q] = chunk * 16;
+        } else {
+            vb[q] = vd[q] = vh[q] = vw[q] = 0;
+            noff[q] = (uint32_t)min(bm0 + srow[q], M - 1) * (uint32_t)(K * 2) + chunk * 16;  // dense A row
+        }
+    }
+    auto set_tap = [&](const int tap) {   // the convolution's gathered rows of one tap
+        const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int nd = vd[q] + dz, nh = vh[q] + dy, nw = vw[q] + dx;
+            const bool in = (unsigned)nd < (unsigned)p.R && (unsigned)nh < (unsigned)p.R && (unsigned)nw < (unsigned)p.R;
+            const int chunk = (lane & 3) ^ ((srow[q] >> 2) & 3);
+            noff[q] = (in ? (uint32_t)voxel_to_token(vb[q], nd, nh, nw, p.R) * (uint32_t)(Cin * 2) : p.zero_off) + chunk * 16;
+        }
+    };
+    // issue side: the group (four K tiles = 128 channels) whose tiles are being fetched.  A piece's address is the operand's
+    // base (SGPR pair) + a 32-bit lane offset that moves once per group + the tile's 64 t bytes in the instruction's offset
+    // field; that field is added to the LDS address too, so M0 (a literal + the wave's base) is set 64 t lower.
+    const int gpt = AMODE ? Cin / 128 : 1;
+    int g_in_tap = 0, tap_i = 0;
+    if (AMODE == 1) set_tap(0);
+    auto next_group = [&]() {
+        woff[0] += 256; woff[1] += 256;
+        if (AMODE == 1 && ++g_in_tap == gpt) {
+            g_in_tap = 0;
+            set_tap(++tap_i);
+        } else {
+            noff[0] += 256; noff[1] += 256;
+        }
+    };
+    // (The piece is inline assembly on purpose: behind the compiler's own global_load_lds its waitcnt pass stops counting LDS
+    // returns and drains lgkmcnt to 0 in front of every MFMA that consumes a fragment -- i.e. each K step would start by waiting for
+    // the read issued two MFMAs earlier.  Invisible to that pass, the reads get the counted waits their issue order allows; the
+    // pieces themselves are only ever waited for by the explicit vmcnt below.)
+    const uint32_t mine = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ring + wave * 2048;
+#define R2_DMA(base, voff, lds, t)                                                                                   \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"                            \
+                 :: "s"((uint32_t)((lds) - (t) * 64)), "v"(voff), "s"(base), "n"((t) * 64) : "memory")
+    // piece 2 wave + q of tile t of the issue group, into ring slot `slot`
+#define R2_DMA_A(slot, t, q) R2_DMA(Ab, noff[q], mine + (slot) * RTILE + (q) * 1024, t)
+#define R2_DMA_W(slot, t, q) R2_DMA(Wb, woff[q], mine + (slot) * RTILE + RT * 64 + (q) * 1024, t)
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // fragment addresses inside a tile buffer (row * 64 + swizzled chunk * 16), for K steps 0 and 1
+    // (rows 32 i further are 2048 i bytes further with the same swizzle; ring slots 2 and 3 are beyond a ds_read's 16-bit offset
+    // field and get base registers of their own, pinned so that they are not re-derived with a vector add per read)
+    int aoff[2][2], boff[2][2];   // [K step][ring half]
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int ra = wr * 128 + r, rb = wc * 64 + r;
+        aoff[s][0] = ra * 64 + (((2 * s + kh) ^ ((ra >> 2) & 3)) << 4);
+        boff[s][0] = RT * 64 + rb * 64 + (((2 * s + kh) ^ ((rb >> 2) & 3)) << 4);
+        aoff[s][1] = aoff[s][0] + 2 * RTILE;
+        boff[s][1] = boff[s][0] + 2 * RTILE;
+        asm volatile("" : "+v"(aoff[s][1]), "+v"(boff[s][1]));
+    }
+    bf16x8 fa[2][4], fb[2][2];
+#define R2_SB __builtin_amdgcn_sched_barrier(0)
+#define R2_M(set, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0)
+#define R2_RA(set, i, slot, step) fa[set][i] = *(const bf16x8 *)(ring + ((slot) & 1) * RTILE + aoff[step][(slot) >> 1] + (i) * 2048)
+#define R2_RB(set, j, slot, step) fb[set][j] = *(const bf16x8 *)(ring + ((slot) & 1) * RTILE + boff[step][(slot) >> 1] + (j) * 2048)
+    // one K step: the eight MFMAs of fragment set USE, between them the six fragment reads of the step after it (set USE ^ 1,
+    // from ring slot `slot`, K step `step`) and pieces of tile `it` of the issue group (into slot `it`): MODE 1 = its A and W
+    // pieces number q, MODE 2 = all four, MODE 0 = none
+#define R2_HALF(USE, READ, slot, step, MODE, it, q)                      \
+    R2_M(USE, 0, 0); R2_SB;                                              \
+    if (READ) R2_RA(USE ^ 1, 0, slot, step);                             \
+    R2_SB; R2_M(USE, 0, 1); R2_SB;                                       \
+    if (READ) R2_RB(USE ^ 1, 0, slot, step);                             \
+    if ((MODE) == 2) R2_DMA_A(it, it, 0);                                \
+    R2_SB; R2_M(USE, 1, 0); R2_SB;                                       \
+    if (READ) R2_RB(USE ^ 1, 1, slot, step);                             \
+    if ((MODE) == 1) R2_DMA_A(it, it, q);                                \
+    if ((MODE) == 2) R2_DMA_W(it, it, 0);                                \
+    R2_SB; R2_M(USE, 1, 1); R2_SB;                                       \
+    if (READ) R2_RA(USE ^ 1, 1, slot, step);                             \
+    if ((MODE) == 2) R2_DMA_A(it, it, 1);                                \
+    R2_SB; R2_M(USE, 2, 0); R2_SB;                                       \
+    if (READ) R2_RA(USE ^ 1, 2, slot, step);                             \
+    if ((MODE) == 1) R2_DMA_W(it, it, q);                                \
+    if ((MODE) == 2) R2_DMA_W(it, it, 1);                                \
+    R2_SB; R2_M(USE, 2, 1); R2_SB;                                       \
+    if (READ) R2_RA(USE ^ 1, 3, slot, step);                             \
+    R2_SB; R2_M(USE, 3, 0); R2_M(USE, 3, 1); R2_SB;
+    // tile t of a group sits in ring slot t; during it the tile three further on (slot and tile-in-group (t + 3) & 3) is issued:
+    // M1 / M2 = what the first / second K step issues.  VM = this wave's younger pieces allowed in flight when its pieces of the
+    // NEXT tile must have landed (-1: there is no next tile)
+#define R2_TILE(t, M1, M2, VM)                                                                  \
+    R2_HALF(0, true, t, 1, M1, ((t) + 3) & 3, 0)                                                \
+    if ((VM) >= 0) {                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+        if ((VM) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                         \
+        else if ((VM) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                    \
+        else if ((VM) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_s_barrier();                                                           \
+    }                                                                                           \
+    R2_SB;                                                                                      \
+    R2_HALF(1, (VM) >= 0, ((t) + 1) & 3, 0, M2, ((t) + 3) & 3, 1)
+    // the K loop; VMS = VM of the steady state (= of the last group's first tile)
+#define R2_LOOP(M1, M2, VMS)                                      \
+    for (int g = 0, groups = K / 128; g + 1 < groups; g++) {      \
+        R2_TILE(0, M1, M2, VMS)                                   \
+        next_group();                                             \
+        R2_SB;                                                    \
+        R2_TILE(1, M1, M2, VMS)                                   \
+        R2_TILE(2, M1, M2, VMS)                                   \
+        R2_TILE(3, M1, M2, VMS)                                   \
+    }                                                             \
+    R2_TILE(0, M1, M2, VMS)                                       \
+    R2_TILE(1, 0, 0, 4)                                           \
+    R2_TILE(2, 0, 0, 0)                                           \
+    R2_TILE(3, 0, 0, -1)
+
+    // prologue: tiles 0, 1, 2
+    R2_DMA_A(0, 0, 0); R2_DMA_W(0, 0, 0); R2_DMA_A(0, 0, 1); R2_DMA_W(0, 0, 1);
+    R2_DMA_A(1, 1, 0); R2_DMA_W(1, 1, 0); R2_DMA_A(1, 1, 1); R2_DMA_W(1, 1, 1);
+    R2_DMA_A(2, 2, 0); R2_DMA_W(2, 2, 0); R2_DMA_A(2, 2, 1); R2_DMA_W(2, 2, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    R2_RA(0, 0, 0, 0); R2_RB(0, 0, 0, 0); R2_RB(0, 1, 0, 0); R2_RA(0, 1, 0, 0); R2_RA(0, 2, 0, 0); R2_RA(0, 3, 0, 0);
+    R2_SB;
+    // a SIMD holds one wave of each wave row (waves w and w + 4): row 0 issues a tile's four pieces during the first K step, row 1
+    // during the second, so that the two waves sharing a matrix pipe are never both held up behind a piece at the same time
+    // (measured against every wave issuing two pieces per K step, R2_LOOP(1, 1, 6): convolution 407-409 -> 401-402 us)
+    if (wr == 0) {
+        R2_LOOP(2, 0, 8)
+    } else {
+        R2_LOOP(0, 2, 4)
+    }
+#undef R2_LOOP
+#undef R2_TILE
+#undef R2_DMA_A
+#undef R2_DMA_W
+#undef R2_DMA
+#undef R2_HALF
+#undef R2_RA
+#undef R2_RB
+#undef R2_M
+#undef R2_SB
+    __syncthreads();
+
+    // ring_epilogue's accumulator order is acc[i][j] too
+    ring_epilogue<EPI>(p, acc, ring, wave, lane, bm0, bn0, wr, wc);
+}
+
 // host-side launch of the ring kernel (dynamic LDS above the 64 KB default needs the attribute once)
 template <int AMODE, int EPI>
 static inline hipError_t launch_gemm_ring(const GemmP &p, hipStream_t s) {
     static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_ring_kernel<AMODE, EPI>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, RING * RTILE);
     if (attr != hipSuccess) return attr;
+    if (p.K % 128 == 0 && (!AMODE || p.Cin % 128 == 0)) {
+        static const hipError_t attr2 = hipFuncSetAttribute((const void *)gemm_ring2_kernel<AMODE, EPI>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, RING * RTILE);
+        if (attr2 != hipSuccess) return attr2;
+        hipLaunchKernelGGL((gemm_ring2_kernel<AMODE, EPI>), dim3((p.M + RT - 1) / RT, (p.N + RT - 1) / RT), dim3(512),
+                           RING * RTILE, s, p);
+        return hipSuccess;
+    }
     hipLaunchKernelGGL((gemm_ring_kernel<AMODE, EPI>), dim3((p.M + RT - 1) / RT, (p.N + RT - 1) / RT), dim3(512),
                        RING * RTILE, s, p);
     return hipSuccess;
