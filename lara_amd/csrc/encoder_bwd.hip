@@ -322,6 +322,207 @@ gemm_bf16_tn_lds_kernel(const TnGroup grp) {
         }
 }
 
+// ---- the convolution's weight gradient on a 256 x 256 tile ---------------------------------------------
+// gemm_bf16_tn_lds_kernel<true> for N = Kc = 256, restructured like gemm_ring2_kernel (mfma_gemm.h): one workgroup of 8 waves
+// (2 x 4, wave tile 128 x 64) owns ALL 256 x 256 outputs of one (tap, token split), so a stage of 32 token rows (2 x 16 KB) feeds
+// 16 MFMAs per wave instead of 8 -- half the LDS-DMA pieces, fragment reads and barriers per MFMA -- and travels through a ring of
+// four stages (128 KB, one workgroup per CU): stage st+3 is issued during stage st, a piece at a time between MFMAs (wave row 0
+// in the first K step, row 1 in the second), each wave waits for its pieces of stage st+1 with a counted vmcnt, one barrier per
+// stage, fragment reads (ds_read_b64_tr_b16, the same [row][512 B] image with the 16-byte chunk index XORed by (row & 3) << 2)
+// dealt over the MFMAs of the K step before.  The gathered rows' byte offsets (four per wave and stage) come through the scalar
+// cache one stage ahead.  T x splits workgroups, dealt so that one XCD gets consecutive (split, tap) pairs: the 27 taps of a split
+// read the same rows of A and overlapping rows of B through that XCD's L2.
+struct TnRingP {
+    const unsigned short *A, *B;
+    float *part;     // [splits][256][T * 256]
+    const int *nbr;  // [T][M] byte offsets of the B rows
+    int M, lda, ldb, T, chunk, splits;   // chunk: token rows per split, a multiple of 128
+};
+constexpr int TR_TILE = 32 * 512, TR_STAGE = 2 * TR_TILE, TR_RING = 4;
+
+__global__ void __launch_bounds__(512)
+gemm_tn_ring_kernel(const TnRingP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // TR_RING * TR_STAGE bytes
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // workgroup -> (split, tap): ids go round-robin over the 8 XCDs; XCD x takes the x-th run of consecutive pairs
+    const int total = p.T * p.splits, xcd = blockIdx.x & 7, q8 = total >> 3, rem = total & 7;
+    const int pi = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (blockIdx.x >> 3);
+    const int split = pi / p.T, tap = pi - split * p.T;
+    const int m_start = split * p.chunk, m_end = min(p.M, m_start + p.chunk);
+    const int groups = max(0, (m_end - m_start) >> 7);   // four stages each
+    const uint32_t lda2 = (uint32_t)p.lda * 2u;
+
+    // staging: wave w moves rows 4w .. 4w+3 of a stage of each operand, as two 2-row pieces; lane L lands in row 4w + 2q + (L >> 5),
+    // physical chunk L & 31, and fetches the logical chunk (L & 31) ^ ((row & 3) << 2)
+    const int hrow = lane >> 5;
+    const uint32_t hmask = hrow ? ~0u : 0u;
+    uint32_t aoffq[2], bch[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int rr = 2 * q + hrow;   // == row & 3
+        const uint32_t lc = (uint32_t)((lane & 31) ^ (rr << 2));
+        aoffq[q] = (uint32_t)(m_start + 4 * wave + rr) * lda2 + lc * 16u;
+        bch[q] = lc * 16u;
+    }
+    const char *pa = (const char *)p.A;   // + the stage being issued
+    const char *const Bb = (const char *)p.B;
+    const __attribute__((address_space(4))) int *pt =
+        (const __attribute__((address_space(4))) int *)(p.nbr + (size_t)tap * p.M + m_start + 4 * wave);   // + the stage whose offsets are loaded
+    int tn[2][4];   // [stage parity]: byte offsets of this wave's four B rows
+    const uint32_t mine = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ring + wave * 2048;
+#define TR_DMA(base, voff, lds)                                                                      \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                      \
+                 :: "s"((uint32_t)(lds)), "v"(voff), "s"(base) : "memory")
+#define TR_DMA_A(slot, q) TR_DMA(pa, aoffq[q], mine + (slot) * TR_STAGE + (q) * 1024)
+#define TR_DMA_B(slot, q, par)                                                                       \
+    {                                                                                                \
+        const uint32_t bo_ = ((uint32_t)(tn[par][2 * (q) + 1] - tn[par][2 * (q)]) & hmask) + (uint32_t)tn[par][2 * (q)] + bch[q]; \
+        TR_DMA(Bb, bo_, mine + (slot) * TR_STAGE + TR_TILE + (q) * 1024);                             \
+    }
+#define TR_TABLE(par)                                                                                \
+    {                                                                                                \
+        tn[par][0] = pt[0]; tn[par][1] = pt[1]; tn[par][2] = pt[2]; tn[par][3] = pt[3];              \
+        pt += 32;                                                                                    \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // fragment addresses inside a stage (gemm_bf16_tn_lds_kernel's, with 512-byte rows): K step s covers rows 16 s .., a
+    // fragment is two transposing reads (rows + 0 and + 4); ring slots 2 and 3 get base registers of their own
+    const int g16 = lane >> 4, l = lane & 15, kh = g16 >> 1;
+    const int frow = 8 * kh + (l >> 2);
+    auto faddr = [&](const int col) { return frow * 512 + ((((col >> 3) ^ ((frow & 3) << 2))) << 4) + (col & 7) * 2; };
+    int aaddr[4][2], baddr[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        aaddr[i][0] = faddr(wr * 128 + 32 * i + 16 * (g16 & 1) + 4 * (l & 3));
+        aaddr[i][1] = aaddr[i][0] + 2 * TR_STAGE;
+        asm volatile("" : "+v"(aaddr[i][1]));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        baddr[j][0] = TR_TILE + faddr(wc * 64 + 32 * j + 16 * (g16 & 1) + 4 * (l & 3));
+        baddr[j][1] = baddr[j][0] + 2 * TR_STAGE;
+        asm volatile("" : "+v"(baddr[j][1]));
+    }
+    bf16x8 fa[2][4], fb[2][2];
+#define TR_SB __builtin_amdgcn_sched_barrier(0)
+#define TR_M(set, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0)
+#define TR_RD(dst, addr)                                                                                                        \
+    {                                                                                                                           \
+        union { bf16x4 h[2]; bf16x8 v; } u_;                                                                                    \
+        u_.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(ring + (addr)));          \
+        u_.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(ring + (addr) + 4 * 512)); \
+        dst = u_.v;                                                                                                             \
+    }
+#define TR_RA(set, i, slot, step) TR_RD(fa[set][i], ((slot) & 1) * TR_STAGE + (step) * (16 * 512) + aaddr[i][(slot) >> 1])
+#define TR_RB(set, j, slot, step) TR_RD(fb[set][j], ((slot) & 1) * TR_STAGE + (step) * (16 * 512) + baddr[j][(slot) >> 1])
+    // one K step: the eight MFMAs of fragment set USE, between them the fragment reads of the step after it (set USE ^ 1, ring slot
+    // `slot`, K step `step`) and, if ISSUE, the four pieces of the stage three further on (ring slot `is`, offsets of parity `par`);
+    // TAB: the offsets of the stage after that one are requested behind the seventh MFMA (of the SECOND K step: the scalar load
+    // shares lgkmcnt with the fragment reads, and the first K step ends in the drain before the barrier)
+#define TR_HALF(USE, READ, slot, step, ISSUE, is, par, TAB)               \
+    TR_M(USE, 0, 0); TR_SB;                                              \
+    if (READ) TR_RA(USE ^ 1, 0, slot, step);                             \
+    TR_SB; TR_M(USE, 0, 1); TR_SB;                                       \
+    if (READ) TR_RB(USE ^ 1, 0, slot, step);                             \
+    if (ISSUE) TR_DMA_A(is, 0);                                          \
+    TR_SB; TR_M(USE, 1, 0); TR_SB;                                       \
+    if (READ) TR_RB(USE ^ 1, 1, slot, step);                             \
+    if (ISSUE) TR_DMA_A(is, 1);                                          \
+    TR_SB; TR_M(USE, 1, 1); TR_SB;                                       \
+    if (READ) TR_RA(USE ^ 1, 1, slot, step);                             \
+    if (ISSUE) TR_DMA_B(is, 0, par);                                     \
+    TR_SB; TR_M(USE, 2, 0); TR_SB;                                       \
+    if (READ) TR_RA(USE ^ 1, 2, slot, step);                             \
+    if (ISSUE) { TR_DMA_B(is, 1, par); pa += 32 * lda2; }                \
+    TR_SB; TR_M(USE, 2, 1); TR_SB;                                       \
+    if (READ) TR_RA(USE ^ 1, 3, slot, step);                             \
+    TR_SB; TR_M(USE, 3, 0); TR_SB;                                       \
+    if (TAB) TR_TABLE(par ^ 1);                                          \
+    TR_SB; TR_M(USE, 3, 1); TR_SB;
+    // stage t of a group sits in ring slot t; I1 / I2: the first / second K step issues stage t + 3 (slot (t + 3) & 3, offsets of
+    // parity (t + 3) & 1); TAB: request the offsets of stage t + 4.  VM = this wave's younger pieces allowed in flight when its
+    // pieces of the NEXT stage must have landed (-1: there is no next stage)
+#define TR_TILE_(t, I1, I2, TAB, VM)                                                            \
+    TR_HALF(0, true, t, 1, I1, ((t) + 3) & 3, ((t) + 3) & 1, false)                             \
+    if ((VM) >= 0) {                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+        if ((VM) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                         \
+        else if ((VM) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_s_barrier();                                                           \
+    }                                                                                           \
+    TR_SB;                                                                                      \
+    TR_HALF(1, (VM) >= 0, ((t) + 1) & 3, 0, I2, ((t) + 3) & 3, ((t) + 3) & 1, TAB)
+#define TR_LOOP(I1, I2, VMS)                                      \
+    for (int g = 0; g + 1 < groups; g++) {                        \
+        TR_TILE_(0, I1, I2, true, VMS)                            \
+        TR_TILE_(1, I1, I2, true, VMS)                            \
+        TR_TILE_(2, I1, I2, true, VMS)                            \
+        TR_TILE_(3, I1, I2, true, VMS)                            \
+    }                                                             \
+    TR_TILE_(0, I1, I2, false, VMS)                               \
+    TR_TILE_(1, false, false, false, 4)                           \
+    TR_TILE_(2, false, false, false, 0)                           \
+    TR_TILE_(3, false, false, false, -1)
+
+    if (groups > 0) {
+        // prologue: stages 0, 1, 2 (and the offsets of stage 3)
+        TR_TABLE(0)
+        TR_DMA_A(0, 0); TR_DMA_A(0, 1); TR_DMA_B(0, 0, 0); TR_DMA_B(0, 1, 0); pa += 32 * lda2;
+        TR_TABLE(1)
+        TR_DMA_A(1, 0); TR_DMA_A(1, 1); TR_DMA_B(1, 0, 1); TR_DMA_B(1, 1, 1); pa += 32 * lda2;
+        TR_TABLE(0)
+        TR_DMA_A(2, 0); TR_DMA_A(2, 1); TR_DMA_B(2, 0, 0); TR_DMA_B(2, 1, 0); pa += 32 * lda2;
+        TR_TABLE(1)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        TR_RA(0, 0, 0, 0); TR_RB(0, 0, 0, 0); TR_RB(0, 1, 0, 0); TR_RA(0, 1, 0, 0); TR_RA(0, 2, 0, 0); TR_RA(0, 3, 0, 0);
+        TR_SB;
+        if (wr == 0) {
+            TR_LOOP(true, false, 8)
+        } else {
+            TR_LOOP(false, true, 4)
+        }
+    }
+#undef TR_LOOP
+#undef TR_TILE_
+#undef TR_HALF
+#undef TR_RA
+#undef TR_RB
+#undef TR_RD
+#undef TR_M
+#undef TR_SB
+#undef TR_TABLE
+#undef TR_DMA_B
+#undef TR_DMA_A
+#undef TR_DMA
+    // accumulator (i, j)[reg]: A column wr*128 + 32 i + (reg&3) + 8 (reg>>2) + 4 (lane>>5), B column wc*64 + 32 j + (lane&31)
+    const int ldc = p.T * 256;
+    float *out = p.part + (size_t)split * 256 * ldc + (size_t)tap * 256;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = wc * 64 + 32 * j + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int n = wr * 128 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                out[(size_t)n * ldc + col] = acc[i][j][e];
+            }
+        }
+}
+
 // dst[i] += sum over parts of part[s * stride + i]; 64 elements per workgroup, blockDim / 64 slices of the
 // parts (256 threads when there are many elements and few parts, 1024 for the opposite)
 __global__ void __launch_bounds__(1024)
@@ -763,8 +964,31 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     // 32-bit byte offsets and 24-bit row multiplies in the kernel
     if ((size_t)(M + 1) * lda * 2 >= (1ull << 32) || (size_t)(M + 1) * ldb * 2 >= (1ull << 32) || M >= (1 << 24) || ldb >= (1 << 23))
         return LARA2DGS_E_INVALID;
-    const int tiles = ((N + 127) / 128) * ((Kc + 127) / 128) * T;
     const size_t out_bytes = (size_t)N * T * Kc * 4;
+    const int n = N * T * Kc;
+#ifndef LARA_TN_OLD
+    if (nbr && N == 256 && Kc == 256 && (M & 127) == 0 && !(lda & 7) && !(ldb & 7) && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0) {
+        // the convolution's weight gradient: one 256 x 256 workgroup per (tap, split), one round of workgroups over the device
+        static const int cus = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+            return v > 0 ? v : 256;
+        }();
+        static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_tn_ring_kernel,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, TR_RING * TR_STAGE);
+        if (attr != hipSuccess) return LARA2DGS_E_LAUNCH;
+        const int g128 = M / 128;
+        int splits = max(1, min(min(cus / T, g128), (int)(TN_PART_BYTES / out_bytes)));
+        const int chunk = ((g128 + splits - 1) / splits) * 128;
+        splits = (M + chunk - 1) / chunk;   // every split has rows
+        TnRingP q{};
+        q.A = A; q.B = B; q.part = part; q.nbr = nbr; q.M = M; q.lda = lda; q.ldb = ldb; q.T = T; q.chunk = chunk; q.splits = splits;
+        hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(T * splits), dim3(512), TR_RING * TR_STAGE, s, q);
+        hipLaunchKernelGGL(accum_partials4_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
+        return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
+    }
+#endif
+    const int tiles = ((N + 127) / 128) * ((Kc + 127) / 128) * T;
     // about 1024 workgroups per launch (4 per CU: one round), in multiples of 8 splits (one per XCD, see the
     // kernel), at least 256 token rows each; a split that starts beyond M writes zeros
     const int want = 1024;
@@ -786,7 +1010,6 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
         if (nbr) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), dim3(tiles * splits), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), dim3(tiles * splits), dim3(256), 0, s, p);
     }
-    const int n = N * T * Kc;
     if ((n & 3) == 0 && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0 && (n / 4 + 63) / 64 < 128 && splits >= 64)
         hipLaunchKernelGGL(accum_partials4_wide_kernel, dim3((n / 4 + 63) / 64), dim3(1024), 0, s, dst, part, n, splits, (size_t)n);
     else if ((n & 3) == 0 && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0)
