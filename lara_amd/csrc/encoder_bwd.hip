@@ -334,43 +334,57 @@ gemm_bf16_tn_lds_kernel(const TnGroup grp) {
 // read the same rows of A and overlapping rows of B through that XCD's L2.
 struct TnRingP {
     const unsigned short *A, *B;
-    float *part;     // [splits][256][T * 256]
-    const int *nbr;  // [T][M] byte offsets of the B rows
-    int M, lda, ldb, T, chunk, splits;   // chunk: token rows per split, a multiple of 128
+    float *part;     // [splits][N][T * Kc]
+    const int *nbr;  // gathered B rows: [T][M] byte offsets (then N = Kc = 256), or null
+    int M, lda, ldb, T, ntile, ktile, Kc;   // N = 256 ntile, ktile = ceil(Kc / 256) (Kc % 8 == 0; gathered: Kc = 256); T taps (1 without nbr)
+    int chunk, splits;                  // chunk: token rows per split, a multiple of 128
+};
+// several products in one launch (the weight gradients of a block's linear layers): a workgroup finds its product through the
+// cumulative workgroup counts
+struct TnRingGroup {
+    TnRingP p[TN_GROUP_MAX];
+    int first_wg[TN_GROUP_MAX + 1];
+    int count;
 };
 constexpr int TR_TILE = 32 * 512, TR_STAGE = 2 * TR_TILE, TR_RING = 4;
 
+template <bool GATHER>
 __global__ void __launch_bounds__(512)
-gemm_tn_ring_kernel(const TnRingP p) {
+gemm_tn_ring_kernel(const TnRingGroup grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];  // TR_RING * TR_STAGE bytes
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    // workgroup -> (split, tap): ids go round-robin over the 8 XCDs; XCD x takes the x-th run of consecutive pairs
-    const int total = p.T * p.splits, xcd = blockIdx.x & 7, q8 = total >> 3, rem = total & 7;
-    const int pi = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (blockIdx.x >> 3);
-    const int split = pi / p.T, tap = pi - split * p.T;
+    int id = blockIdx.x, which = 0;
+    while (which + 1 < grp.count && id >= grp.first_wg[which + 1]) which++;
+    id -= grp.first_wg[which];
+    const TnRingP &p = grp.p[which];
+    // workgroup -> (split, tile): ids go round-robin over the 8 XCDs; an XCD takes a run of consecutive pairs (the tiles of a
+    // split read the same rows of A, and the same or overlapping rows of B, through that XCD's L2)
+    const int tiles = p.T * p.ntile * p.ktile, total = tiles * p.splits, xcd = id & 7, q8 = total >> 3, rem = total & 7;
+    const int pi = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (id >> 3);
+    const int split = pi / tiles, tile = pi - split * tiles;
+    const int tap = GATHER ? tile : 0, nt = GATHER ? 0 : tile / p.ktile, kt = GATHER ? 0 : tile - nt * p.ktile;
     const int m_start = split * p.chunk, m_end = min(p.M, m_start + p.chunk);
     const int groups = max(0, (m_end - m_start) >> 7);   // four stages each
-    const uint32_t lda2 = (uint32_t)p.lda * 2u;
+    const uint32_t lda2 = (uint32_t)p.lda * 2u, ldb2 = (uint32_t)p.ldb * 2u;
 
     // staging: wave w moves rows 4w .. 4w+3 of a stage of each operand, as two 2-row pieces; lane L lands in row 4w + 2q + (L >> 5),
     // physical chunk L & 31, and fetches the logical chunk (L & 31) ^ ((row & 3) << 2)
     const int hrow = lane >> 5;
-    const uint32_t hmask = hrow ? ~0u : 0u;
-    uint32_t aoffq[2], bch[2];
+    uint32_t aoffq[2], boffq[2];   // (gathered: boffq is the byte offset inside the row only)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int rr = 2 * q + hrow;   // == row & 3
         const uint32_t lc = (uint32_t)((lane & 31) ^ (rr << 2));
-        aoffq[q] = (uint32_t)(m_start + 4 * wave + rr) * lda2 + lc * 16u;
-        bch[q] = lc * 16u;
+        aoffq[q] = (uint32_t)(m_start + 4 * wave + rr) * lda2 + (uint32_t)nt * 512u + lc * 16u;
+        // (a ragged last column tile fetches in-bounds columns again; its surplus accumulator columns are not stored)
+        boffq[q] = GATHER ? lc * 16u : (uint32_t)(m_start + 4 * wave + rr) * ldb2 + (uint32_t)min(kt * 256 + (int)lc * 8, p.Kc - 8) * 2u;
     }
-    const char *pa = (const char *)p.A;   // + the stage being issued
-    const char *const Bb = (const char *)p.B;
-    const __attribute__((address_space(4))) int *pt =
-        (const __attribute__((address_space(4))) int *)(p.nbr + (size_t)tap * p.M + m_start + 4 * wave);   // + the stage whose offsets are loaded
+    const char *pa = (const char *)p.A, *pb = (const char *)p.B;   // + the stage being issued (pb: plain rows only)
+    const __attribute__((address_space(4))) int *pt = (const __attribute__((address_space(4))) int *)(
+        GATHER ? p.nbr + (size_t)tap * p.M + m_start + 4 * wave : nullptr);   // + the stage whose offsets are loaded
     int tn[2][4];   // [stage parity]: byte offsets of this wave's four B rows
     const uint32_t mine = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ring + wave * 2048;
 #define TR_DMA(base, voff, lds)                                                                      \
@@ -378,12 +392,15 @@ gemm_tn_ring_kernel(const TnRingP p) {
                  :: "s"((uint32_t)(lds)), "v"(voff), "s"(base) : "memory")
 #define TR_DMA_A(slot, q) TR_DMA(pa, aoffq[q], mine + (slot) * TR_STAGE + (q) * 1024)
 #define TR_DMA_B(slot, q, par)                                                                       \
-    {                                                                                                \
-        const uint32_t bo_ = ((uint32_t)(tn[par][2 * (q) + 1] - tn[par][2 * (q)]) & hmask) + (uint32_t)tn[par][2 * (q)] + bch[q]; \
-        TR_DMA(Bb, bo_, mine + (slot) * TR_STAGE + TR_TILE + (q) * 1024);                             \
+    if (GATHER) {                                                                                    \
+        const uint32_t bo_ = (uint32_t)(hrow ? tn[par][2 * (q) + 1] : tn[par][2 * (q)]) + boffq[q];  \
+        TR_DMA(pb, bo_, mine + (slot) * TR_STAGE + TR_TILE + (q) * 1024);                             \
+    } else {                                                                                         \
+        TR_DMA(pb, boffq[q], mine + (slot) * TR_STAGE + TR_TILE + (q) * 1024);                        \
     }
+#define TR_NEXT_STAGE { pa += 32 * lda2; if (!GATHER) pb += 32 * ldb2; }
 #define TR_TABLE(par)                                                                                \
-    {                                                                                                \
+    if (GATHER) {                                                                                    \
         tn[par][0] = pt[0]; tn[par][1] = pt[1]; tn[par][2] = pt[2]; tn[par][3] = pt[3];              \
         pt += 32;                                                                                    \
     }
@@ -441,10 +458,10 @@ gemm_tn_ring_kernel(const TnRingP p) {
     if (ISSUE) TR_DMA_A(is, 1);                                          \
     TR_SB; TR_M(USE, 1, 1); TR_SB;                                       \
     if (READ) TR_RA(USE ^ 1, 1, slot, step);                             \
-    if (ISSUE) TR_DMA_B(is, 0, par);                                     \
+    if (ISSUE) { TR_DMA_B(is, 0, par) }                                  \
     TR_SB; TR_M(USE, 2, 0); TR_SB;                                       \
     if (READ) TR_RA(USE ^ 1, 2, slot, step);                             \
-    if (ISSUE) { TR_DMA_B(is, 1, par); pa += 32 * lda2; }                \
+    if (ISSUE) { TR_DMA_B(is, 1, par) TR_NEXT_STAGE }                    \
     TR_SB; TR_M(USE, 2, 1); TR_SB;                                       \
     if (READ) TR_RA(USE ^ 1, 3, slot, step);                             \
     TR_SB; TR_M(USE, 3, 0); TR_SB;                                       \
@@ -479,11 +496,11 @@ gemm_tn_ring_kernel(const TnRingP p) {
     if (groups > 0) {
         // prologue: stages 0, 1, 2 (and the offsets of stage 3)
         TR_TABLE(0)
-        TR_DMA_A(0, 0); TR_DMA_A(0, 1); TR_DMA_B(0, 0, 0); TR_DMA_B(0, 1, 0); pa += 32 * lda2;
+        TR_DMA_A(0, 0); TR_DMA_A(0, 1); TR_DMA_B(0, 0, 0) TR_DMA_B(0, 1, 0) TR_NEXT_STAGE
         TR_TABLE(1)
-        TR_DMA_A(1, 0); TR_DMA_A(1, 1); TR_DMA_B(1, 0, 1); TR_DMA_B(1, 1, 1); pa += 32 * lda2;
+        TR_DMA_A(1, 0); TR_DMA_A(1, 1); TR_DMA_B(1, 0, 1) TR_DMA_B(1, 1, 1) TR_NEXT_STAGE
         TR_TABLE(0)
-        TR_DMA_A(2, 0); TR_DMA_A(2, 1); TR_DMA_B(2, 0, 0); TR_DMA_B(2, 1, 0); pa += 32 * lda2;
+        TR_DMA_A(2, 0); TR_DMA_A(2, 1); TR_DMA_B(2, 0, 0) TR_DMA_B(2, 1, 0) TR_NEXT_STAGE
         TR_TABLE(1)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -504,12 +521,13 @@ gemm_tn_ring_kernel(const TnRingP p) {
 #undef TR_M
 #undef TR_SB
 #undef TR_TABLE
+#undef TR_NEXT_STAGE
 #undef TR_DMA_B
 #undef TR_DMA_A
 #undef TR_DMA
-    // accumulator (i, j)[reg]: A column wr*128 + 32 i + (reg&3) + 8 (reg>>2) + 4 (lane>>5), B column wc*64 + 32 j + (lane&31)
-    const int ldc = p.T * 256;
-    float *out = p.part + (size_t)split * 256 * ldc + (size_t)tap * 256;
+    // accumulator (i, j)[reg]: A column 256 nt + wr*128 + 32 i + (reg&3) + 8 (reg>>2) + 4 (lane>>5), B column 256 kt + wc*64 + 32 j + (lane&31)
+    const int ldc = p.T * p.Kc;
+    float *out = p.part + ((size_t)split * p.ntile + nt) * 256 * ldc + (size_t)tap * p.Kc + kt * 256;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -518,7 +536,7 @@ gemm_tn_ring_kernel(const TnRingP p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int n = wr * 128 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                out[(size_t)n * ldc + col] = acc[i][j][e];
+                if (GATHER || kt * 256 + col < p.Kc) out[(size_t)n * ldc + col] = acc[i][j][e];
             }
         }
 }
@@ -957,6 +975,15 @@ constexpr size_t TN_PART_BYTES = 128ull << 20;  // partial-tile buffer of the we
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+inline int cu_count() {   // the ring kernels run one workgroup per CU: launches are sized to one round
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v > 0 ? v : 256;
+    }();
+    return cus;
+}
+
 // dst[N, T*Kc] += A^T . B; `part` holds TN_PART_BYTES
 int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, int ldb, int Kc, int T, const int *nbr,
             int M, float *dst, float *part, hipStream_t s) {
@@ -969,21 +996,20 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
 #ifndef LARA_TN_OLD
     if (nbr && N == 256 && Kc == 256 && (M & 127) == 0 && !(lda & 7) && !(ldb & 7) && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0) {
         // the convolution's weight gradient: one 256 x 256 workgroup per (tap, split), one round of workgroups over the device
-        static const int cus = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-            return v > 0 ? v : 256;
-        }();
-        static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_tn_ring_kernel,
+        const int cus = cu_count();
+        static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_tn_ring_kernel<true>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, TR_RING * TR_STAGE);
         if (attr != hipSuccess) return LARA2DGS_E_LAUNCH;
         const int g128 = M / 128;
         int splits = max(1, min(min(cus / T, g128), (int)(TN_PART_BYTES / out_bytes)));
         const int chunk = ((g128 + splits - 1) / splits) * 128;
         splits = (M + chunk - 1) / chunk;   // every split has rows
-        TnRingP q{};
-        q.A = A; q.B = B; q.part = part; q.nbr = nbr; q.M = M; q.lda = lda; q.ldb = ldb; q.T = T; q.chunk = chunk; q.splits = splits;
-        hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(T * splits), dim3(512), TR_RING * TR_STAGE, s, q);
+        TnRingGroup g{};
+        TnRingP &q = g.p[0];
+        q.A = A; q.B = B; q.part = part; q.nbr = nbr; q.M = M; q.lda = lda; q.ldb = ldb; q.T = T; q.ntile = q.ktile = 1; q.Kc = 256;
+        q.chunk = chunk; q.splits = splits;
+        g.count = 1; g.first_wg[0] = 0; g.first_wg[1] = T * splits;
+        hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, dim3(T * splits), dim3(512), TR_RING * TR_STAGE, s, g);
         hipLaunchKernelGGL(accum_partials4_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
         return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
     }
@@ -1046,6 +1072,49 @@ int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
         }
         return LARA2DGS_OK;
     }
+#ifndef LARA_TN_OLD
+    // every product in 256 x 256 tiles and 128-row groups: the ring kernel, one round of workgroups (one per CU), every workgroup the
+    // same number of token rows (the largest chunk that keeps the launch within the CU count)
+    bool ringable = true;
+    long units = 0;
+    for (int k = 0; k < count; k++) {
+        const TnJob &j = jobs[k];
+        ringable = ringable && !(j.N & 255) && !(j.M & 127) && j.M >= 128;   // (Kc % 8 == 0 above; a ragged last column tile is fine)
+        units += (long)(j.N / 256) * ((j.Kc + 255) / 256) * (j.M / 128);
+    }
+    if (ringable) {
+        static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_tn_ring_kernel<false>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, TR_RING * TR_STAGE);
+        if (attr != hipSuccess) return LARA2DGS_E_LAUNCH;
+        const int cus = cu_count();
+        TnRingGroup g{};
+        AccGroup a{};
+        g.count = a.count = count;
+        for (int cg = (int)max(1l, (units + cus - 1) / cus);; cg++) {   // cg: 128-row groups per workgroup
+            int wgs = 0, rwg = 0;
+            size_t off_f = 0;
+            for (int k = 0; k < count; k++) {
+                const TnJob &j = jobs[k];
+                const int tiles = (j.N / 256) * ((j.Kc + 255) / 256), n = j.N * j.Kc, splits = (j.M / 128 + cg - 1) / cg;
+                TnRingP &q = g.p[k];
+                q.A = j.A; q.B = j.B; q.part = part + off_f; q.nbr = nullptr; q.M = j.M; q.lda = j.lda; q.ldb = j.ldb; q.T = 1;
+                q.ntile = j.N / 256; q.ktile = (j.Kc + 255) / 256; q.Kc = j.Kc; q.chunk = cg * 128; q.splits = splits;
+                g.first_wg[k] = wgs;
+                wgs += tiles * splits;
+                a.dst[k] = j.dst; a.part[k] = part + off_f; a.n[k] = n; a.parts[k] = splits; a.first_wg[k] = rwg;
+                rwg += (n / 4 + 63) / 64;
+                off_f += (size_t)splits * n;
+            }
+            g.first_wg[count] = wgs;
+            a.first_wg[count] = rwg;
+            if (wgs <= cus && off_f * 4 <= TN_PART_BYTES) break;
+            if (cg > (1 << 20)) return LARA2DGS_E_INVALID;
+        }
+        hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, dim3(g.first_wg[count]), dim3(512), TR_RING * TR_STAGE, s, g);
+        hipLaunchKernelGGL(accum_partials4_group_kernel, dim3(a.first_wg[count]), dim3(256), 0, s, a);
+        return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
+    }
+#endif
     // about 1280 workgroups (five per CU: the kernel is latency-bound below four), splits in multiples of 8 (one per XCD), at
     // least 256 token rows per split
     const int want = 1280;
