@@ -588,6 +588,8 @@ gemm_ring_kernel(const GemmP p) {
 // builds of this loop (results invalid) place the rest: MFMAs alone 278 us (1.67 PF: the clock the part sustains), + fragment
 // reads 312, + pieces 362 (no barrier), + the barrier 408 -- the barrier costs nothing without the pieces (306): what it costs is
 // the waves' different luck at issuing them; frozen source addresses (everything from L1 / L2) change nothing (405).
+// Where inside a K step the pieces sit (behind MFMAs 2-5 or 2, 4, 6, 7) and s_setprio(1) over the K step that issues none
+// measured within noise of each other (394-400 us, two passes each).
 // Needs K % 128 == 0 (and Cin % 128 == 0 for the convolution); launch_gemm_ring falls back to gemm_ring_kernel otherwise.
 template <int AMODE, int EPI>
 __global__ void __launch_bounds__(512)
