@@ -590,6 +590,12 @@ gemm_ring_kernel(const GemmP p) {
 // the waves' different luck at issuing them; frozen source addresses (everything from L1 / L2) change nothing (405).
 // Where inside a K step the pieces sit (behind MFMAs 2-5 or 2, 4, 6, 7) and s_setprio(1) over the K step that issues none
 // measured within noise of each other (394-400 us, two passes each).
+// The epilogue (half a megabyte per tile: residual in, result out) runs with the CU's matrix pipe idle -- one workgroup per CU, and a
+// round's workgroups reach it together: 36 of the convolution's 392 us (measured by skipping it).  Built to hide it and measured on
+// the same box: 4-wave workgroups on 128 x 256 tiles with a three-stage ring (72 KB), two per CU, each running under the other's
+// epilogue and waits -- parity-green, 485 us against 400: the W panel then travels once per 128 rows, 6 pieces per wave and K tile
+// instead of 4, and the pieces are what this loop pays for.  The block's MLP products (K = 256 / 512, HBM-bound at 94-104 us) on this
+// kernel: 99-102 us, no gain over gemm_bf16_nt_kernel's four workgroups per CU.
 // Needs K % 128 == 0 (and Cin % 128 == 0 for the convolution); launch_gemm_ring falls back to gemm_ring_kernel otherwise.
 template <int AMODE, int EPI>
 __global__ void __launch_bounds__(512)
