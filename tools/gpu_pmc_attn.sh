@@ -21,7 +21,7 @@ import csv, glob, re, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(group_attn_fused2_kernel|group_attn_kernel|gemm_ring_kernel<\d, \d>|gemm_bf16_nt_kernel<\d, \d|ln_cast_kernel)", r["Kernel_Name"])
+        m = re.search(r"(group_attn_fused2_kernel|group_attn_kernel|gemm_ring2?_kernel<\d, \d>|gemm_tn_ring_kernel<\w+>|gemm_bf16_nt_kernel<\d, \d|ln_cast_kernel)", r["Kernel_Name"])
         if m: acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in acc.items():
     print(k, {n: round(sum(v) / len(v)) for n, v in sorted(c.items())})

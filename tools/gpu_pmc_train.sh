@@ -21,7 +21,7 @@ for d in sorted(glob.glob(sys.argv[1] + "*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            m = re.search(r"(gemm_bf16_tn_kernel<\w+>|gemm_bf16_tn_lds_kernel<\w+>|gemm_ring_kernel<\d, \d>|ln_bwd_kernel|accum_partials_kernel)", r["Kernel_Name"])
+            m = re.search(r"(gemm_bf16_tn_kernel<\w+>|gemm_bf16_tn_lds_kernel<\w+>|gemm_ring2?_kernel<\d, \d>|gemm_tn_ring_kernel<\w+>|ln_bwd_kernel|accum_partials_kernel)", r["Kernel_Name"])
             if m: acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, c in acc.items():
             print(k, {n: round(sum(v) / len(v)) for n, v in c.items()}, "launches", len(next(iter(c.values()))))
