@@ -984,6 +984,19 @@ inline int cu_count() {   // the ring kernels run one workgroup per CU: launches
     return cus;
 }
 
+struct TnJob {
+    const unsigned short *A; int lda, N;
+    const unsigned short *B; int ldb, Kc;
+    int M;
+    float *dst;
+};
+int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s);
+// a plain product gemm_tn_group runs on the 256 x 256 ring kernel (its own conditions, restated: gemm_tn hands such a product over)
+inline bool tn_ring_shape(int M, int N, int Kc, int lda, int ldb, const float *dst) {
+    return M >= 128 && !(M & 127) && !(N & 255) && !(Kc & 7) && !(lda & 7) && !(ldb & 7) && (size_t)(M + 1) * lda * 2 < (1ull << 32) &&
+           (size_t)(M + 1) * ldb * 2 < (1ull << 32) && M < (1 << 24) && ldb < (1 << 23) && (((uintptr_t)dst) & 15) == 0;
+}
+
 // dst[N, T*Kc] += A^T . B; `part` holds TN_PART_BYTES
 int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, int ldb, int Kc, int T, const int *nbr,
             int M, float *dst, float *part, hipStream_t s) {
@@ -994,6 +1007,10 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
     const size_t out_bytes = (size_t)N * T * Kc * 4;
     const int n = N * T * Kc;
 #ifndef LARA_TN_OLD
+    if (!nbr && T == 1 && tn_ring_shape(M, N, Kc, lda, ldb, dst)) {
+        const TnJob j{A, lda, N, B, ldb, Kc, M, dst};
+        return gemm_tn_group(&j, 1, part, s);
+    }
     if (nbr && N == 256 && Kc == 256 && (M & 127) == 0 && !(lda & 7) && !(ldb & 7) && (((uintptr_t)dst | (uintptr_t)part) & 15) == 0) {
         // the convolution's weight gradient: one 256 x 256 workgroup per (tap, split), one round of workgroups over the device
         const int cus = cu_count();
@@ -1048,12 +1065,6 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
 // dst_k[N_k, Kc_k] += A_k^T . B_k for several products that are ready at the same time, as one launch + one reduction launch
 // (plain products only: no gathered rows, T = 1).  Falls back to one launch per product where the staged kernel's alignment
 // conditions do not hold.
-struct TnJob {
-    const unsigned short *A; int lda, N;
-    const unsigned short *B; int ldb, Kc;
-    int M;
-    float *dst;
-};
 int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
     bool ok = count >= 1 && count <= TN_GROUP_MAX;
     int tiles_all = 0;
@@ -1079,7 +1090,7 @@ int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
     long units = 0;
     for (int k = 0; k < count; k++) {
         const TnJob &j = jobs[k];
-        ringable = ringable && !(j.N & 255) && !(j.M & 127) && j.M >= 128;   // (Kc % 8 == 0 above; a ragged last column tile is fine)
+        ringable = ringable && tn_ring_shape(j.M, j.N, j.Kc, j.lda, j.ldb, j.dst);   // (a ragged last column tile is fine)
         units += (long)(j.N / 256) * ((j.Kc + 255) / 256) * (j.M / 128);
     }
     if (ringable) {
