@@ -1406,19 +1406,31 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
         L2D_PROF("gbb_dw_conv", s);
         if ((rc = gemm_tn(gb, 256, 256, xn3, 256, 256, 27, nbr, M, dw->wconv, tnpart, s))) return rc;
     }
-    {
-        L2D_PROF("gbb_dx_conv", s);
-        GemmP p{};  // d pn = g + cnn^T(g): the same implicit GEMM with the taps mirrored and in/out swapped
-        p.A = gb; p.W = wt->wconv_t; p.C = g; p.resid = g; p.M = M; p.N = 256; p.K = 27 * 256;
-        p.R = R; p.Cin = 256; p.zero_off = (uint32_t)((size_t)M * 512);
-        if (launch_gemm_ring<1, 1>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
-    }
+    // d pn = g + cnn^T(g): the same implicit GEMM with the taps mirrored and in/out swapped; and behind it the backward of
+    // pn = norm3(x2) -- in the product's epilogue where the tile holds whole rows (EPI 9, mfma_gemm.h), as a pass of its own otherwise.
     // The bf16 copy of g that each LayerNorm backward leaves goes to its own buffer (gb3 behind norm3, gb2 behind norm2, gb --
     // the one the next block's convolution gathers from -- behind norm1), so that the five weight gradients of the block's linear
     // layers, whose operands are then all alive at the end of the block, run as ONE grouped product (gemm_tn_group).
     {
-        L2D_PROF("gbb_ln_bwd", s);
-        if ((rc = ln_bwd(g, false, x2, w->ln3_w, w->eps, nullptr, g, gb3, dw->ln3_w, dw->ln3_b, dw->b2, lnp4, M, s, &red))) return rc;
+        GemmP p{};
+        p.A = gb; p.W = wt->wconv_t; p.C = g; p.resid = g; p.M = M; p.N = 256; p.K = 27 * 256;
+        p.R = R; p.Cin = 256; p.zero_off = (uint32_t)((size_t)M * 512);
+        if (ring2_shape(p, 1)) {
+            L2D_PROF("gbb_dx_conv", s);
+            p.C2 = gb3; p.lnx = x2; p.stats = (const float2 *)(sv + S.stats); p.gamma = w->ln3_w; p.colsum = lnp4;
+            if (launch_gemm_ring<1, 9>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+            const int tiles = (M + RT - 1) / RT;
+            red.add(dw->ln3_w, lnp4, 256, tiles, 768);
+            red.add(dw->ln3_b, lnp4 + 256, 256, tiles, 768);
+            red.add(dw->b2, lnp4 + 512, 256, tiles, 768);
+        } else {
+            {
+                L2D_PROF("gbb_dx_conv", s);
+                if (launch_gemm_ring<1, 1>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+            }
+            L2D_PROF("gbb_ln_bwd", s);
+            if ((rc = ln_bwd(g, false, x2, w->ln3_w, w->eps, nullptr, g, gb3, dw->ln3_w, dw->ln3_b, dw->b2, lnp4, M, s, &red))) return rc;
+        }
     }
     L2D_CHECK_LAUNCH();
     // ---- x2 = x1 + mlp(norm2(x1)) ----

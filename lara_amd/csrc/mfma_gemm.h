@@ -84,7 +84,9 @@ struct GemmP {
     int Cout;            // EPI 5
     uint32_t zero_off;   // AMODE 1: byte offset from A of a zeroed row of Cin bf16 (the padding voxels)
     unsigned short *C2;  // EPI 6: bf16 [M, N] pre-activation out; EPI 7: the same, read
-    float *colsum;       // EPI 7 (gemm_bf16_nt_kernel, optional): [row tiles of 128][N] column sums of the stored bf16 values per row tile
+    float *colsum;       // EPI 7 (gemm_bf16_nt_kernel, optional): [row tiles of 128][N] column sums of the stored bf16 values per row tile;
+                         // EPI 9: [row tiles of 256][3][256] partial column sums (dgamma, dbeta, the bias gradient behind the LayerNorm)
+    const float *lnx;    // EPI 9: fp32 [M, 256], the input of the LayerNorm whose backward the epilogue runs (stats = its mean, rstd)
 };
 
 // 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_exp / v_rcp
@@ -418,6 +420,101 @@ __device__ __forceinline__ void ring_epilogue(const GemmP &p, f32x16 (&acc)[4][2
     }
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), the same value in each of them
+__device__ __forceinline__ float row16_total(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, false));   // row_mirror
+    return x;
+}
+
+// EPI 9 -- the convolution's input gradient with the LayerNorm backward behind it in the epilogue (network.py:94-100 backwards:
+// x_out = pn + cnn(pn), pn = norm3(x2)): dy = acc + resid is the gradient of pn; the tile holds whole rows (N = 256), so
+//   dx = rstd (a - mean(a) - xhat mean(a xhat)),  a = dy gamma,  xhat = (x2 - mean) rstd   (mean, rstd: the forward's stats)
+// is formed here -- fp32 to C (in place over resid), bf16 to C2 -- with the per-tile column sums of dy xhat, dy and dx (dgamma, dbeta,
+// the bias gradient of the layer in front) to p.colsum.  The stand-alone pass read and wrote the 134 MB gradient stream once more
+// (76 us per block).  Through LDS like ring_epilogue (32 x 64 per wave per trip); a row's 256 columns sit in the four waves of a
+// wave row: its two sums are DPP row totals (16 lanes = 64 columns) exchanged through 2 KB of LDS, 16 rows at a time.
+__device__ __forceinline__ void ring_epilogue_lnbwd(const GemmP &p, f32x16 (&acc)[4][2], unsigned char *ring, const int wave,
+                                                    const int lane, const int bm0, const int wr, const int wc) {
+    const int M = p.M, tid = wave * 64 + lane;
+    const int r = lane & 31, kh = lane >> 5;
+    float *ep = (float *)ring + wave * (32 * 68);
+    float2 *rowsum = (float2 *)((float *)ring + 8 * (32 * 68) + 512);   // [2 wave rows][32 rows][4 wave columns]
+    const int lg = lane >> 4, c4 = (lane & 15) * 4, col = wc * 64 + c4;
+    const float4 ga = *(const float4 *)(p.gamma + col);
+    float cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f}, co[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                ep[((e & 3) + 8 * (e >> 2) + 4 * kh) * 68 + j * 32 + r] = i == 0 ? acc[0][j][e] : i == 1 ? acc[1][j][e] : i == 2 ? acc[2][j][e] : acc[3][j][e];
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            __syncthreads();   // the bounce tile is written (half 0) / the row sums of the half before have been read
+            float4 dy[4], xh[4];
+            float rstd[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int lr = 16 * half + 4 * q + lg, row = bm0 + wr * 128 + i * 32 + lr;
+                const bool in = row < M;
+                const size_t o = (size_t)(in ? row : 0) * 256 + col;
+                const float4 v = *(const float4 *)(ep + lr * 68 + c4), rs = *(const float4 *)(p.resid + o), xx = *(const float4 *)(p.lnx + o);
+                const float2 st = p.stats[in ? row : 0];
+                const float m = in ? 1.f : 0.f;
+                dy[q] = make_float4(m * (v.x + rs.x), m * (v.y + rs.y), m * (v.z + rs.z), m * (v.w + rs.w));
+                xh[q] = make_float4((xx.x - st.x) * st.y, (xx.y - st.x) * st.y, (xx.z - st.x) * st.y, (xx.w - st.x) * st.y);
+                rstd[q] = st.y;
+                const float a0 = dy[q].x * ga.x, a1 = dy[q].y * ga.y, a2 = dy[q].z * ga.z, a3 = dy[q].w * ga.w;
+                const float sa = row16_total((a0 + a1) + (a2 + a3));
+                const float sh = row16_total((a0 * xh[q].x + a1 * xh[q].y) + (a2 * xh[q].z + a3 * xh[q].w));
+                if ((lane & 15) == 0) rowsum[(wr * 32 + lr) * 4 + wc] = make_float2(sa, sh);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int lr = 16 * half + 4 * q + lg, row = bm0 + wr * 128 + i * 32 + lr;
+                const float4 s01 = *(const float4 *)(rowsum + (wr * 32 + lr) * 4), s23 = *(const float4 *)(rowsum + (wr * 32 + lr) * 4 + 2);
+                const float sa = ((s01.x + s01.z) + (s23.x + s23.z)) * (1.0f / 256.0f), sh = ((s01.y + s01.w) + (s23.y + s23.w)) * (1.0f / 256.0f);
+                const float a0 = dy[q].x * ga.x, a1 = dy[q].y * ga.y, a2 = dy[q].z * ga.z, a3 = dy[q].w * ga.w;
+                const float4 dx = make_float4(rstd[q] * (a0 - sa - xh[q].x * sh), rstd[q] * (a1 - sa - xh[q].y * sh),
+                                              rstd[q] * (a2 - sa - xh[q].z * sh), rstd[q] * (a3 - sa - xh[q].w * sh));
+                if (row < M) {
+                    const size_t o = (size_t)row * 256 + col;
+                    *(float4 *)((float *)p.C + o) = dx;
+                    ushort4 hb;
+                    hb.x = f2bf(dx.x); hb.y = f2bf(dx.y); hb.z = f2bf(dx.z); hb.w = f2bf(dx.w);
+                    *(ushort4 *)(p.C2 + o) = hb;
+                    cg[0] += dy[q].x * xh[q].x; cg[1] += dy[q].y * xh[q].y; cg[2] += dy[q].z * xh[q].z; cg[3] += dy[q].w * xh[q].w;
+                    cb[0] += dy[q].x; cb[1] += dy[q].y; cb[2] += dy[q].z; cb[3] += dy[q].w;
+                    co[0] += dx.x; co[1] += dx.y; co[2] += dx.z; co[3] += dx.w;
+                }
+            }
+        }
+    }
+    // column sums: a lane holds four columns of the rows = lane >> 4 (mod 4) of its wave row; the four lane groups add up with two
+    // shuffles, the two wave rows through LDS
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cg[c] += __shfl_xor(cg[c], 16); cg[c] += __shfl_xor(cg[c], 32);
+        cb[c] += __shfl_xor(cb[c], 16); cb[c] += __shfl_xor(cb[c], 32);
+        co[c] += __shfl_xor(co[c], 16); co[c] += __shfl_xor(co[c], 32);
+    }
+    __syncthreads();
+    float *cs = (float *)ring;   // [2 wave rows][3][256]
+    if (lane < 16) {
+        *(float4 *)(cs + (wr * 3 + 0) * 256 + col) = make_float4(cg[0], cg[1], cg[2], cg[3]);
+        *(float4 *)(cs + (wr * 3 + 1) * 256 + col) = make_float4(cb[0], cb[1], cb[2], cb[3]);
+        *(float4 *)(cs + (wr * 3 + 2) * 256 + col) = make_float4(co[0], co[1], co[2], co[3]);
+    }
+    __syncthreads();
+    for (int k = tid; k < 768; k += 512) p.colsum[(size_t)(bm0 / RT) * 768 + k] = cs[k] + cs[768 + k];
+}
+
 template <int AMODE, int EPI>
 __global__ void __launch_bounds__(512)
 gemm_ring_kernel(const GemmP p) {
@@ -567,7 +664,7 @@ gemm_ring_kernel(const GemmP p) {
     }
     __syncthreads();
 
-    ring_epilogue<EPI>(p, acc, ring, wave, lane, bm0, bn0, wr, wc);
+    ring_epilogue<EPI == 9 ? 1 : EPI>(p, acc, ring, wave, lane, bm0, bn0, wr, wc);   // (EPI 9 exists on gemm_ring2_kernel only)
 }
 
 // ---- the ring kernel, finely interleaved --------------------------------------------------------------
@@ -773,7 +870,8 @@ gemm_ring2_kernel(const GemmP p) {
     __syncthreads();
 
     // ring_epilogue's accumulator order is acc[i][j] too
-    ring_epilogue<EPI>(p, acc, ring, wave, lane, bm0, bn0, wr, wc);
+    if (EPI == 9) ring_epilogue_lnbwd(p, acc, ring, wave, lane, bm0, wr, wc);
+    else ring_epilogue<EPI == 9 ? 1 : EPI>(p, acc, ring, wave, lane, bm0, bn0, wr, wc);
 }
 
 // host-side launch of the ring kernel (dynamic LDS above the 64 KB default needs the attribute once)
@@ -790,9 +888,11 @@ static inline hipError_t launch_gemm_ring(const GemmP &p, hipStream_t s) {
                            RING * RTILE, s, p);
         return hipSuccess;
     }
+    if (EPI == 9) return hipErrorInvalidValue;   // (the fused LayerNorm backward needs gemm_ring2_kernel's shapes: callers check ring2_shape)
     hipLaunchKernelGGL((gemm_ring_kernel<AMODE, EPI>), dim3((p.M + RT - 1) / RT, (p.N + RT - 1) / RT), dim3(512),
                        RING * RTILE, s, p);
     return hipSuccess;
 }
+static inline bool ring2_shape(const GemmP &p, const int amode) { return p.K % 128 == 0 && (!amode || p.Cin % 128 == 0); }
 
 }  // namespace
