@@ -1006,7 +1006,6 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
         return LARA2DGS_E_INVALID;
     const size_t out_bytes = (size_t)N * T * Kc * 4;
     const int n = N * T * Kc;
-#ifndef LARA_TN_OLD
     if (!nbr && T == 1 && tn_ring_shape(M, N, Kc, lda, ldb, dst)) {
         const TnJob j{A, lda, N, B, ldb, Kc, M, dst};
         return gemm_tn_group(&j, 1, part, s);
@@ -1030,7 +1029,6 @@ int gemm_tn(const unsigned short *A, int lda, int N, const unsigned short *B, in
         hipLaunchKernelGGL(accum_partials4_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, s, dst, part, n, splits, (size_t)n);
         return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
     }
-#endif
     const int tiles = ((N + 127) / 128) * ((Kc + 127) / 128) * T;
     // about 1024 workgroups per launch (4 per CU: one round), in multiples of 8 splits (one per XCD, see the
     // kernel), at least 256 token rows each; a split that starts beyond M writes zeros
@@ -1083,7 +1081,6 @@ int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
         }
         return LARA2DGS_OK;
     }
-#ifndef LARA_TN_OLD
     // every product in 256 x 256 tiles and 128-row groups: the ring kernel, one round of workgroups (one per CU), every workgroup the
     // same number of token rows (the largest chunk that keeps the launch within the CU count)
     bool ringable = true;
@@ -1125,7 +1122,6 @@ int gemm_tn_group(const TnJob *jobs, int count, float *part, hipStream_t s) {
         hipLaunchKernelGGL(accum_partials4_group_kernel, dim3(a.first_wg[count]), dim3(256), 0, s, a);
         return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
     }
-#endif
     // about 1280 workgroups (five per CU: the kernel is latency-bound below four), splits in multiples of 8 (one per XCD), at
     // least 256 token rows per split
     const int want = 1280;
