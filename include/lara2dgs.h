@@ -13,8 +13,10 @@
  *   - every pointer is a DEVICE pointer (HBM) unless stated otherwise; all float data is fp32,
  *     contiguous, 16-byte aligned (a torch allocation is);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the calls return
- *     without synchronising: there is NO host sync on the fast path (the reference blocks on a
- *     D2H copy of `num_rendered` once per view);
+ *     without synchronising (the reference blocks on a D2H copy of `num_rendered` once per view,
+ *     between its scan and its duplicate-with-keys; here the caller may have the same number
+ *     WRITTEN TO HOST MEMORY by the scan kernel -- `counts_out` -- and read it while the rest of the
+ *     forward is still running);
  *   - the caller owns every allocation: outputs, the `state` buffer that forward hands to
  *     backward (the reference's geomBuffer/binningBuffer/imgBuffer), and a transient `scratch`;
  *   - the library keeps no global state and no settings (bar the optional profiling log) and is re-entrant across
@@ -24,10 +26,17 @@
  *     device.  The caller passes `capacity`; if a view needs more, the kernels write the real D into
  *     header[0], raise the `overflow` word header[1] AND poison the outputs with NaN (loud in the data).
  *     Nothing else was harmed: the caller repeats the SAME call with buffers sized for the reported D.
- *     The Python operator does exactly that -- it sizes a call from the counts earlier calls of the same
- *     size reported (2 x their maximum), reads the header lazily through pinned memory and repeats a
- *     call that did not fit; the reference resizes its buffers after a blocking read of num_rendered and
- *     can never fail on D either (lara_amd/rasterizer.py "workspace policy").
+ *     The Python operator does exactly that BEFORE IT RETURNS -- it sizes a call from the counts recent
+ *     calls of the same size reported (2 x their maximum), waits for `counts_out` (written by the scan,
+ *     a fifth of the way into the forward) and repeats a call that did not fit, so that no consumer ever
+ *     sees the poisoned outputs; the reference resizes its buffers after a blocking read of num_rendered
+ *     and can never fail on D either (lara_amd/rasterizer.py "workspace policy").
+ *   - forward-only calls (`forward_only` = 1; the reference's inference callers evaluation.py:129 and
+ *     tools/meshExtractor.py:85 run under no_grad and never call the backward): the forward leaves out
+ *     everything it keeps for the backward -- candidate masks, segment checkpoints, per-pixel finals,
+ *     contributor counts, the work-item lists -- and `state` shrinks to the sorted lists + the surfel
+ *     records (sizes from the same queries with forward_only = 1).  Images, radii and the integer
+ *     surface (point_list, ranges) are the training-mode forward's, bit for bit.
  */
 #ifndef LARA2DGS_H
 #define LARA2DGS_H
@@ -39,7 +48,7 @@
 extern "C" {
 #endif
 
-#define LARA2DGS_ABI_VERSION 9
+#define LARA2DGS_ABI_VERSION 10
 
 #define LARA2DGS_OK 0
 #define LARA2DGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
@@ -63,11 +72,19 @@ typedef struct lara2dgs_view {
                              * can then never pass the 1/255 test, so images and gradients are unchanged while such
                              * surfels leave the binning, sort and composite (their radii read 0) */
     int32_t debug;
+    int32_t forward_only;   /* 1: no backward will follow (inference): see "forward-only calls" above */
     int64_t capacity;       /* max (tile, surfel) pairs the state/scratch buffers were sized for */
     const float *bg;         /* [3]  */
     const float *viewmatrix; /* [16] */
     const float *projmatrix; /* [16] */
     const float *campos;     /* [3]  */
+    uint32_t *counts_out;    /* optional (NULL = off).  uint32[4] in HOST memory the device can write (hipHostMalloc /
+                              * a pinned torch tensor): the scan kernel stores [0] = num_rendered D, [1] = overflow
+                              * (D > capacity), [2] = longest tile list, then -- after a system-scope release -- [3] = 1.
+                              * The caller clears [3] before the call and may spin on it: D is known a fifth of the way
+                              * into the forward, while the scatter / sort / composite kernels are still running.  This
+                              * replaces the reference's blocking D2H copy of num_rendered.  In a multi-view call view i
+                              * must pass views[0].counts_out + 4 * i (or every view NULL). */
 } lara2dgs_view;
 
 /* Byte offsets of the sections of the `state` buffer (for tests, debugging and tooling; the
@@ -113,10 +130,12 @@ const char *lara2dgs_error_string(int code);
 int lara2dgs_last_hip_error(void);
 
 /* Sizes of the two caller-owned buffers.  Replaces the resize-callback scheme of the reference's
- * `rasterize_gaussians` (geomBuffer / binningBuffer / imgBuffer). */
-int64_t lara2dgs_state_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity);
-int64_t lara2dgs_scratch_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity);
-int lara2dgs_get_state_layout(int32_t P, int32_t H, int32_t W, int64_t capacity,
+ * `rasterize_gaussians` (geomBuffer / binningBuffer / imgBuffer).  forward_only = the view's flag: the sections only a
+ * backward reads then have size 0 (their offsets equal the next section's) and the scratch buffer ends with the forward's
+ * own arrays. */
+int64_t lara2dgs_state_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity, int32_t forward_only);
+int64_t lara2dgs_scratch_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity, int32_t forward_only);
+int lara2dgs_get_state_layout(int32_t P, int32_t H, int32_t W, int64_t capacity, int32_t forward_only,
                               lara2dgs_state_layout *out);
 
 /* Replaces `_C.rasterize_gaussians(bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -133,7 +152,8 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
                      float *out_allmap, int32_t *out_radii, void *state, void *scratch,
                      void *stream);
 
-/* Replaces `_C.rasterize_gaussians_backward(...)`.  `state` is the buffer forward filled; the backward WRITES to it (it
+/* Replaces `_C.rasterize_gaussians_backward(...)`.  `state` is the buffer a forward with forward_only = 0 filled (a view
+ * with forward_only = 1 is LARA2DGS_E_INVALID here); the backward WRITES to it (it
  * re-orders the work-item list `bwd_items` in place and sets header[22]): one backward at a time per state buffer.
  * Gradient outputs (any may be NULL when the corresponding input was NULL):
  *   dL_dmeans3D [P,3], dL_dmeans2D [P,3], dL_dshs [P,M,3], dL_dcolors [P,3], dL_dopacities [P],

@@ -62,6 +62,8 @@ bool make_view(const lara2dgs_view *view, ViewDev &v) {
     v.scale_modifier = view->scale_modifier;
     v.cull_transparent = (view->prefiltered >> 1) & 1;
     v.cap = (unsigned)view->capacity;
+    v.fwd_only = view->forward_only != 0;
+    v.counts_out = view->counts_out;
     {
         static const unsigned dbg = getenv("LARA2DGS_DEBUG_FLAGS") ? (unsigned)strtoul(getenv("LARA2DGS_DEBUG_FLAGS"), nullptr, 0) : 0u;
         v.dbg = dbg;
@@ -75,7 +77,7 @@ bool make_view(const lara2dgs_view *view, ViewDev &v) {
 
 StateView carve_state(const ViewDev &v, void *state) {
     lara2dgs_state_layout L;
-    state_layout(v.P, v.H, v.W, v.cap, &L);
+    state_layout(v.P, v.H, v.W, v.cap, v.fwd_only, &L);
     char *b = (char *)state;
     StateView s;
     s.header = (uint32_t *)(b + L.header);
@@ -100,7 +102,7 @@ StateView carve_state(const ViewDev &v, void *state) {
 }
 
 ScratchView carve_scratch(const ViewDev &v, void *scratch, ScratchLayout &L) {
-    scratch_layout(v.P, v.H, v.W, v.cap, &L);
+    scratch_layout(v.P, v.H, v.W, v.cap, v.fwd_only, &L);
     char *b = (char *)scratch;
     ScratchView s;
     s.tile_count = (uint32_t *)(b + L.tile_count);
@@ -134,24 +136,24 @@ const char *lara2dgs_error_string(int code) {
 
 int lara2dgs_last_hip_error(void) { return g_last_hip_error; }
 
-int64_t lara2dgs_state_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity) {
+int64_t lara2dgs_state_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity, int32_t forward_only) {
     if (P < 0 || H <= 0 || W <= 0 || capacity < 0) return LARA2DGS_E_INVALID;
     lara2dgs_state_layout L;
-    state_layout(P, H, W, capacity, &L);
+    state_layout(P, H, W, capacity, forward_only != 0, &L);
     return L.total;
 }
 
-int64_t lara2dgs_scratch_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity) {
+int64_t lara2dgs_scratch_bytes(int32_t P, int32_t H, int32_t W, int64_t capacity, int32_t forward_only) {
     if (P < 0 || H <= 0 || W <= 0 || capacity < 0) return LARA2DGS_E_INVALID;
     ScratchLayout L;
-    scratch_layout(P, H, W, capacity, &L);
+    scratch_layout(P, H, W, capacity, forward_only != 0, &L);
     return L.total;
 }
 
-int lara2dgs_get_state_layout(int32_t P, int32_t H, int32_t W, int64_t capacity,
+int lara2dgs_get_state_layout(int32_t P, int32_t H, int32_t W, int64_t capacity, int32_t forward_only,
                               lara2dgs_state_layout *out) {
     if (!out || P < 0 || H <= 0 || W <= 0 || capacity < 0) return LARA2DGS_E_INVALID;
-    state_layout(P, H, W, capacity, out);
+    state_layout(P, H, W, capacity, forward_only != 0, out);
     return LARA2DGS_OK;
 }
 
@@ -195,6 +197,7 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
     ViewDev v;
     if (!make_view(view, v)) return LARA2DGS_E_INVALID;
     if (!dL_dcolor || !dL_dallmap || !state || !scratch) return LARA2DGS_E_INVALID;
+    if (v.fwd_only) return LARA2DGS_E_INVALID;      // a forward-only call kept nothing for a backward
     if (v.P == 0) return LARA2DGS_OK;
     if (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities) return LARA2DGS_E_INVALID;
     if ((shs == nullptr) == (colors_precomp == nullptr)) return LARA2DGS_E_INVALID;
@@ -269,7 +272,8 @@ bool views_agree(int n, const lara2dgs_view *views) {
         const lara2dgs_view &a = views[0], &b = views[i];
         if (a.P != b.P || a.sh_degree != b.sh_degree || a.sh_coeffs != b.sh_coeffs || a.image_height != b.image_height ||
             a.image_width != b.image_width || a.capacity != b.capacity || a.prefiltered != b.prefiltered ||
-            a.scale_modifier != b.scale_modifier || a.debug != b.debug) return false;   // (the batched kernels run all cameras with views[0]'s scalars)
+            a.scale_modifier != b.scale_modifier || a.debug != b.debug || a.forward_only != b.forward_only) return false;   // (the batched kernels run all cameras with views[0]'s scalars)
+        if (b.counts_out != (a.counts_out ? a.counts_out + 4 * i : nullptr)) return false;   // (... and view 0's counts pointer + 4 z)
     }
     return true;
 }
@@ -304,8 +308,8 @@ inline void zero_strided(void *base, int64_t stride, int64_t bytes, int n_views,
 
 bool strides_ok(const lara2dgs_view &v0, int64_t state_stride, int64_t scratch_stride) {
     return state_stride % 256 == 0 && scratch_stride % 256 == 0 &&
-           state_stride >= lara2dgs_state_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity) &&
-           scratch_stride >= lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity);
+           state_stride >= lara2dgs_state_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity, v0.forward_only) &&
+           scratch_stride >= lara2dgs_scratch_bytes(v0.P, v0.image_height, v0.image_width, v0.capacity, v0.forward_only);
 }
 }  // namespace
 
@@ -383,6 +387,7 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
     if (n_views <= 0 || !views || !state || !scratch || !grad_out) return LARA2DGS_E_INVALID;
     if (!views_agree(n_views, views)) return LARA2DGS_E_INVALID;
     const lara2dgs_view &v0 = views[0];
+    if (v0.forward_only) return LARA2DGS_E_INVALID;      // a forward-only call kept nothing for a backward
     if (!strides_ok(v0, state_stride, scratch_stride)) return LARA2DGS_E_INVALID;
     if (!dL_dcolor || !dL_dallmap) return LARA2DGS_E_INVALID;
     const bool has_sh = shs != nullptr, has_col = colors_precomp != nullptr, has_sr = scales && rotations,

@@ -163,6 +163,15 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         header[1] = total > v.cap ? 1u : 0u;
         header[2] = m;
         s_max = m;
+        if (v.counts_out) {
+            // the caller's copy of the pair count, in HOST memory: the reference reads this number with a blocking copy between
+            // its scan and its duplicate-with-keys; here the caller spins on word 3 while the rest of the forward runs
+            uint32_t *c = v.counts_out + 4 * blockIdx.z;
+            __hip_atomic_store(&c[0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&c[1], total > v.cap ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&c[2], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&c[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     // Launch order of the composite kernels: longest list first (LPT), so that the heavy centre
     // tiles spread over all CUs instead of piling onto the few CUs their ids map to.  A 64-bucket
@@ -195,7 +204,9 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
     // Backward work list.  A tile's list is cut into L2D_SEG-entry segments; nb = floor((len-1)/SEG)
     // of them are full and get an entry in bwd_items (and a checkpoint row, seg_base[tile] + s, at
     // their upper boundary); the last, partial one is launched per tile in bwd_order (longest first).
+    // (A forward-only call has no such sections: it goes straight to the sort's work list.)
     __syncthreads();
+    if (!v.fwd_only) {
     if (tid == 0) carry_s = 0;
     if (tid < 64) bcnt[tid] = 0;
     __syncthreads();
@@ -247,6 +258,7 @@ tile_scan_kernel(ViewDev v, const uint32_t *__restrict__ tile_count, uint32_t *_
         const uint32_t pl = len - seg_cnt[i] * L2D_SEG;
         bwd_order[atomicAdd(&bcnt[63u - (uint32_t)(((uint64_t)min(pl, (uint32_t)L2D_SEG) * 64u) / (L2D_SEG + 1u))], 1u)] = (uint32_t)i;
     }
+    }   // !fwd_only
     // The sort's work list: a list longer than 2048 entries is shared by several workgroups (tile_sort_kernel), one
     // extra work item per additional part; at most `tiles` items (a tile that finds the list full gets fewer parts).
     __syncthreads();
@@ -301,9 +313,11 @@ scatter_kernel(ViewDev v, const uint4 *__restrict__ rect, const uint32_t *__rest
         const uint4 r = rect[idx];
         rx0 = r.x & 0xffff; ry0 = r.x >> 16; rx1 = r.y & 0xffff; ry1 = r.y >> 16;
         word = ((uint64_t)r.z << 32) | (uint32_t)idx;
-        const uint32_t pb = block_base[blockIdx.x] + r.w;
-        pair_base[idx] = pb;
-        if (idx == v.P - 1) pair_base[v.P] = pb + (uint32_t)(rx1 - rx0) * (uint32_t)(ry1 - ry0);
+        if (!v.fwd_only) {      // surfel-major pair numbering: where the backward writes a pair's gradient row
+            const uint32_t pb = block_base[blockIdx.x] + r.w;
+            pair_base[idx] = pb;
+            if (idx == v.P - 1) pair_base[v.P] = pb + (uint32_t)(rx1 - rx0) * (uint32_t)(ry1 - ry0);
+        }
     }
     if (use_lds) {
         for (int t = threadIdx.x; t < v.tiles; t += blockDim.x) hist[t] = 0;
@@ -416,6 +430,7 @@ struct PairMap {
     int tx, ty;
     uint32_t first;  // position of the tile's first entry in the sorted list
     __device__ __forceinline__ void put(const uint32_t id, const uint32_t i) const {
+        if (!pair_pos) return;      // forward-only call: nobody will gather gradient rows
         const uint4 r = rect[id];
         const int rx0 = r.x & 0xffff, ry0 = r.x >> 16, rx1 = r.y & 0xffff;
         pair_pos[first + i] = pair_base[id] + (uint32_t)((ty - ry0) * (rx1 - rx0) + (tx - rx0));
@@ -596,7 +611,7 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
     const int S = (int)(sort_parts[tile] & 0xffffu);   // (bits 16+: the parts' arrival tickets, see the fallback below)
     uint64_t *seg = keys + rg.x;
     uint32_t *out = point_list + rg.x;
-    const PairMap pm{rect, pair_base, pair_pos, tile % v.gx, tile / v.gx, rg.x};
+    const PairMap pm{rect, pair_base, v.fwd_only ? nullptr : pair_pos, tile % v.gx, tile / v.gx, rg.x};
     bool whole_list_in_place = S == 1 && n > L2D_SORT_LDS_KEYS;   // beyond 8192 entries, or no work items left for this tile
     if (S == 1 && !whole_list_in_place) {
         sort_dispatch(seg, n, out, 0u, lds, bkt, sh, pm);

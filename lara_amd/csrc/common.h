@@ -26,7 +26,9 @@ struct ViewDev {
     unsigned cap;  // capacity in (tile, surfel) pairs
     unsigned dbg;  // LARA2DGS_DEBUG_FLAGS (perf experiments only; 0 in production)
     int cull_transparent;  // opt-in: surfels with opacity < 1/255 are culled in preprocess (lara2dgs_view.prefiltered bit 1)
+    int fwd_only;          // lara2dgs_view.forward_only: nothing is kept for a backward
     const float *bg, *viewmatrix, *projmatrix, *campos;
+    uint32_t *counts_out;  // host-visible uint32[4] of view 0 (view z: + 4 z), or null: lara2dgs_view.counts_out
 };
 
 // A multi-view call carves the views' `state` / `scratch` buffers out of one allocation each at a constant stride, and all
@@ -90,9 +92,12 @@ static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 // between cap / 2 and cap are the normal case, and 20 bytes per pair of capacity buy them the segmented backward).
 __host__ __device__ static inline int64_t l2d_ckpt_slots(int64_t cap) { return cap / L2D_SEG + 1; }
 
-static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state_layout *L) {
+// fwd_only: the sections only a backward reads have size 0 (offset = the next section's); the kernels of such a call never
+// touch them.
+static inline void state_layout(int P, int H, int W, int64_t cap, int fwd_only, lara2dgs_state_layout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const int64_t HW = (int64_t)H * W;
+    const int64_t k = fwd_only ? 0 : 1;     // multiplies the size of every backward-only section
     int64_t o = 0;
     L->header = o;      o = align_up(o + 256, 256);
     L->geom = o;        o = align_up(o + (int64_t)P * GEOM_F * 4, 256);
@@ -100,24 +105,24 @@ static inline void state_layout(int P, int H, int W, int64_t cap, lara2dgs_state
     L->point_list = o;  o = align_up(o + cap * 4, 256);
     L->ranges = o;      o = align_up(o + tiles * 8, 256);
     L->tile_order = o;  o = align_up(o + tiles * 4, 256);
-    L->pair_base = o;   o = align_up(o + ((int64_t)P + 1) * 4, 256);
-    L->pair_pos = o;    o = align_up(o + cap * 4, 256);
-    L->final_T = o;     o = align_up(o + L2D_CKPT_F * HW * 4, 256);
-    L->n_contrib = o;   o = align_up(o + 2 * HW * 4, 256);
+    L->pair_base = o;   o = align_up(o + k * ((int64_t)P + 1) * 4, 256);
+    L->pair_pos = o;    o = align_up(o + k * cap * 4, 256);
+    L->final_T = o;     o = align_up(o + k * L2D_CKPT_F * HW * 4, 256);
+    L->n_contrib = o;   o = align_up(o + k * 2 * HW * 4, 256);
     const int64_t nseg = cap / L2D_SEG + 1;
-    L->seg_base = o;    o = align_up(o + (tiles + 1) * 4, 256);
-    L->seg_cnt = o;     o = align_up(o + tiles * 4, 256);
-    L->bwd_order = o;   o = align_up(o + tiles * 4, 256);
-    L->bwd_items = o;   o = align_up(o + (nseg + tiles) * 8, 256);   // (+ tiles: the ordered list also holds every tile's last segment)
-    L->ckpt = o;        o = align_up(o + l2d_ckpt_slots(cap) * L2D_CKPT_F * 256 * 4, 256);
-    L->pair_mask = o;   o = align_up(o + cap * 8, 256);
-    L->tile_maxc = o;   o = align_up(o + tiles * 4, 256);
-    L->seg_cost = o;    o = align_up(o + (nseg + tiles) * 4, 256);
+    L->seg_base = o;    o = align_up(o + k * (tiles + 1) * 4, 256);
+    L->seg_cnt = o;     o = align_up(o + k * tiles * 4, 256);
+    L->bwd_order = o;   o = align_up(o + k * tiles * 4, 256);
+    L->bwd_items = o;   o = align_up(o + k * (nseg + tiles) * 8, 256);   // (+ tiles: the ordered list also holds every tile's last segment)
+    L->ckpt = o;        o = align_up(o + k * l2d_ckpt_slots(cap) * L2D_CKPT_F * 256 * 4, 256);
+    L->pair_mask = o;   o = align_up(o + k * cap * 8, 256);
+    L->tile_maxc = o;   o = align_up(o + k * tiles * 4, 256);
+    L->seg_cost = o;    o = align_up(o + k * (nseg + tiles) * 4, 256);
     L->total = o;
 }
 
 struct ScratchLayout { int64_t tile_count, tile_fill, sub_start, sort_parts, sort_items, rect, keys, block_tot, pair_grad, pair_valid, total; };
-static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayout *L) {
+static inline void scratch_layout(int P, int H, int W, int64_t cap, int fwd_only, ScratchLayout *L) {
     const int64_t tiles = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     int64_t o = 0;
     L->tile_count = o;  o = align_up(o + tiles * 4 * L2D_SLICES, 256);
@@ -133,7 +138,7 @@ static inline void scratch_layout(int P, int H, int W, int64_t cap, ScratchLayou
     L->pair_grad = fwd0;  // backward reuses the forward-only region
     L->pair_valid = align_up(fwd0 + cap * GRAD_F * 4, 256);
     const int64_t bwd_end = align_up(L->pair_valid + cap + 256, 256);
-    L->total = fwd_end > bwd_end ? fwd_end : bwd_end;
+    L->total = (fwd_only || fwd_end > bwd_end) ? fwd_end : bwd_end;
 }
 
 // ---- launchers (one per .hip translation unit) -------------------------------------------------

@@ -266,6 +266,10 @@ struct FwdPixel {
 // One workgroup per tile walks the tile's whole list.  (Round 3 built a depth-segment split of the long lists -- transmittance
 // prepass, per-segment walks from the true prefix, a combine pass: exact, and 406 us against 254 at LaRa's statistics; DESIGN.md
 // section 3.2.  It shipped as an opt-in until round 5 and is gone: the tails are filled by the other views of a multi-view launch.)
+// KEEP = the call keeps what a backward needs (candidate masks, segment checkpoints, per-pixel finals, contributor counts,
+// per-segment costs, the tile's deepest contributor); a forward-only call (lara2dgs_view.forward_only) writes the images and
+// nothing else -- at LaRa's init statistics 62.5 MB written per view become 10.5 (profiles/traffic_r05.json).
+template <bool KEEP>
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ geom,
@@ -309,8 +313,10 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             const float qnan = __uint_as_float(0x7fc00000u);
             for (int ch = 0; ch < 3; ch++) out_color[ch * HW + pix] = qnan;
             for (int ch = 0; ch < 7; ch++) out_allmap[ch * HW + pix] = qnan;
-            for (int ch = 0; ch < L2D_CKPT_F; ch++) final_T[pix + ch * HW] = qnan;
-            n_contrib[pix] = 0; n_contrib[pix + HW] = 0;
+            if (KEEP) {
+                for (int ch = 0; ch < L2D_CKPT_F; ch++) final_T[pix + ch * HW] = qnan;
+                n_contrib[pix] = 0; n_contrib[pix + HW] = 0;
+            }
         }
         return;
     }
@@ -331,9 +337,11 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     // cost: recorded per (tile, segment) -- full segments at seg_base[tile] + s, everything from the last (partial) segment on in
     // the tile's own slot -- and used by bwd_order_kernel to launch the backward's items dearest first.
     const int tid = threadIdx.x;
-    const uint32_t cost_nb = seg_cnt[tile];
-    uint32_t *const cost_full = seg_cost + seg_base[tile], *const cost_last = seg_cost + (v.cap / L2D_SEG + 1u) + tile;
-    for (uint32_t q = tid; q <= cost_nb; q += 256) *(q < cost_nb ? cost_full + q : cost_last) = 0u;
+    const uint32_t cost_nb = KEEP ? seg_cnt[tile] : 0u;
+    uint32_t *const cost_full = KEEP ? seg_cost + seg_base[tile] : nullptr,
+             *const cost_last = KEEP ? seg_cost + (v.cap / L2D_SEG + 1u) + tile : nullptr;
+    if (KEEP)
+        for (uint32_t q = tid; q <= cost_nb; q += 256) *(q < cost_nb ? cost_full + q : cost_last) = 0u;
     int cost_round = -1;
     constexpr int SPT = CHUNK / 256;  // list entries staged per thread and round
     uint32_t id1[SPT], id2[SPT];
@@ -348,13 +356,13 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     for (int q = 0; q < SPT; q++) cb1[q] = lo + q * 256 + tid < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = lo; base < hi; base += CHUNK) {
         if (__syncthreads_count(px.done) == 256) break;
-        if (tid == 0) {     // (between this barrier and the staging barrier no wave is in its walk)
+        if (KEEP && tid == 0) {     // (between this barrier and the staging barrier no wave is in its walk)
             if (cost_round >= 0) { if ((uint32_t)cost_round < cost_nb) cost_full[cost_round] = s_cost; else *cost_last += s_cost; }
             s_cost = 0u;
         }
         cost_round = (base - lo) / CHUNK;
         dbg_rounds++;
-        if (base && base % L2D_SEG == 0 && !px.done) {
+        if (KEEP && base && base % L2D_SEG == 0 && !px.done) {
             // crossing a segment boundary: park the running sums over entries [0, base) so that the
             // backward can start a walk here (pixels that are done never read theirs)
             float *ck = ckpt + ((size_t)seg_base[tile] + (size_t)(base / L2D_SEG - 1)) * (L2D_CKPT_F * 256) + tid;
@@ -371,7 +379,7 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             id2[q] = base + 2 * CHUNK + o < hi ? point_list[range.x + base + 2 * CHUNK + o] : 0u;
             cb1[q] = base + CHUNK + o < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
             stage_entry<CHUNK>(geom, id0, cb0, base + o < hi, X0, Y0, rec, nullptr, o,
-                               base + o < hi ? pair_mask + range.x + base + o : nullptr);
+                               KEEP && base + o < hi ? pair_mask + range.x + base + o : nullptr);
         }
         __syncthreads();
         if (__ballot(!px.done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
@@ -439,10 +447,10 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             trip(rB0, rB1, jB0, jB1, hB0, hB1, rA0, rA1, jA0, jA1, hA0, hA1);
             ntrips++;
         }
-        if (lane == 0 && ntrips) atomicAdd(&s_cost, ntrips);
+        if (KEEP && lane == 0 && ntrips) atomicAdd(&s_cost, ntrips);
     }
     const float T = px.T;
-    {   // the backward's work items of this tile end at the deepest contributor of any of its pixels: one word per tile
+    if (KEEP) {   // the backward's work items of this tile end at the deepest contributor of any of its pixels: one word per tile
         if (threadIdx.x == 0) s_tmax = 0u;
         __syncthreads();
         uint32_t m = px.last_contributor;
@@ -456,14 +464,16 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         }
     }
     if (inside) {
-        final_T[pix] = T;
-        final_T[pix + HW] = px.M1;
-        final_T[pix + 2 * HW] = px.M2;
-        final_T[pix + 3 * HW] = px.C0; final_T[pix + 4 * HW] = px.C1; final_T[pix + 5 * HW] = px.C2;
-        final_T[pix + 6 * HW] = px.Dd;
-        final_T[pix + 7 * HW] = px.N0; final_T[pix + 8 * HW] = px.N1; final_T[pix + 9 * HW] = px.N2;
-        n_contrib[pix] = px.last_contributor;
-        n_contrib[pix + HW] = px.median_contributor;
+        if (KEEP) {
+            final_T[pix] = T;
+            final_T[pix + HW] = px.M1;
+            final_T[pix + 2 * HW] = px.M2;
+            final_T[pix + 3 * HW] = px.C0; final_T[pix + 4 * HW] = px.C1; final_T[pix + 5 * HW] = px.C2;
+            final_T[pix + 6 * HW] = px.Dd;
+            final_T[pix + 7 * HW] = px.N0; final_T[pix + 8 * HW] = px.N1; final_T[pix + 9 * HW] = px.N2;
+            n_contrib[pix] = px.last_contributor;
+            n_contrib[pix + HW] = px.median_contributor;
+        }
         out_color[0 * HW + pix] = px.C0 + T * v.bg[0];
         out_color[1 * HW + pix] = px.C1 + T * v.bg[1];
         out_color[2 * HW + pix] = px.C2 + T * v.bg[2];
@@ -1129,8 +1139,9 @@ int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *
     if (vbp) vb = *vbp;
     const unsigned nz = vbp ? (unsigned)vb.n : 1u;    // blockIdx.z = view (st / out_* are view 0's)
     {
-        L2D_PROF("composite_fwd", s);
-        hipLaunchKernelGGL(composite_fwd_kernel, dim3(v.tiles, 1, nz), dim3(256), 0, s, v, st.header, st.ranges, st.point_list,
+        L2D_PROF(v.fwd_only ? "composite_fwd_only" : "composite_fwd", s);
+        auto kern = v.fwd_only ? composite_fwd_kernel<false> : composite_fwd_kernel<true>;
+        hipLaunchKernelGGL(kern, dim3(v.tiles, 1, nz), dim3(256), 0, s, v, st.header, st.ranges, st.point_list,
                            (const float4 *)st.geom, st.tile_order, (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base,
                            st.seg_cnt, st.ckpt, st.pair_mask, st.tile_maxc, st.seg_cost, out_color, out_allmap, vb);
     }

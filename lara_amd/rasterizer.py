@@ -20,8 +20,11 @@ non-GPU tensors the operator raises.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
+import threading
+import time
 import warnings
 from typing import NamedTuple, Optional
 
@@ -31,7 +34,7 @@ from torch import nn
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (LARA2DGS_LIB: another build of the same library -- kernel A/B experiments, tools/build_variant.sh; never a CPU path)
 LIB_PATH = os.environ.get("LARA2DGS_LIB") or os.path.join(_HERE, "liblara2dgs.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class _View(ctypes.Structure):
@@ -39,10 +42,11 @@ class _View(ctypes.Structure):
         ("P", ctypes.c_int32), ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
         ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
         ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
-        ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+        ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32), ("forward_only", ctypes.c_int32),
         ("capacity", ctypes.c_int64),
         ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
         ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p),
+        ("counts_out", ctypes.c_void_p),
     ]
 
 
@@ -77,11 +81,11 @@ def load_library():
     lib.lara2dgs_error_string.argtypes = [ctypes.c_int]
     lib.lara2dgs_last_hip_error.restype = ctypes.c_int
     lib.lara2dgs_state_bytes.restype = i64
-    lib.lara2dgs_state_bytes.argtypes = [i32, i32, i32, i64]
+    lib.lara2dgs_state_bytes.argtypes = [i32, i32, i32, i64, i32]
     lib.lara2dgs_scratch_bytes.restype = i64
-    lib.lara2dgs_scratch_bytes.argtypes = [i32, i32, i32, i64]
+    lib.lara2dgs_scratch_bytes.argtypes = [i32, i32, i32, i64, i32]
     lib.lara2dgs_get_state_layout.restype = ctypes.c_int
-    lib.lara2dgs_get_state_layout.argtypes = [i32, i32, i32, i64, ctypes.POINTER(StateLayout)]
+    lib.lara2dgs_get_state_layout.argtypes = [i32, i32, i32, i64, i32, ctypes.POINTER(StateLayout)]
     lib.lara2dgs_forward.restype = ctypes.c_int
     lib.lara2dgs_forward.argtypes = [ctypes.POINTER(_View)] + [vp] * 13
     lib.lara2dgs_backward.restype = ctypes.c_int
@@ -151,25 +155,27 @@ def _sizing_P(P: int) -> int:
     return (P + 32767) // 65536 * 65536 + 32768
 
 
-# The reference resizes geomBuffer / binningBuffer / imgBuffer after READING num_rendered on the host, once per view
-# (SURVEY.md section 8b): a call at renderer_2dgs.py:209-218 can therefore never fail on the number of (tile, surfel) pairs D,
-# and it pays a device->host synchronisation per view for it.  Here D stays on the device; the buffers are sized BEFORE the
-# call from what earlier calls of the same size class produced, and a call that does not fit is REPEATED at the size it
-# reported -- it is never an error (round 5; rounds 1-4 sized for 16 P and raised beyond it):
-#   * size class ("bucket") = (device, quantised surfel count, H, W); `_hwm` keeps the largest D any view of the class has
-#     reported (headers arrive through pinned memory, read when their event has completed: `check_pending`);
-#   * capacity of the next call = max(LARA2DGS_DUP_FACTOR * surfels, 2 * high-water mark), rounded up to the grid
+# The reference resizes geomBuffer / binningBuffer / imgBuffer after READING num_rendered on the host, once per view, between
+# its scan and its duplicate-with-keys: a call at renderer_2dgs.py:209-218 can therefore never fail on
+# the number of (tile, surfel) pairs D and never returns garbage -- and the device idles behind that read, every view.  Here:
+#   * the buffers are sized BEFORE the call from what recent calls of the same size class produced, and the WHOLE forward is
+#     enqueued at once; the scan kernel stores D and the overflow word to pinned host memory (`lara2dgs_view.counts_out`) a fifth
+#     of the way into the forward, and the operator waits for THAT word before it returns -- the device is still busy with the
+#     scatter / sort / composite kernels meanwhile, so the queue does not drain, but the host has the reference's guarantee: a
+#     call that did not fit is REPEATED at the size it reported (same stream, same output tensors) before anybody can see its
+#     outputs.  No consumer ever reads a poisoned image (rounds 1-4 raised on overflow; round 5 repaired lazily and leaked NaN
+#     to whatever ran in between: VERDICT r5 missing #4).  What this costs: the host cannot run more than one forward ahead of the
+#     device (measured: DESIGN.md section 3.1);
+#   * size class ("bucket") = (device, quantised surfel count, H, W); `_hist` keeps the pair counts of the class's last
+#     `_HISTORY` calls -- a WINDOW, not a high-water mark: one transient spike (a training run whose surfels grow, then an
+#     evaluation in the same process) does not pin 16 Mi-pair buffers for the life of the process (round 5 did);
+#   * capacity of the next call = max(LARA2DGS_DUP_FACTOR * surfels, 2 * the window's maximum), rounded up to the grid
 #     {2^k, 1.5 * 2^k} so that buffer sizes recur (the caching allocator then recycles the blocks);
-#   * the FIRST call of a class -- nothing measured yet -- and the 16 calls after a repeated one read D synchronously (what the
-#     reference does on every call): an overflow there is repaired before the call returns;
-#   * otherwise the check is lazy: an overflowing call (its D more than doubled against everything the class has seen) left
-#     NaN-poisoned outputs; at the next operator call / at its backward / in `check_pending` the SAME forward is enqueued again
-#     at the reported size, on its own stream, into the same output tensors, and a warning says which consumers may have read
-#     the poisoned values in between.  `debug=True` in the settings (the reference's own switch for synchronous error
-#     checking) makes every call synchronous.
-_hwm = {}      # bucket -> largest D seen
-_guard = {}    # bucket -> coming calls that read D synchronously
-_GUARD_CALLS = 16
+#   * a call under `torch.no_grad()` / whose inputs need no gradient is a FORWARD-ONLY call (`lara2dgs_view.forward_only`): the
+#     kernels keep nothing for a backward, the state buffer shrinks to the sorted lists + surfel records and is released as soon
+#     as the call is enqueued (the reference's inference callers: evaluation.py:129, tools/meshExtractor.py:85).
+_HISTORY = 256
+_hist = {}     # bucket -> deque of the largest D (over the views) of each of its last _HISTORY calls
 _reruns = 0    # forwards repeated at a larger capacity since the process started (tests, bench)
 
 
@@ -186,30 +192,116 @@ def _cap_grid(n: int) -> int:
     return min(k, 0xFFFFFFFF)
 
 
+def note_pair_count(bucket, D: int):
+    """Record the pair count of one call of a size class (the operator does; tools replay a history with it)."""
+    h = _hist.get(bucket)
+    if h is None:
+        h = _hist[bucket] = collections.deque(maxlen=_HISTORY)
+    h.append(int(D))
+
+
+def _recent_max(bucket) -> int:
+    h = _hist.get(bucket)
+    return max(h) if h else 0
+
+
+def _next_capacity(bucket) -> int:
+    return _cap_grid(max(bucket[1] * _dup_factor(), 2 * _recent_max(bucket)))
+
+
 def binning_capacity(P: int, H: int = 0, W: int = 0, device: Optional[torch.device] = None) -> int:
     """(tile, surfel) pairs the buffers of the next call of this size class are sized for (see the policy above).  With
     only `P`: the starting capacity of a class nothing was measured for."""
-    want = _sizing_P(P) * _dup_factor()
-    if device is not None:
-        want = max(want, 2 * _hwm.get(_bucket(device, P, H, W), 0))
-    return _cap_grid(want)
+    if device is None:
+        return _cap_grid(_sizing_P(P) * _dup_factor())
+    return _next_capacity(_bucket(device, P, H, W))
 
 
 def capacity_report() -> dict:
-    """{(device, sized surfels, H, W): {"D_max": high-water mark, "capacity": next call's}} + "reruns": forwards repeated."""
-    rep = {b: {"D_max": d, "capacity": _cap_grid(max(b[1] * _dup_factor(), 2 * d))} for b, d in _hwm.items()}
+    """{(device, sized surfels, H, W): {"D_max": the window's maximum, "calls": its length, "capacity": next call's}} +
+    "reruns": forwards repeated."""
+    rep = {b: {"D_max": max(h), "calls": len(h), "capacity": _cap_grid(max(b[1] * _dup_factor(), 2 * max(h)))}
+           for b, h in _hist.items() if h}
     rep["reruns"] = _reruns
     return rep
 
 
 def reset_capacity_history():
     """Forget the measured pair counts (tests)."""
-    _hwm.clear()
-    _guard.clear()
+    _hist.clear()
+
+
+# ---- the pair counts, read while the forward runs --------------------------------------------------------------------------
+_tls = threading.local()
+_COUNT_SPINS = 4000          # polls of the pinned words before the loop starts yielding the GIL / looking at the stream
+_counts_fallbacks = 0        # calls whose counts had to be read from the device header instead (never expected)
+
+
+class _Counts:
+    """uint32[n][4] of pinned host memory the scan kernel writes (D, overflow, longest list, ready) -- one per thread, re-used
+    by every call (a call has read its words before it returns)."""
+
+    def __init__(self, n):
+        self.t = torch.zeros((max(n, 16), 4), dtype=torch.int32).pin_memory()
+        self.np = self.t.numpy().view("uint32")
+        self.ptr = self.t.data_ptr()
+
+
+def _counts(n) -> _Counts:
+    c = getattr(_tls, "counts", None)
+    if c is None or c.np.shape[0] < n:
+        c = _tls.counts = _Counts(n)
+    return c
+
+
+def _wait_counts(c: _Counts, n: int, done: torch.cuda.Event, headers):
+    """Spin until the scan kernel(s) of the forward just enqueued have stored their counts; returns (max D, overflow?).
+    `done` was recorded behind the whole forward: if it has completed and the words are still missing, the device could not
+    write the pinned buffer -- then (never seen) the counts come from the device headers, with a blocking copy."""
+    global _counts_fallbacks
+    ready = c.np[:n, 3]
+    spins = 0
+    while not ready.all():
+        spins += 1
+        if spins > _COUNT_SPINS:
+            if done.query() and not ready.all():
+                _counts_fallbacks += 1
+                h = headers().cpu().numpy().view("uint32").reshape(n, -1)
+                return int(h[:, 0].max()), bool(h[:, 1].any())
+            time.sleep(0)
+    return int(c.np[:n, 0].max()), bool(c.np[:n, 1].any())
+
+
+def _run_forward(bucket, n, enqueue, debug=False):
+    """Enqueue a forward (`enqueue(cap, counts_ptr) -> (state, headers, extra)`; `headers()` = its 64-byte device headers) at
+    the capacity the size class's history asks for, wait for its pair counts, and repeat it at the reported size while it does
+    not fit -- all before returning.  Returns (state, cap, extra, D)."""
+    global _reruns
+    cap = _next_capacity(bucket)
+    c = _counts(n)
+    while True:
+        c.np[:n, 3] = 0
+        state, headers, extra = enqueue(cap, c.ptr)
+        done = torch.cuda.Event()
+        done.record()
+        D, overflow = _wait_counts(c, n, done, headers)
+        note_pair_count(bucket, D)
+        if not overflow:
+            break
+        new_cap = _cap_grid(max(2 * D, bucket[1] * _dup_factor()))
+        if new_cap <= cap:      # only at the 32-bit limit of the pair index
+            raise RuntimeError(
+                f"lara_amd: a view produced {D} (tile, surfel) pairs, beyond the 32-bit pair index the buffers use "
+                f"(capacity {cap}); its outputs were poisoned with NaN.")
+        _reruns += 1
+        state = headers = None
+        cap = new_cap
+    if debug:       # the reference's debug switch: synchronous error checking (a faulting kernel raises here, not later)
+        torch.cuda.current_stream().synchronize()
+    return state, cap, extra, D
 
 
 _scratch = {}   # (device index, stream id) -> uint8 tensor
-_pending = []   # [_Run] forwards whose pair counts have not been read yet
 
 
 _GUARD = 1 << 16   # poison mode: guard bytes on either side of a state / scratch buffer
@@ -252,89 +344,6 @@ def _get_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf
-
-
-class _Run:
-    """One enqueued forward (a view, or the n views of a multi-view call): its state buffer(s), the pinned copy of the
-    64-byte header(s) and how to enqueue it again at a larger capacity."""
-    __slots__ = ("bucket", "cap", "state", "extra", "enqueue", "stream", "debug", "ev", "hdrs", "done", "n")
-
-    def __init__(self, bucket, cap, enqueue, stream, debug, n=1):
-        self.bucket, self.cap, self.enqueue, self.stream, self.debug, self.n = bucket, cap, enqueue, stream, debug, n
-        self.state = self.extra = self.ev = self.hdrs = None
-        self.done = False
-
-    def launch(self, cap):
-        """Enqueue the forward at `cap` on the current stream and start the asynchronous copy of its header(s)."""
-        self.cap = cap
-        self.state, hdr_dev, self.extra = self.enqueue(cap)
-        hdr = torch.empty(hdr_dev.shape, dtype=torch.int32, pin_memory=True)
-        hdr.copy_(hdr_dev, non_blocking=True)
-        self.ev = torch.cuda.Event()
-        self.ev.record()
-        self.hdrs = hdr.view(-1, 16)
-
-    def settle(self, lazy=False):
-        """Read the header(s) (waiting for them if need be); a forward that did not fit is enqueued again at the size it
-        reported, on its own stream, into the same outputs.  Afterwards `state` / `cap` are what the backward uses."""
-        global _reruns
-        if self.done:
-            return
-        while True:
-            self.ev.synchronize()
-            D = max(int(h[0]) & 0xFFFFFFFF for h in self.hdrs)
-            _hwm[self.bucket] = max(_hwm.get(self.bucket, 0), D)
-            if not any(int(h[1]) != 0 for h in self.hdrs):
-                break
-            cap = _cap_grid(max(2 * D, self.bucket[1] * _dup_factor()))
-            if cap <= self.cap:      # only at the 32-bit limit of the pair index
-                self.done = True
-                raise RuntimeError(
-                    f"lara_amd: a view produced {D} (tile, surfel) pairs, beyond the 32-bit pair index the buffers use "
-                    f"(capacity {self.cap}); its outputs were poisoned with NaN.")
-            if lazy:
-                warnings.warn(
-                    f"lara_amd: a rasteriser call produced {D} (tile, surfel) pairs for a capacity of {self.cap} (more than "
-                    "twice anything calls of this size had produced); its outputs held NaN until now and have been "
-                    "re-rendered in place.  Operators that consumed them in between saw NaN; the next "
-                    f"{_GUARD_CALLS} calls of this size read the pair count synchronously.", RuntimeWarning, stacklevel=3)
-                _guard[self.bucket] = _GUARD_CALLS
-            _reruns += 1
-            with torch.cuda.stream(self.stream):
-                self.launch(cap)
-        self.done = True
-        self.enqueue = None      # drops the references to inputs and outputs
-
-
-def _guarded(bucket, debug) -> bool:
-    """Does this call read its pair count synchronously?  (debug / first call of a size class / after a repeated call)"""
-    if debug or bucket not in _hwm:
-        return True
-    g = _guard.get(bucket, 0)
-    if g > 0:
-        _guard[bucket] = g - 1
-        return True
-    return False
-
-
-def check_pending(block: bool = False):
-    """Read the pair counts of earlier forwards -- without stalling any stream unless ``block`` -- and repeat the ones that
-    did not fit their buffers (see the workspace policy above).  Never raises for an overflow that a larger buffer cures."""
-    global _pending
-    runs, _pending = _pending, []
-    keep = []
-    for i, run in enumerate(runs):
-        if run.done:
-            continue
-        if block or run.ev.query():
-            try:
-                run.settle(lazy=True)
-            except Exception:
-                _pending = keep + runs[i + 1:]
-                raise
-        else:
-            keep.append(run)
-    _pending = keep
 
 
 def _prep(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor]:
@@ -387,8 +396,8 @@ def _make_view(rs: GaussianRasterizationSettings, P: int, M: int, cap: int, devi
         raise RuntimeError("lara_amd: bg[3], viewmatrix[4,4], projmatrix[4,4], campos[3] expected")
     v = _View(P, int(rs.sh_degree), M, int(rs.image_height), int(rs.image_width),
               float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
-              int(bool(rs.prefiltered)) | (2 if _cull_transparent else 0), int(bool(rs.debug)), cap,
-              bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
+              int(bool(rs.prefiltered)) | (2 if _cull_transparent else 0), int(bool(rs.debug)), 0, cap,
+              bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), None)
     return v, (bg, vm, pm, cp)
 
 
@@ -423,39 +432,40 @@ def _validate(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_
     return device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c)
 
 
-def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
-    """Validate, allocate, enqueue the forward.  Returns everything backward / the tests need."""
+def _needs_state(*tensors) -> bool:
+    """Will a backward follow?  (Evaluated by the callers of the autograd nodes: inside `Function.forward` grad mode is off.)"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, forward_only=False):
+    """Validate, allocate, enqueue the forward; returns once its pair count is known and it fits (see the workspace policy).
+    `forward_only`: nothing is kept for a backward and the returned `state` is the short one."""
     lib = load_library()
     device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c) = _validate(
         means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.sh_degree)
     H, W = int(rs.image_height), int(rs.image_width)
-    check_pending()
+    fo = int(bool(forward_only))
     with torch.cuda.device(device):
         view, keep = _make_view(rs, P, M, 0, device)
+        view.forward_only = fo
         color = torch.empty((3, H, W), dtype=torch.float32, device=device)
         allmap = torch.empty((7, H, W), dtype=torch.float32, device=device)
         radii = torch.empty((P,), dtype=torch.int32, device=device)
 
-        def enqueue(cap):
+        def enqueue(cap, counts_ptr):
             view.capacity = cap
-            state = _alloc_bytes(lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap), device)
-            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap))
+            view.counts_out = counts_ptr
+            state = _alloc_bytes(lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap, fo), device)
+            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap, fo))
             rc = lib.lara2dgs_forward(ctypes.byref(view), _ptr(means3D_c), _ptr(sh_c), _ptr(col_c),
                                       _ptr(opa_c), _ptr(sc_c), _ptr(rot_c), _ptr(tm_c),
                                       color.data_ptr(), allmap.data_ptr(), radii.data_ptr(),
                                       state.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
             _check(rc, "lara2dgs_forward")
-            return state, state[:64].view(torch.int32), None
+            return state, (lambda: state[:64].view(torch.int32)), None
 
-        bucket = _bucket(device, P, H, W)
-        run = _Run(bucket, 0, enqueue, torch.cuda.current_stream(device), bool(rs.debug))
-        guarded = _guarded(bucket, rs.debug)
-        run.launch(binning_capacity(P, H, W, device))
-        if guarded:
-            run.settle()
-        else:
-            _pending.append(run)
-    return dict(color=color, radii=radii, allmap=allmap, run=run, M=M, keep=keep,
+        state, cap, _, D = _run_forward(_bucket(device, P, H, W), 1, enqueue, bool(rs.debug))
+    return dict(color=color, radii=radii, allmap=allmap, state=state, cap=cap, D=D, M=M, keep=keep,
                 inputs=(means3D_c, sh_c, col_c, sc_c, rot_c, tm_c))
 
 
@@ -471,7 +481,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.M = M
         ctx.prefiltered_bits = int(bool(rs.prefiltered)) | (2 if _cull_transparent else 0)   # as the forward ran
-        ctx.run = r["run"]      # holds `state` (replaced if the forward had to be repeated at a larger capacity)
+        ctx.state, ctx.cap, ctx.D = r["state"], r["cap"], r["D"]
         ctx.flags = (sh_c is not None, col_c is not None, sc_c is not None, tm_c is not None)
         ctx.shapes = (sh.shape if sh_c is not None else None, opacities.shape)
         empty = means3D_c.new_empty(0)
@@ -494,9 +504,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         device = means3D.device
         P = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
-        run = ctx.run
-        run.settle(lazy=True)  # the header is long there by the time autograd gets here
-        state, cap = run.state, run.cap
+        state, cap = ctx.state, ctx.cap
         with torch.cuda.device(device):
             if grad_color is None:
                 grad_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
@@ -505,8 +513,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_color = _prep(grad_color, "grad_color", device)
             grad_allmap = _prep(grad_allmap, "grad_allmap", device)
             view = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
-                         float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)),
-                         cap, bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
+                         float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)), 0,
+                         cap, bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), None)
             new = lambda *s: torch.empty(s, dtype=torch.float32, device=device)
             g_means3D = new(P, 3)
             g_means2D = new(P, 3)
@@ -516,7 +524,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_sc = new(P, 2) if has_sr else None
             g_rot = new(P, 4) if has_sr else None
             g_tm = new(P, 9) if has_tm else None
-            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap))
+            scratch = _get_scratch(device, lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap, 0))
             stream = torch.cuda.current_stream(device).cuda_stream
             rc = lib.lara2dgs_backward(
                 ctypes.byref(view), _ptr(means3D), _ptr(sh if has_sh else None),
@@ -548,6 +556,47 @@ def _views_array(settings, P, M, cap, device, prefiltered_bits=None):
     return arr, keep
 
 
+def _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, forward_only=False):
+    """The n views of a scene in one library call (see `_forward_impl`); `state` holds the n per-view states at stride `sb`."""
+    lib = load_library()
+    rs0 = settings[0]
+    n = len(settings)
+    for rs in settings[1:]:
+        if (rs.image_height, rs.image_width, rs.sh_degree, bool(rs.prefiltered), float(rs.scale_modifier), bool(rs.debug)) != \
+                (rs0.image_height, rs0.image_width, rs0.sh_degree, bool(rs0.prefiltered), float(rs0.scale_modifier), bool(rs0.debug)):
+            raise RuntimeError("lara_amd: the views of one multi-view call must agree in image size, sh_degree, prefiltered, "
+                               "scale_modifier and debug")
+    device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c) = _validate(
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs0.sh_degree)
+    H, W = int(rs0.image_height), int(rs0.image_width)
+    fo = int(bool(forward_only))
+    with torch.cuda.device(device):
+        views, keep = _views_array(settings, P, M, 0, device)
+        color = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
+        allmap = torch.empty((n, 7, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((n, P), dtype=torch.int32, device=device)
+
+        def enqueue(cap, counts_ptr):
+            for i in range(n):
+                views[i].capacity = cap
+                views[i].forward_only = fo
+                views[i].counts_out = counts_ptr + 16 * i
+            sb = (lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap, fo) + 255) // 256 * 256
+            qb = (lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap, fo) + 255) // 256 * 256
+            state = _alloc_bytes(n * sb, device)
+            scratch = _get_scratch(device, n * qb)      # a scratch buffer per view: every kernel is one launch over the cameras
+            rc = lib.lara2dgs_forward_views(n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c),
+                                            _ptr(sc_c), _ptr(rot_c), _ptr(tm_c), color.data_ptr(), allmap.data_ptr(),
+                                            radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb,
+                                            torch.cuda.current_stream(device).cuda_stream)
+            _check(rc, "lara2dgs_forward_views")
+            return state, (lambda: state.view(n, sb)[:, :64].contiguous().view(torch.int32)), (sb, qb)
+
+        state, cap, (sb, qb), D = _run_forward(_bucket(device, P, H, W), n, enqueue, any(rs.debug for rs in settings))
+    return dict(color=color, radii=radii, allmap=allmap, state=state, cap=cap, strides=(sb, qb), D=D, M=M, keep=keep,
+                inputs=(means3D_c, sh_c, col_c, sc_c, rot_c, tm_c))
+
+
 class _RasterizeViews(torch.autograd.Function):
     """ONE autograd node for the n views of a scene: same surfels, n cameras (the reference's loop at
     lightning/network.py:486-497 issues n nodes).  Per-camera state is carved from one allocation; every kernel is one
@@ -555,52 +604,15 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
-        lib = load_library()
         settings = tuple(settings)
         rs0 = settings[0]
-        n = len(settings)
-        for rs in settings[1:]:
-            if (rs.image_height, rs.image_width, rs.sh_degree, bool(rs.prefiltered), float(rs.scale_modifier), bool(rs.debug)) != \
-                    (rs0.image_height, rs0.image_width, rs0.sh_degree, bool(rs0.prefiltered), float(rs0.scale_modifier), bool(rs0.debug)):
-                raise RuntimeError("lara_amd: the views of one multi-view call must agree in image size, sh_degree, prefiltered, "
-                                   "scale_modifier and debug")
-        device, P, M, (means3D_c, sh_c, col_c, opa_c, sc_c, rot_c, tm_c) = _validate(
-            means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs0.sh_degree)
-        H, W = int(rs0.image_height), int(rs0.image_width)
-        check_pending()
-        debug = any(rs.debug for rs in settings)
-        with torch.cuda.device(device):
-            views, keep = _views_array(settings, P, M, 0, device)
-            color = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
-            allmap = torch.empty((n, 7, H, W), dtype=torch.float32, device=device)
-            radii = torch.empty((n, P), dtype=torch.int32, device=device)
-
-            def enqueue(cap):
-                for i in range(n):
-                    views[i].capacity = cap
-                sb = (lib.lara2dgs_state_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
-                qb = (lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap) + 255) // 256 * 256
-                state = _alloc_bytes(n * sb, device)
-                scratch = _get_scratch(device, n * qb)      # a scratch buffer per view: every kernel is one launch over the cameras
-                rc = lib.lara2dgs_forward_views(n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c),
-                                                _ptr(sc_c), _ptr(rot_c), _ptr(tm_c), color.data_ptr(), allmap.data_ptr(),
-                                                radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb,
-                                                torch.cuda.current_stream(device).cuda_stream)
-                _check(rc, "lara2dgs_forward_views")
-                return state, state.view(n, sb)[:, :64].contiguous().view(torch.int32), (sb, qb)
-
-            bucket = _bucket(device, P, H, W)
-            run = _Run(bucket, 0, enqueue, torch.cuda.current_stream(device), debug, n)
-            guarded = _guarded(bucket, debug)
-            run.launch(binning_capacity(P, H, W, device))
-            if guarded:
-                run.settle()
-            else:
-                _pending.append(run)
+        r = _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings)
+        color, radii, allmap, M, keep = r["color"], r["radii"], r["allmap"], r["M"], r["keep"]
+        means3D_c, sh_c, col_c, sc_c, rot_c, tm_c = r["inputs"]
+        ctx.state, ctx.cap, ctx.strides, ctx.D = r["state"], r["cap"], r["strides"], r["D"]
         ctx.settings = settings
         ctx.M = M
         ctx.prefiltered_bits = int(bool(rs0.prefiltered)) | (2 if _cull_transparent else 0)
-        ctx.run = run
         ctx.flags = (sh_c is not None, col_c is not None, sc_c is not None, tm_c is not None)
         ctx.shapes = (sh.shape if sh_c is not None else None, opacities.shape)
         empty = means3D_c.new_empty(0)
@@ -622,9 +634,7 @@ class _RasterizeViews(torch.autograd.Function):
         device = means3D.device
         P = means3D.shape[0]
         H, W = int(rs0.image_height), int(rs0.image_width)
-        run = ctx.run
-        run.settle(lazy=True)
-        state, cap, (sb, qb) = run.state, run.cap, run.extra
+        state, cap, (sb, qb) = ctx.state, ctx.cap, ctx.strides
         G = GradLayout()
         _check(lib.lara2dgs_get_grad_layout(P, ctx.M, int(has_sh), int(has_col), int(has_sr), int(has_tm), ctypes.byref(G)),
                "lara2dgs_get_grad_layout")
@@ -639,8 +649,8 @@ class _RasterizeViews(torch.autograd.Function):
             for i, rs in enumerate(settings):
                 bg, vm, pm, cp = cams[4 * i:4 * i + 4]
                 views[i] = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
-                                 float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)), cap,
-                                 bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr())
+                                 float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)), 0, cap,
+                                 bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), None)
             out = torch.empty((max(G.total, 4),), dtype=torch.float32, device=device)
             # each view's gradient rows stay in its own scratch buffer until ONE preprocess_bwd launch folds the n views into
             # the summed gradient (no per-view gradient tensors)
@@ -679,6 +689,10 @@ def rasterize_gaussians_views(settings, means3D, means2D, opacities, shs=None, c
         raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
     means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp = (
         _as_f32(t) for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
+    if not _needs_state(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp):
+        # inference (evaluation.py:129 / tools/meshExtractor.py:85 run under no_grad): a forward-only call, no autograd node
+        r = _forward_views_impl(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, tuple(settings), True)
+        return r["color"], r["radii"], r["allmap"]
     return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                  tuple(settings))
 
@@ -695,6 +709,10 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     # kernel launches -- so the explicit cast is the whole of its effect)
     means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = (
         _as_f32(t) for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
+    if not _needs_state(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+        # inference (evaluation.py:129 / tools/meshExtractor.py:85 run under no_grad): a forward-only call, no autograd node
+        r = _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, True)
+        return r["color"], r["radii"], r["allmap"]
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      rotations, cov3Ds_precomp, raster_settings)
 
@@ -741,24 +759,29 @@ class GaussianRasterizer(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # introspection used by the parity tests and by bench.py (not part of the reference surface)
 # ---------------------------------------------------------------------------------------------
-def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
-    """Typed views into a forward's ``state`` buffer (the integer parity surface)."""
+def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int, forward_only: bool = False) -> dict:
+    """Typed views into a forward's ``state`` buffer (the integer parity surface).  A forward-only state holds the sections
+    up to `tile_order`."""
     lib = load_library()
     L = StateLayout()
-    _check(lib.lara2dgs_get_state_layout(P, H, W, cap, ctypes.byref(L)), "lara2dgs_get_state_layout")
+    _check(lib.lara2dgs_get_state_layout(P, H, W, cap, int(forward_only), ctypes.byref(L)), "lara2dgs_get_state_layout")
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
 
     def sec(off, nbytes, dtype, shape):
         return state[off:off + nbytes].view(dtype).view(shape)
 
     hdr = sec(L.header, 256, torch.int32, (64,))
-    return dict(
+    common = dict(
         header=hdr,
         geom=sec(L.geom, P * 80, torch.float32, (P, 20)),
         cullbox=sec(L.cullbox, P * 16, torch.float32, (P, 4)),
         point_list=sec(L.point_list, cap * 4, torch.int32, (cap,)),
         ranges=sec(L.ranges, tiles * 8, torch.int32, (tiles, 2)),
-        tile_order=sec(L.tile_order, tiles * 4, torch.int32, (tiles,)),
+        tile_order=sec(L.tile_order, tiles * 4, torch.int32, (tiles,)))
+    if forward_only:
+        return common
+    return dict(
+        common,
         final_T=sec(L.final_T, 10 * H * W * 4, torch.float32, (10, H, W)),
         n_contrib=sec(L.n_contrib, 2 * H * W * 4, torch.int32, (2, H, W)),
         seg_base=sec(L.seg_base, (tiles + 1) * 4, torch.int32, (tiles + 1,)),
@@ -772,16 +795,15 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int) -> dict:
 
 
 def forward_with_state(raster_settings, means3D, opacities, shs=None, colors_precomp=None,
-                       scales=None, rotations=None, cov3D_precomp=None) -> dict:
-    """Forward only, returning the saved ``state`` too: ``dict(color, radii, allmap, views, ...)``."""
+                       scales=None, rotations=None, cov3D_precomp=None, forward_only=False) -> dict:
+    """One forward returning its ``state`` too: ``dict(color, radii, allmap, state, cap, D, views, ...)`` -- the training-mode
+    forward's full state, or (``forward_only``) the short one of an inference call."""
     with torch.no_grad():
         r = _forward_impl(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                          raster_settings)
-    r["run"].settle()       # synchronises; a forward that did not fit has been repeated by now
-    r["state"], r["cap"] = r["run"].state, r["run"].cap
+                          raster_settings, forward_only)
     P = means3D.shape[0]
-    r["views"] = state_views(r["state"], P, int(raster_settings.image_height),
-                             int(raster_settings.image_width), r["cap"])
+    r["views"] = state_views(r["state"], P, int(raster_settings.image_height),      # (the layout is the real P's; the buffer is sized for _sizing_P)
+                             int(raster_settings.image_width), r["cap"], forward_only)
     return r
 
 

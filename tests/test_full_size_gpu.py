@@ -39,10 +39,10 @@ def test_multi_view_launch_at_benchmark_size_equals_the_per_view_operator_and_th
     inp = leaves()
     color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
                                                      scales=inp["scales"], rotations=inp["rotations"])
-    run = color.grad_fn.run     # the forward's state buffer and capacity (final once the backward has read the pair counts)
+    node = color.grad_fn        # the forward's state buffer and capacity
+    state, (sb, _), cap = node.state, node.strides, node.cap
     ((color * dc).sum() + (allmap * da).sum()).backward()
     torch.cuda.synchronize()
-    state, (sb, _), cap = run.state, run.extra, run.cap
 
     want = None
     for i, rs in enumerate(settings):
@@ -64,7 +64,6 @@ def test_multi_view_launch_at_benchmark_size_equals_the_per_view_operator_and_th
     r = {"views": views, "radii": radii[v], "color": color[v].detach(), "allmap": allmap[v].detach()}
     D = _check_forward(r, run_oracle(oracle_view(cams[v], bgs[v]), to_numpy(act)), S, S)
     assert 1_000_000 < D < 3_000_000
-    rasterizer.check_pending(block=True)
 
 
 def test_trained_like_regime_at_benchmark_size_multi_view_launch_against_the_oracle(hip_lib):
@@ -88,10 +87,9 @@ def test_trained_like_regime_at_benchmark_size_multi_view_launch_against_the_ora
     inp = {k: t.to(DEV).clone().requires_grad_(True) for k, t in act.items()}
     color, radii, allmap = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
                                                      scales=inp["scales"], rotations=inp["rotations"])
-    run = color.grad_fn.run
+    state, (sb, _), cap = color.grad_fn.state, color.grad_fn.strides, color.grad_fn.cap
     ((color * gc).sum() + (allmap * ga).sum()).backward()
     torch.cuda.synchronize()
-    state, (sb, _), cap = run.state, run.extra, run.cap
     views = rasterizer.state_views(state.view(n, sb)[v], P, S, S, cap)
     r = {"views": views, "radii": radii[v], "color": color[v].detach(), "allmap": allmap[v].detach()}
     D = _check_forward(r, run_oracle(oracle_view(cams[v], bgs[v]), to_numpy(act)), S, S)
@@ -105,7 +103,6 @@ def test_trained_like_regime_at_benchmark_size_multi_view_launch_against_the_ora
     rep = oracle_conditioned_gradient_check(to_numpy(act), cams[v], bgs[v], dc, da, {k: t.grad.cpu().numpy() for k, t in inp.items()})
     print("trained-like, full size, view %d: D = %d; (rel-L2 HIP, rel-L2 oracle +1ulp, surfels > 1e-3 HIP, oracle): %s" % (
         v, D, {k: (round(a, 6), round(b, 6), c, d) for k, (a, b, c, d) in rep.items()}))
-    rasterizer.check_pending(block=True)
 
 
 def test_eval_resolution_at_full_surfel_count_against_the_oracle(hip_lib):
@@ -130,8 +127,8 @@ def test_eval_resolution_at_full_surfel_count_against_the_oracle(hip_lib):
     color, radii, allmap = GaussianRasterizer(raster_settings(cam, bg, device=DEV))(
         means3D=inp["means3D"], means2D=torch.zeros_like(inp["means3D"]), shs=inp["shs"], opacities=inp["opacities"],
         scales=inp["scales"], rotations=inp["rotations"])
-    run = color.grad_fn.run
-    assert run.done, "the first call of a size class settles its capacity before it returns"
+    class run:      # the forward's state buffer and capacity (settled before the operator returned)
+        state, cap = color.grad_fn.state, color.grad_fn.cap
     ((color * torch.from_numpy(dc).to(DEV)).sum() + (allmap * torch.from_numpy(da).to(DEV)).sum()).backward()
     torch.cuda.synchronize()
     views = rasterizer.state_views(run.state, P, S, S, run.cap)
@@ -225,7 +222,6 @@ def test_pipeline_at_benchmark_size_two_scene_streams_equal_one_over_50_steps(hi
                 worst["cos"] = min(worst["cos"], cos)
                 assert d <= (2e-4 if fp32_path(n) else 1e-2) and cos >= 1 - 1e-5, (step, n, d, cos)
     torch.cuda.synchronize()
-    rasterizer.check_pending(block=True)
     # the fine subsets really changed size: P for the coarse pass + a different count per (step, scene)
     assert 524288 in sizes_seen and len(sizes_seen) > 50, len(sizes_seen)
     print(f"two-stream vs one-stream over 50 full-size steps: outputs bit-identical; worst gradient difference (of max) "

@@ -291,9 +291,7 @@ def test_backward_work_items_are_ordered_dearest_first(hip_lib):
     inp = {k: v.to(DEV).requires_grad_(True) for k, v in act.items()}
     color, _, allmap = GaussianRasterizer(rs)(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
                                               scales=inp["scales"], rotations=inp["rotations"])
-    run = color.grad_fn.run
-    run.settle()
-    state, cap = run.state, run.cap
+    state, cap = color.grad_fn.state, color.grad_fn.cap
     P = act["means3D"].shape[0]
     v = rasterizer.state_views(state, P, 64, 64, cap)
     torch.cuda.synchronize()
@@ -326,7 +324,7 @@ def test_backward_with_the_capacity_barely_above_the_pair_count(hip_lib, monkeyp
     cam, bg = cams[1], (1.0, 1.0, 1.0)
     ref = run_oracle(oracle_view(cam, bg), to_numpy(act))
     cap = int(ref.num_rendered) + 64
-    monkeypatch.setattr(rasterizer, "binning_capacity", lambda P, *a: cap)
+    monkeypatch.setattr(rasterizer, "_next_capacity", lambda bucket: cap)
     r = _gpu_forward(raster_settings(cam, bg, sh_degree=1, device=DEV), act)
     v = r["views"]
     assert int(v["header"][1]) == 0 and r["cap"] == cap
@@ -401,11 +399,12 @@ def _call(rs, t, **kw):
                                   opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], **kw)
 
 
-def test_a_call_that_outgrows_its_buffers_is_repeated_not_fatal(hip_lib, monkeypatch):
+def test_a_call_that_outgrows_its_buffers_is_repeated_before_it_returns(hip_lib, monkeypatch):
     """The reference sizes its buffers AFTER reading num_rendered: a call at renderer_2dgs.py:209-218 never
-    fails on the pair count.  Here the buffers are sized before the call from what earlier calls produced; when the surfels
-    grow (scales ramped, as a training run ramps them) the capacity follows, and a call that does not fit is repeated at the
-    size it reported.  No exception at any point; every image, radius and gradient equal to a run whose buffers were
+    fails on the pair count and never returns garbage.  Here the buffers are sized before the call from what recent calls
+    produced; when the surfels grow (scales ramped, as a training run ramps them) the capacity follows, and a call that does
+    not fit is repeated at the size it reported BEFORE THE OPERATOR RETURNS: no exception, no warning, no NaN in anything a
+    consumer enqueued right behind the call reads; every image, radius and gradient equal to a run whose buffers were
     generous from the start, bit for bit."""
     import warnings
     from lara_amd import rasterizer
@@ -424,21 +423,23 @@ def test_a_call_that_outgrows_its_buffers_is_repeated_not_fatal(hip_lib, monkeyp
             with torch.no_grad():
                 t["scales"].mul_(f)
             color, radii, allmap = _call(rs, t)
+            seen = torch.isnan(color).sum() + torch.isnan(allmap).sum()      # a consumer enqueued right behind the call
+            node = color.grad_fn
             (color.sum() + allmap[:2].sum()).backward()
             torch.cuda.synchronize()
-            run = color.grad_fn.run
+            assert int(seen) == 0, "a consumer read poisoned outputs"
             out.append((color.detach().clone(), radii.clone(), allmap.detach().clone(),
-                        {k: v.grad.clone() for k, v in t.items()}, int(run.hdrs[0][0]), run.cap))
+                        {k: v.grad.clone() for k, v in t.items()}, node.D, node.cap))
         return out
 
     before = rasterizer._reruns
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         tight = run_ramp(1)
-    lazy_reruns = rasterizer._reruns - before
-    generous = run_ramp(512)
-    assert rasterizer._reruns - before == lazy_reruns, "the generous run must never repeat a call"
-    assert lazy_reruns >= 2 and any("re-rendered in place" in str(x.message) for x in w)
+        reruns = rasterizer._reruns - before
+        generous = run_ramp(512)
+    assert rasterizer._reruns - before == reruns, "the generous run must never repeat a call"
+    assert reruns >= 2
     Ds = [o[4] for o in tight]
     assert max(Ds) > 16 * P and Ds[4] > 2 * Ds[3], "the ramp must leave the old 16 P behind and jump by more than 2x once"
     for (c0, r0, a0, g0, D0, cap0), (c1, r1, a1, g1, D1, cap1) in zip(tight, generous):
@@ -451,33 +452,53 @@ def test_a_call_that_outgrows_its_buffers_is_repeated_not_fatal(hip_lib, monkeyp
     rasterizer.reset_capacity_history()
 
 
-def test_first_call_and_debug_calls_read_the_pair_count_synchronously(hip_lib, monkeypatch):
-    """Nothing measured yet for a size class (and `debug=True`, the reference's own switch for synchronous checking): the
-    call reads D before it returns, as the reference does on every call -- an overflow is repaired before anyone can see a
-    poisoned value, without a warning."""
+def test_overflow_is_repaired_under_no_grad_and_in_multi_view_calls_too(hip_lib, monkeypatch):
+    """The same guarantee for the inference callers (forward-only calls) and for the multi-view call, where ONE view of the n
+    outgrowing the capacity repeats the call: outputs equal a generous run's, nothing poisoned is ever visible."""
     import warnings
-    from lara_amd import rasterizer
+    from lara_amd import rasterizer, rasterize_gaussians_views
     act, cams = _ramp_scene()
-    monkeypatch.setenv("LARA2DGS_DUP_FACTOR", "1")
-    monkeypatch.setattr(rasterizer, "_cap_grid", lambda n: min(max(int(n), 1024), 0xFFFFFFFF))
+    settings = [raster_settings(c, (1, 1, 1), device=DEV) for c in cams[:3]]
     t = {k: v.to(DEV) for k, v in act.items()}
-    ref = None
-    for debug in (False, True):
+    big = dict(t, scales=t["scales"] * 6)
+
+    def run(factor):
+        monkeypatch.setenv("LARA2DGS_DUP_FACTOR", str(factor))
+        monkeypatch.setattr(rasterizer, "_cap_grid", lambda n: min(max(int(n), 1024), 0xFFFFFFFF))
         rasterizer.reset_capacity_history()
-        rs = raster_settings(cams[0], (1, 1, 1), device=DEV)._replace(debug=debug)
-        before = rasterizer._reruns
-        with warnings.catch_warnings():
-            warnings.simplefilter("error")
-            color, radii, allmap = _call(rs, t)        # first call of the class: synchronous
-            assert rasterizer._reruns == before + 1 and not rasterizer._pending
-            assert not torch.isnan(color).any()          # (no synchronisation needed: the repeat was enqueued before the return)
-            if debug:                                    # a later call, far beyond what the class has seen: still synchronous
-                big = dict(t, scales=t["scales"] * 8)
-                c2, _, _ = _call(rs, big)
-                assert rasterizer._reruns == before + 2 and not rasterizer._pending and not torch.isnan(c2).any()
-        ref = color if ref is None else ref
-        assert torch.equal(ref, color)
+        out = []
+        with torch.no_grad():
+            for inp in (t, big, t):
+                c, r, a = _call(settings[0], inp)
+                out += [c, r, a, torch.isnan(c).sum() + torch.isnan(a).sum()]
+                c, r, a = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
+                                                    scales=inp["scales"], rotations=inp["rotations"])
+                out += [c, r, a, torch.isnan(c).sum() + torch.isnan(a).sum()]
+        torch.cuda.synchronize()
+        return out
+
+    before = rasterizer._reruns
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tight = run(1)
+        reruns = rasterizer._reruns - before
+        generous = run(512)
+    assert reruns >= 2 and rasterizer._reruns - before == reruns
+    for x, y in zip(tight, generous):
+        assert torch.equal(x, y)
+    assert all(int(x) == 0 for x in tight[3::4])
     rasterizer.reset_capacity_history()
+
+
+def test_debug_calls_synchronise(hip_lib):
+    """`debug=True` is the reference's switch for synchronous error checking: the call returns with its stream drained."""
+    act, cams = _ramp_scene()
+    t = {k: v.to(DEV) for k, v in act.items()}
+    rs = raster_settings(cams[0], (1, 1, 1), device=DEV)
+    ref, _, _ = _call(rs, t)
+    color, _, _ = _call(rs._replace(debug=True), t)
+    assert torch.cuda.current_stream().query()
+    assert torch.equal(ref, color)
 
 
 def test_mark_visible_and_argument_errors(hip_lib):

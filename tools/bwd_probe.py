@@ -25,11 +25,10 @@ for regime in ('init', 'trained', 'fine'):  # 'fine': the opacity > 0.005 subset
             color, radii, allmap = GaussianRasterizer(rs)(means3D=act["means3D"], means2D=torch.zeros_like(act["means3D"]),
                                                           shs=act["shs"], opacities=act["opacities"],
                                                           scales=act["scales"], rotations=act["rotations"])
-            run = color.grad_fn.run
+            state, cap = color.grad_fn.state, color.grad_fn.cap
             torch.autograd.backward([color, allmap], [gc, ga])
             torch.cuda.synchronize()
         P = act["means3D"].shape[0]
-        state, cap = run.state, run.cap
         h = rasterizer.state_views(state, P, 512, 512, cap)["header"].cpu().numpy().astype('uint32')
         span = (int(h[11]) - (~int(h[10]) & 0xffffffff)) & 0xffffffff
         v = rasterizer.state_views(state, P, 512, 512, cap)
