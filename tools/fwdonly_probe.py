@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--regime", default="init")
     ap.add_argument("--grown", type=int, default=7_500_000, help="pair count a training run was seen to reach (D per view)")
+    ap.add_argument("--only", default="", help="per_view | views_api: run just that loop (counter passes)")
     ap.add_argument("--out", default="gpurun_out/fwdonly_probe.json")
     args = ap.parse_args()
     from lara_amd import cameras, synthetic, GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_views
@@ -80,6 +81,8 @@ def main():
     def phase(name):
         out[name] = {}
         for what, fn in (("per_view", per_view), ("views_api", views_api)):
+            if args.only and what != args.only:
+                continue
             try:
                 out[name][what] = rate(fn)
             except torch.OutOfMemoryError as e:      # (round 5: forwards whose pair counts were not read yet own their state)
@@ -89,6 +92,9 @@ def main():
                 json.dump(out, f, indent=1)
 
     phase("fresh")
+    if args.only:
+        print(json.dumps(out))
+        return
     # what `step_with_reference_lr` leaves behind: the size class has seen D = --grown pairs per view
     b = rz._bucket(dev, scenes[0]["centers"].shape[0], args.res, args.res)
     if hasattr(rz, "note_pair_count"):

@@ -83,11 +83,13 @@ if os.path.exists(known_f):
                   open(os.path.join(prof, f"{tag}_traffic_calibration.json"), "w"), indent=1)
 traffic = {}
 for c, key in (("FETCH_SIZE", "fetch_counter"), ("WRITE_SIZE", "write_counter")):
-    agg, cnt = pmc_table(os.path.join(out, f"traffic_{tag}_{c}", "**", "*counter_collection.csv"))
-    for k, d in agg.items():
-        if "lara" in k or k.endswith("_fwd") or k.endswith("_bwd") or "tile_" in k or "scatter" in k or "<" in k:
-            name = re.sub(r"<.*", "", k)
-            traffic.setdefault(name, {})[key] = int(d[c] / cnt[(k, c)] * 1024)  # counter unit: KB
+    # (the second directory: per-view calls under no_grad -- the forward-only instantiation of the library, tools/gpu_traffic.sh)
+    for sub, suffix in ((f"traffic_{tag}_{c}", ""), (f"traffic_{tag}_{c}_fwdonly", "@forward_only_call")):
+        agg, cnt = pmc_table(os.path.join(out, sub, "**", "*counter_collection.csv"))
+        for k, d in agg.items():
+            if "lara" in k or k.endswith("_fwd") or k.endswith("_bwd") or "tile_" in k or "scatter" in k or "<" in k:
+                name = re.sub(r"<.*", "", k) + suffix
+                traffic.setdefault(name, {})[key] = int(d[c] / cnt[(k, c)] * 1024)  # counter unit: KB
 if traffic:
     for v in traffic.values():
         v["read"] = 2 * v.get("fetch_counter", 0)         # calibrated (see above)
