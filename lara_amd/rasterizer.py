@@ -493,6 +493,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               tm_c if tm_c is not None else empty,
                               radii, *keep)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)      # (else autograd zero-fills a gradient for the int32 `radii` on every backward)
         return color, radii, allmap
 
     @staticmethod
@@ -620,6 +621,7 @@ class _RasterizeViews(torch.autograd.Function):
                               sc_c if sc_c is not None else empty, rot_c if rot_c is not None else empty,
                               tm_c if tm_c is not None else empty, radii, *keep)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)      # (else autograd zero-fills a gradient for the int32 `radii` [n, P] on every backward)
         return color, radii, allmap
 
     @staticmethod

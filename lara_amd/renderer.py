@@ -139,7 +139,7 @@ class _SurfaceMapsViews(torch.autograd.Function):
     side, each [H, n*W, C] -- the per-scene concatenation of lightning/network.py:527 written directly by the kernel."""
 
     @staticmethod
-    def forward(ctx, color, allmap, rays, rots, depth_ratio):
+    def forward(ctx, color, allmap, rays, rots, depth_ratio, into=None):
         if not color.is_cuda:
             raise RuntimeError("lara_amd: tensors must live on an MI355X (HIP) device; there is no CPU path")
         color, allmap = color.float().contiguous(), allmap.float().contiguous()
@@ -148,8 +148,17 @@ class _SurfaceMapsViews(torch.autograd.Function):
         if color.shape != (n, 3, H, W) or allmap.shape != (n, 7, H, W) or rays.shape != (n, H, W, 6) or rots.shape != (n, 3, 3):
             raise RuntimeError("expected color [n,3,H,W], allmap [n,7,H,W], rays [n,H,W,6], rots [n,3,3]")
         o = dict(dtype=torch.float32, device=color.device)
-        image, depth, acc = torch.empty(H, n * W, 3, **o), torch.empty(H, n * W, 1, **o), torch.empty(H, n * W, **o)
-        rnorm, dnorm, rdist = torch.empty(H, n * W, 3, **o), torch.empty(H, n * W, 3, **o), torch.empty(H, n * W, **o)
+        shapes = ((H, n * W, 3), (H, n * W, 1), (H, n * W), (H, n * W, 3), (H, n * W, 3), (H, n * W))
+        if into is None:
+            image, depth, acc, rnorm, dnorm, rdist = (torch.empty(*sh, **o) for sh in shapes)
+        else:
+            # `into`: six caller-owned buffers the kernel writes instead -- a scene's slices of the batch's [B, H, n*W, C] outputs
+            # (lara_amd.pipeline: the stack of network.py:529 then copies nothing).  They are not inputs of the graph: the
+            # outputs are fresh tensors over the same memory.
+            for t, sh in zip(into, shapes):
+                if tuple(t.shape) != sh or t.dtype != torch.float32 or not t.is_contiguous() or t.device != color.device or t.requires_grad:
+                    raise RuntimeError("lara_amd: `into` buffers must be contiguous fp32 tensors of the maps' shapes that need no gradient")
+            image, depth, acc, rnorm, dnorm, rdist = (t.detach() for t in into)
         with torch.cuda.device(color.device):
             _check(_lib().lara_surface_maps_forward_views(n, H, W, color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), rots.data_ptr(),
                                                           float(depth_ratio), image.data_ptr(), depth.data_ptr(), acc.data_ptr(),
@@ -173,12 +182,38 @@ class _SurfaceMapsViews(torch.autograd.Function):
                                                            d_color.data_ptr(), d_allmap.data_ptr(),
                                                            torch.cuda.current_stream(color.device).cuda_stream),
                    "lara_surface_maps_backward_views")
-        return d_color, d_allmap, None, None, None
+        return d_color, d_allmap, None, None, None, None
 
 
-def surface_maps_views(color, allmap, rays, rots, depth_ratio=0.0):
+def surface_maps_views(color, allmap, rays, rots, depth_ratio=0.0, into=None):
     """The fused post-processing of n views at once, outputs concatenated along the width (see `_SurfaceMapsViews`)."""
-    return _SurfaceMapsViews.apply(color, allmap, rays, rots, depth_ratio)
+    return _SurfaceMapsViews.apply(color, allmap, rays, rots, depth_ratio, into)
+
+
+MAP_KEYS = ("image", "depth", "acc_map", "rend_normal", "depth_normal", "rend_dist")      # the order of the six maps everywhere
+
+
+class _AssembleScenes(torch.autograd.Function):
+    """`torch.stack(parts)` (network.py:529) when the parts already LIVE in `buf[i]` -- each scene's post-processing wrote its
+    slice of the batch buffer (`surface_maps_views(..., into=...)`): no copy forward, slices of the gradient backward."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        for i, p in enumerate(parts):
+            if p.data_ptr() != buf[i].data_ptr() or p.shape != buf[i].shape:
+                raise RuntimeError("lara_amd: a scene's map does not live in its slice of the batch buffer")
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g.unbind(0))
+
+
+def batch_map_buffers(B, H, VW, device, prexes=("",)):
+    """The batch's output dictionary as uninitialised buffers {key+prex: [B, H, V*W, C]} for `render_views(..., into=)`."""
+    o = dict(dtype=torch.float32, device=device)
+    chans = {"image": (3,), "depth": (1,), "acc_map": (), "rend_normal": (3,), "depth_normal": (3,), "rend_dist": ()}
+    return {k + prex: torch.empty((B, H, VW) + chans[k], **o) for prex in prexes for k in MAP_KEYS}
 
 
 def surface_maps(color, allmap, rays, rot, depth_ratio=0.0):
@@ -284,7 +319,7 @@ class Renderer(nn.Module):
                 f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist}
 
     def render_views(self, cams, rays, centers, shs, opacity, scales, rotations, device, bg_colors=None,
-                     cov3D_precomp=None, prex='', depth_ratio=0.0, concat=False):
+                     cov3D_precomp=None, prex='', depth_ratio=0.0, concat=False, into=None):
         """All views of a scene in ONE rasteriser call (one autograd node, per-camera state carved from one
         allocation, gradients summed over the views inside the library): what the reference's inner loop
         (lightning/network.py:486-497 coarse, :516-525 fine) does with one ``render_img`` per view.  ``cams`` is a
@@ -292,7 +327,8 @@ class Renderer(nn.Module):
         per-view backgrounds the loop passes through ``set_bg_color`` (default: this renderer's colour).  Returns the
         list of per-view dictionaries ``render_img`` would have returned; with ``concat=True`` ONE dictionary whose maps
         are the views' maps side by side, [H, n*W, C] -- what network.py:527 builds with ``torch.cat(..., dim=1)`` --
-        written by one post-processing launch for all views."""
+        written by one post-processing launch for all views -- into the caller's buffers when ``into`` ({key+prex: [H, n*W, C]})
+        is given."""
         n = len(cams)
         if torch.is_tensor(bg_colors) and bg_colors.dim() == 2:     # rows on 16-byte boundaries (see cameras.make_cameras)
             bg_colors = torch.nn.functional.pad(bg_colors.float(), (0, 1))[:, :3]
@@ -304,7 +340,8 @@ class Renderer(nn.Module):
         if concat and rays is not None:
             rots = torch.stack([cam.world_view_transform[:3, :3] for cam in cams]).transpose(1, 2)       # renderer_2dgs.py:231
             rays_t = rays if torch.is_tensor(rays) else torch.stack(list(rays))
-            image, depth, acc, rnorm, dnorm, rdist = surface_maps_views(color, allmap, rays_t, rots, depth_ratio)
+            image, depth, acc, rnorm, dnorm, rdist = surface_maps_views(
+                color, allmap, rays_t, rots, depth_ratio, None if into is None else tuple(into[k + prex] for k in MAP_KEYS))
             return {f"image{prex}": image, f"depth{prex}": depth, f"acc_map{prex}": acc, f"rend_normal{prex}": rnorm,
                     f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist}
         out = []
