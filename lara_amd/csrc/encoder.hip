@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "mfma_gemm.h"
+#include "mlp_fused.h"
 #include "../../include/lara_groupattn.h"
 
 namespace {
@@ -101,7 +102,17 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
     unsigned short *hid = xn + (size_t)M * 256;  // [M, 512]
     float2 *stats = (float2 *)((char *)workspace + (size_t)M * 256 * 2 * 4);
     char *zero_row = (char *)workspace + (size_t)M * 256 * 2 * 4 + (size_t)M * 8;
-    // 2. MLP
+    // 2. MLP + norm3: ONE kernel per 128-row tile (mlp_fused.h); the hidden tensor never leaves the CU
+#ifndef LARA_MLP_UNFUSED
+    (void)hid;
+    {
+        L2D_PROF("gb_mlp_fused", s);
+        MlpP p{};
+        p.x1 = x; p.x2 = x; p.ln2_w = w->ln2_w; p.ln2_b = w->ln2_b; p.b1 = w->b1; p.b2 = w->b2; p.ln3_w = w->ln3_w; p.ln3_b = w->ln3_b;
+        p.w1 = w->w1; p.w2 = w->w2; p.xn3 = xn; p.stats = stats; p.eps = w->eps; p.M = M;
+        if (launch_mlp_fused<false>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    }
+#else       // (rounds 2-5: four launches; tools/build_variant.sh -DLARA_MLP_UNFUSED for A/B runs)
     {
         L2D_PROF("gb_ln2", s);
         hipLaunchKernelGGL(ln_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w->ln2_w, w->ln2_b, w->eps, xn,
@@ -128,6 +139,7 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
         hipLaunchKernelGGL(ln_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w->ln3_w, w->ln3_b, w->eps, xn,
                            stats, M);
     }
+#endif
     L2D_CHECK_LAUNCH();
     if (hipMemsetAsync(zero_row, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     {

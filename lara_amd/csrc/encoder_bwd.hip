@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "mfma_gemm.h"
+#include "mlp_fused.h"
 #include "group_attn.h"
 #include "../../include/lara_groupattn.h"
 
@@ -1277,6 +1278,15 @@ int block_forward_keep(int M, int cond_dim, const float *x_in, const unsigned sh
         hipLaunchKernelGGL(group_attn_fused2_kernel<true>, dim3((G + 3) / 4), dim3(64), 0, s, x_in, w->ln1_w, w->ln1_b, w->eps, wqp, kv, wop,
                            x1, G, xn1, q, o);
     }
+#ifndef LARA_MLP_UNFUSED
+    (void)lnb;
+    {   // norm2 -> fc1 -> GELU -> fc2 -> + x1 -> norm3 as one kernel per 128-row tile (mlp_fused.h); leaves xn2, z, h, x2, xn3, stats
+        MlpP p{};
+        p.x1 = x1; p.x2 = x2; p.ln2_w = w->ln2_w; p.ln2_b = w->ln2_b; p.b1 = w->b1; p.b2 = w->b2; p.ln3_w = w->ln3_w; p.ln3_b = w->ln3_b;
+        p.w1 = w->w1; p.w2 = w->w2; p.xn3 = xn3; p.stats = (float2 *)(save + L.stats); p.xn2 = xn2; p.z = z; p.h = h; p.eps = w->eps; p.M = M;
+        if (launch_mlp_fused<true>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+    }
+#else       // (rounds 2-5: four launches; tools/build_variant.sh -DLARA_MLP_UNFUSED for A/B runs)
     hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x1, w->ln2_w, w->ln2_b, w->eps, xn2, (float2 *)nullptr, M);
     {
         GemmP p{};
@@ -1290,6 +1300,7 @@ int block_forward_keep(int M, int cond_dim, const float *x_in, const unsigned sh
     }
     hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x2, w->ln3_w, w->ln3_b, w->eps, xn3,
                        (float2 *)(save + L.stats), M);
+#endif
     if (hipMemsetAsync(xn3 + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
 }
