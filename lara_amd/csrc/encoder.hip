@@ -110,7 +110,7 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
         MlpP p{};
         p.x1 = x; p.x2 = x; p.ln2_w = w->ln2_w; p.ln2_b = w->ln2_b; p.b1 = w->b1; p.b2 = w->b2; p.ln3_w = w->ln3_w; p.ln3_b = w->ln3_b;
         p.w1 = w->w1; p.w2 = w->w2; p.xn3 = xn; p.stats = stats; p.eps = w->eps; p.M = M;
-        if (launch_mlp_fused<false>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        if (launch_mlp_fused<0>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     }
 #else       // (rounds 2-5: four launches; tools/build_variant.sh -DLARA_MLP_UNFUSED for A/B runs)
     {

@@ -1284,7 +1284,7 @@ int block_forward_keep(int M, int cond_dim, const float *x_in, const unsigned sh
         MlpP p{};
         p.x1 = x1; p.x2 = x2; p.ln2_w = w->ln2_w; p.ln2_b = w->ln2_b; p.b1 = w->b1; p.b2 = w->b2; p.ln3_w = w->ln3_w; p.ln3_b = w->ln3_b;
         p.w1 = w->w1; p.w2 = w->w2; p.xn3 = xn3; p.stats = (float2 *)(save + L.stats); p.xn2 = xn2; p.z = z; p.h = h; p.eps = w->eps; p.M = M;
-        if (launch_mlp_fused<true>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        if (launch_mlp_fused<1>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
     }
 #else       // (rounds 2-5: four launches; tools/build_variant.sh -DLARA_MLP_UNFUSED for A/B runs)
     hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x1, w->ln2_w, w->ln2_b, w->eps, xn2, (float2 *)nullptr, M);
@@ -1441,6 +1441,34 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
     }
     L2D_CHECK_LAUNCH();
     // ---- x2 = x1 + mlp(norm2(x1)) ----
+#ifndef LARA_MLP_UNFUSED
+    {
+        // dz = (g2 W2) * gelu'(z) and dy = dz W1 as ONE kernel per 128-row tile (mlp_fused.h): dz stays in LDS between the two products
+        // (it still leaves for the weight gradient of fc1), its per-tile column sums are the pieces of db1.  LARA_MLP_BWD_LN: norm2's
+        // backward in the same kernel's epilogue (MODE 2) -- measured slower than the pass of its own (profiles/r06_mlp_fused_phases.txt)
+        L2D_PROF("gbb_dx_mlp", s);
+        MlpP p{};
+        p.gin = gb3; p.w1 = wt->w2_t; p.w2 = wt->w1_t; p.z = z; p.h = dzb; p.x1 = x1; p.ln2_w = w->ln2_w; p.eps = w->eps;
+        p.part_b1 = lnp4 + lnset; p.M = M;
+        const int tiles = (M + 127) / 128;
+#ifdef LARA_MLP_BWD_LN
+        p.g = g; p.gout = gb2; p.part_ln = lnp4 + 2 * lnset;
+        if (launch_mlp_fused<2>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+        red.add(dw->ln2_w, lnp4 + 2 * lnset, 256, tiles, 768);
+        red.add(dw->ln2_b, lnp4 + 2 * lnset + 256, 256, tiles, 768);
+#else
+        p.gout = tmpb;
+        if (launch_mlp_fused<3>(p, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+#endif
+        red.add(dw->b1, lnp4 + lnset, 512, tiles, 512);
+    }
+#ifndef LARA_MLP_BWD_LN
+    {
+        L2D_PROF("gbb_ln_bwd", s);
+        if ((rc = ln_bwd(tmpb, true, x1, w->ln2_w, w->eps, g, g, gb2, dw->ln2_w, dw->ln2_b, nullptr, lnp4 + 2 * lnset, M, s, &red))) return rc;
+    }
+#endif
+#else
     {
         L2D_PROF("gbb_dx_mlp", s);
         // dz = (g2 W2) * gelu'(z); its column sums per 128-row tile (= the pieces of db1) come out of the same epilogue
@@ -1452,6 +1480,7 @@ int lara_groupblock_backward(int32_t scenes, int32_t R, int32_t cond_dim, const 
         L2D_PROF("gbb_ln_bwd", s);
         if ((rc = ln_bwd(tmpb, true, x1, w->ln2_w, w->eps, g, g, gb2, dw->ln2_w, dw->ln2_b, nullptr, lnp4 + 2 * lnset, M, s, &red))) return rc;
     }
+#endif
     L2D_CHECK_LAUNCH();
     // ---- x1 = x0 + cross_attn(norm1(x0), cond, cond) ----
     {

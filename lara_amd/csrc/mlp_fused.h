@@ -51,8 +51,9 @@ template <int NW> struct MfCfg {
     static constexpr int AHEAD = SLOTS - 2;                // slots in flight behind the one being multiplied (see the loop)
     static constexpr int PW = 16 / NW;                     // one-KB pieces of a slot per wave
     static constexpr int HC = TM * 256;                    // the hidden chunk: [4 panels of 32 units][TM tokens][64 B]
-    static constexpr int LDS = HC + SLOTS * MF_SLOT + MF_CONST;   // 101 KB / 69 KB (phase 0's TM x 512 B of normalised rows and the
-                                                                  // epilogue's bounce tiles alias the chunk + ring region)
+    static constexpr int ZC = TM * 256;                    // the chunk's pre-activations z, same layout (training forward: out; backward: in)
+    static constexpr int LDS = HC + ZC + SLOTS * MF_SLOT + MF_CONST;   // 133 KB / 85 KB (phase 0's TM x 512 B of normalised rows and the
+                                                                       // epilogue's bounce tiles alias the chunk + ring region)
 };
 
 struct MlpP {
@@ -65,17 +66,34 @@ struct MlpP {
     unsigned short *xn2, *z, *h;      // TRAIN: bf16 [M, 256], [M, 512], [M, 512]
     float eps;
     int M;
+    // MODE 2 (the backward of the same chain, see mlp_fused_kernel): w1 = W2^T [512, 256], w2 = W1^T [256, 512]; x1, ln2_w, eps, z as
+    // above (z is READ); h = dz out (bf16 [M, 512])
+    const unsigned short *gin;        // bf16 [M, 256]: the gradient of x2 (what norm3's backward left)
+    float *g;                         // fp32 [M, 256] in / out: the residual stream's gradient; out = g + norm2's backward
+    unsigned short *gout;             // bf16 [M, 256] out: the same, rounded
+    float *part_ln;                   // [row tiles][3][256]: per-tile column sums of dy xhat, dy, out (dgamma, dbeta of norm2, -)
+    float *part_b1;                   // [row tiles][512]: per-tile column sums of dz (the bias gradient of fc1)
 };
 
-template <bool TRAIN, int NW>
+// MODE 0: inference forward; 1: training forward (TRAIN); 2: the BACKWARD of the same chain, which has the same shape --
+//     dz = (g2 . W2) * gelu'(z)            <-> fc1 with W2^T as its weight, the activation a product with gelu'(z) read from HBM
+//     dy = dz . W1   (rounded to bf16)      <-> fc2 with W1^T as its weight
+//     g  = g + norm2_backward(dy; x1)       <-> the epilogue
+// (network.py:94 backwards; rounds 2-5: two products, 175 us, + a LayerNorm backward pass, 98 us, per layer.)  Phase 0 copies the bf16
+// gradient rows into the fragment layout (no LayerNorm); the chunk's dz leaves through LDS for the weight gradient of fc1, its
+// per-tile column sums (fc1's bias gradient) are taken on the way; the epilogue re-deals the tile so that a wave owns WHOLE rows
+// (64 rows x 256 floats at a time through LDS) and runs ln_bwd_kernel's arithmetic on them, operation for operation.
+template <int MODE, int NW>
 __global__ void __launch_bounds__(64 * NW)
 mlp_fused_kernel(const MlpP p) {
+    constexpr bool TRAIN = MODE == 1;
     using Cfg = MfCfg<NW>;
     constexpr int TM = Cfg::TM, PANEL = TM * 64, MF_SLOTS = Cfg::SLOTS, MF_AHEAD = Cfg::AHEAD, PW = Cfg::PW, MF_HC = Cfg::HC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *const hc = lds;                       // hidden chunk
     unsigned char *const ring = lds + MF_HC;             // weight slots
-    float *const cst = (float *)(lds + MF_HC + MF_SLOTS * MF_SLOT);
+    unsigned char *const zc = lds + MF_HC + MF_SLOTS * MF_SLOT;      // z chunk
+    float *const cst = (float *)(lds + MF_HC + MF_SLOTS * MF_SLOT + Cfg::ZC);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kh = lane >> 5;
@@ -120,11 +138,23 @@ mlp_fused_kernel(const MlpP p) {
     };
 
     // ---- phase 0: norm2 of the tile's rows -> bf16 -> LDS [8 panels of 32 channels][128 tokens][64 B] (aliases chunk + ring)
+    if (MODE >= 2) {
+        if (MODE == 2 && tid < 64) ((float4 *)cst)[tid] = ((const float4 *)p.ln2_w)[tid];      // gamma of norm2
+    } else
     for (int t = tid; t < 320; t += 64 * NW) {      // the constants: b1 | b2 | gamma3 | beta3
         const float *src = t < 128 ? p.b1 + t * 4 : t < 192 ? p.b2 + (t - 128) * 4 : t < 256 ? p.ln3_w + (t - 192) * 4 : p.ln3_b + (t - 256) * 4;
         ((float4 *)cst)[t] = *(const float4 *)src;
     }
-    if (!(MF_TIMING & 4)) {
+    if (MODE >= 2) {
+        uint2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = ((const uint2 *)(p.gin + (size_t)min(bm0 + wave * 16 + i, M - 1) * 256))[lane];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int tok = wave * 16 + i;
+            *(uint2 *)(lds + (lane >> 3) * PANEL + tok * 64 + ((((lane & 7) >> 1) ^ ((tok >> 2) & 3)) << 4) + (lane & 1) * 8) = v[i];
+        }
+    } else if (!(MF_TIMING & 4)) {
         const float4 g = ((const float4 *)p.ln2_w)[lane], be = ((const float4 *)p.ln2_b)[lane];
         float4 v[16];
 #pragma unroll
@@ -169,6 +199,8 @@ mlp_fused_kernel(const MlpP p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc2[i][j][e] = 0.f;
     f32x16 acc1[2];
+    float *const csum = cst + 256;                 // MODE 2, 3: [NW waves][128] column sums of the chunk's dz
+    (void)csum; (void)zc;
 
     // fragment offsets inside a slot / the chunk: row * 64 + ((K step's chunk pair 2 s + kh) ^ ((row >> 2) & 3)) * 16
     int a1off[2], a2off[2], b2off[2];      // [K step s]: fc1's A rows (W1: wh * 64 + r, + 32 i = + 2048 i), fc2's A rows (chunk: wr * 64 + r), fc2's B rows (W2: wc * 64 + r)
@@ -208,6 +240,27 @@ mlp_fused_kernel(const MlpP p) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             const unsigned char *slot = ring + (n % MF_SLOTS) * MF_SLOT;
+            if (MODE >= 2 && k == 0) {
+                // the chunk's pre-activations z [TM tokens x 128 units] into LDS, in the chunk buffer's layout, by DMA: 4 TM / 16 one-KB
+                // pieces (16 tokens x 32 units each), 16-byte row-contiguous reads (the accumulator layout's own 8-byte gathers used a
+                // quarter of every 64-byte sector they touched).  Needed at k == 3; the pieces are older than the weight slots that
+                // iteration waits for, so its counted wait covers them.  (The buffer's last readers were the k == 3 epilogue of the
+                // chunk before: four barriers ago.)
+                const uint32_t zc_a = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)zc;
+#pragma unroll
+                for (int q = 0; q < (4 * TM / 16) / NW; q++) {
+                    const int piece = q * NW + wave, pan = piece / (TM / 16), tok = 16 * (piece % (TM / 16)) + (lane >> 2);
+                    const uint32_t off = (uint32_t)min(bm0 + tok, M - 1) * 1024u + (uint32_t)c * 256u + (uint32_t)pan * 64u +
+                                         (uint32_t)(((lane & 3) ^ ((tok >> 2) & 3)) << 4);
+                    MF_DMA((const char *)p.z, off, zc_a + piece * 1024);
+                }
+            }
+            if (MODE >= 2 && k == 5 && tid < 128) {      // fc1's bias gradient of the chunk: the eight waves' column sums (see k == 4)
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) t += csum[w * 128 + tid];
+                p.part_b1[(size_t)blockIdx.x * 512 + c * 128 + tid] = t;
+            }
             if (k < 4) {
                 // fc1^T: four K steps (sub-tile, s) of two MFMAs: acc1[i] += W1 rows (wh*64 + 32 i + r) . xn tokens (wt*32 + r)
 #pragma unroll
@@ -229,27 +282,57 @@ mlp_fused_kernel(const MlpP p) {
 #pragma unroll
                         for (int eg = 0; eg < 4; eg++) {
                             const int u0 = wh * 64 + 32 * i + 8 * eg + 4 * kh;
+                            uint2 hh;
+                            if (MODE >= 2) {      // dz = (g2 . W2) * gelu'(z)
+                                const uint2 zz = *(const uint2 *)(zc + (2 * wh + i) * PANEL + tok * 64 + ((eg ^ ((tok >> 2) & 3)) << 4) + kh * 8);
+                                hh.x = f2bf2(acc1[i][4 * eg] * gelu_erf_grad(bf2f((unsigned short)zz.x)),
+                                             acc1[i][4 * eg + 1] * gelu_erf_grad(bf2f((unsigned short)(zz.x >> 16))));
+                                hh.y = f2bf2(acc1[i][4 * eg + 2] * gelu_erf_grad(bf2f((unsigned short)zz.y)),
+                                             acc1[i][4 * eg + 3] * gelu_erf_grad(bf2f((unsigned short)(zz.y >> 16))));
+                            } else {
                             const float4 bs = *(const float4 *)(cst + c * 128 + u0);
                             const float z0 = acc1[i][4 * eg] + bs.x, z1 = acc1[i][4 * eg + 1] + bs.y;
                             const float z2 = acc1[i][4 * eg + 2] + bs.z, z3 = acc1[i][4 * eg + 3] + bs.w;
-                            if (TRAIN && bm0 + tok < M) {
+                            if (TRAIN) {      // z leaves through LDS like h (row-contiguous 16-byte stores, see k == 4)
                                 uint2 zz;
                                 zz.x = f2bf2(z0, z1); zz.y = f2bf2(z2, z3);
-                                *(uint2 *)(p.z + (size_t)(bm0 + tok) * 512 + c * 128 + u0) = zz;
+                                *(uint2 *)(zc + (2 * wh + i) * PANEL + tok * 64 + ((eg ^ ((tok >> 2) & 3)) << 4) + kh * 8) = zz;
                             }
-                            uint2 hh;
                             hh.x = f2bf2(gelu_erf(z0), gelu_erf(z1)); hh.y = f2bf2(gelu_erf(z2), gelu_erf(z3));
+                            }
                             *(uint2 *)(hc + (2 * wh + i) * PANEL + tok * 64 + ((eg ^ ((tok >> 2) & 3)) << 4) + kh * 8) = hh;
                         }
                 }
             } else {
-                if (k == 4 && TRAIN) {
-                    // (the barrier of this slot published the chunk) h out, row-contiguous: 128 tokens x 256 bytes
+                if (k == 4 && (TRAIN || MODE >= 2)) {
+                    // (the barrier of this slot published the chunk) h / dz out, row-contiguous: 128 tokens x 256 bytes.  MODE 2: the
+                    // column sums of what is stored (fc1's bias gradient) on the way: a thread's pieces all belong to columns
+                    // 8 (tid & 15) .. + 8; its four tokens, then the wave's four lanes of a column group, then (k == 5) the waves
+                    float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int idx = u * (64 * NW) + tid, tok = idx >> 4, c16 = idx & 15;
                         const uint4 v = *(const uint4 *)(hc + (c16 >> 2) * PANEL + tok * 64 + (((c16 & 3) ^ ((tok >> 2) & 3)) << 4));
-                        if (bm0 + tok < M) *(uint4 *)(p.h + (size_t)(bm0 + tok) * 512 + c * 128 + c16 * 8) = v;
+                        if (bm0 + tok < M) {
+                            *(uint4 *)(p.h + (size_t)(bm0 + tok) * 512 + c * 128 + c16 * 8) = v;
+                            if (TRAIN)
+                                *(uint4 *)(p.z + (size_t)(bm0 + tok) * 512 + c * 128 + c16 * 8) =
+                                    *(const uint4 *)(zc + (c16 >> 2) * PANEL + tok * 64 + (((c16 & 3) ^ ((tok >> 2) & 3)) << 4));
+                            if (MODE >= 2) {
+                                cs8[0] += __uint_as_float(v.x << 16); cs8[1] += __uint_as_float(v.x & 0xffff0000u);
+                                cs8[2] += __uint_as_float(v.y << 16); cs8[3] += __uint_as_float(v.y & 0xffff0000u);
+                                cs8[4] += __uint_as_float(v.z << 16); cs8[5] += __uint_as_float(v.z & 0xffff0000u);
+                                cs8[6] += __uint_as_float(v.w << 16); cs8[7] += __uint_as_float(v.w & 0xffff0000u);
+                            }
+                        }
+                    }
+                    if (MODE >= 2) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { cs8[q] += __shfl_xor(cs8[q], 16, 64); cs8[q] += __shfl_xor(cs8[q], 32, 64); }
+                        if (lane < 16) {
+                            *(float4 *)(csum + wave * 128 + lane * 8) = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
+                            *(float4 *)(csum + wave * 128 + lane * 8 + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
+                        }
                     }
                 }
                 // fc2: two K steps of four MFMAs: acc2[i][j] += h tokens (wr*64 + 32 i + r) . W2 rows (wc*64 + 32 j + r)
@@ -273,6 +356,100 @@ mlp_fused_kernel(const MlpP p) {
         return;
     }
 
+    if (MODE == 3) {
+        // ---- the backward's products alone: dy = bf16(acc2) to HBM (p.gout), row-contiguous through LDS; norm2's backward stays a
+        //      pass of its own (ln_bwd_kernel: many small workgroups at HBM speed, where the fused epilogue below serialises its
+        //      0.47 GB behind the products of ONE workgroup per CU)
+        unsigned short *bounce = (unsigned short *)lds;      // [64][256] bf16
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    bounce[(wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * 256 + wc * 64 + j * 32 + r] = f2bf(acc2[i][j][e]);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; u++) {      // 64 rows x 512 bytes = 2048 sixteen-byte pieces
+                const int idx = u * 512 + tid, lrow = idx >> 5, c16 = idx & 31;
+                const int row = bm0 + (lrow >> 5) * 64 + i * 32 + (lrow & 31);
+                if (row < M) *(uint4 *)(p.gout + (size_t)row * 256 + c16 * 8) = *(const uint4 *)(bounce + lrow * 256 + c16 * 8);
+            }
+        }
+        return;
+    }
+    if (MODE == 2) {
+        // ---- epilogue of the backward: dy = bf16(acc2); g <- g + norm2's backward (ln_bwd_kernel's arithmetic); a wave owns whole rows.
+        //      Half i of the tile = the rows wr * 64 + 32 i + (0 .. 31) of both wave rows: 64 rows x 256 floats through LDS,
+        //      wave w then takes bounce rows 8 w .. 8 w + 7.
+        float *bounce = (float *)lds;                       // [64][256]
+        const float4 gam = ((const float4 *)cst)[lane];
+        float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, po[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float4 xv[8], kv[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int lrow = wave * 8 + t, row = min(bm0 + (lrow >> 5) * 64 + i * 32 + (lrow & 31), M - 1);
+                xv[t] = ((const float4 *)(p.x1 + (size_t)row * 256))[lane];
+                kv[t] = ((const float4 *)(p.g + (size_t)row * 256))[lane];
+            }
+            __syncthreads();      // (i == 1: the rows of half 0 have been read)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    bounce[(wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * 256 + wc * 64 + j * 32 + r] = bf2f(f2bf(acc2[i][j][e]));
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int lrow = wave * 8 + t, row = bm0 + (lrow >> 5) * 64 + i * 32 + (lrow & 31);
+                const float4 v = xv[t], k = kv[t], d = ((const float4 *)(bounce + lrow * 256))[lane];
+                float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                const float mean = s * (1.0f / 256.0f);
+                const float c0 = v.x - mean, c1 = v.y - mean, c2 = v.z - mean, c3 = v.w - mean;
+                float q = c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + p.eps);
+                const float h0 = c0 * rstd, h1 = c1 * rstd, h2 = c2 * rstd, h3 = c3 * rstd;
+                const float a0 = d.x * gam.x, a1 = d.y * gam.y, a2 = d.z * gam.z, a3 = d.w * gam.w;
+                float sa = a0 + a1 + a2 + a3, sh = a0 * h0 + a1 * h1 + a2 * h2 + a3 * h3;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sh += __shfl_xor(sh, o, 64); }
+                sa *= (1.0f / 256.0f); sh *= (1.0f / 256.0f);
+                const float4 rr = make_float4(rstd * (a0 - sa - h0 * sh) + k.x, rstd * (a1 - sa - h1 * sh) + k.y,
+                                              rstd * (a2 - sa - h2 * sh) + k.z, rstd * (a3 - sa - h3 * sh) + k.w);
+                if (row < M) {
+                    ((float4 *)(p.g + (size_t)row * 256))[lane] = rr;
+                    uint2 hb;
+                    hb.x = f2bf2(rr.x, rr.y); hb.y = f2bf2(rr.z, rr.w);
+                    ((uint2 *)(p.gout + (size_t)row * 256))[lane] = hb;
+                    pg[0] += d.x * h0; pg[1] += d.y * h1; pg[2] += d.z * h2; pg[3] += d.w * h3;
+                    pb[0] += d.x; pb[1] += d.y; pb[2] += d.z; pb[3] += d.w;
+                    po[0] += rr.x; po[1] += rr.y; po[2] += rr.z; po[3] += rr.w;
+                }
+            }
+        }
+        __syncthreads();
+        float *red = (float *)lds;      // [NW][12][64]
+#pragma unroll
+        for (int c = 0; c < 4; c++) { red[(wave * 12 + c) * 64 + lane] = pg[c]; red[(wave * 12 + 4 + c) * 64 + lane] = pb[c]; red[(wave * 12 + 8 + c) * 64 + lane] = po[c]; }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) t += red[(w * 12 + k) * 64 + lane];
+                p.part_ln[(size_t)blockIdx.x * 768 + (k >> 2) * 256 + 4 * lane + (k & 3)] = t;      // quantity k / 4, channel 4 lane + k % 4
+            }
+        }
+        return;
+    }
     // ---- epilogue: x2 = acc2 + b2 + x1, norm3(x2).  Per wave 32 rows x 64 columns per trip through LDS (as ring_epilogue);
     //      a lane then holds four columns (c4) of rows 16 half + 4 q + lg; a row's 256 columns sit in the four waves of its wave row.
     // the residual rows this lane adds below (16 float4: the registers the fc1 operand held until the last chunk), requested in one
@@ -347,12 +524,13 @@ mlp_fused_kernel(const MlpP p) {
     }
 }
 
-template <bool TRAIN>
+template <int MODE>
 static inline hipError_t launch_mlp_fused(const MlpP &p, hipStream_t s) {
     using Cfg = MfCfg<MF_NW>;
-    static const hipError_t attr = hipFuncSetAttribute((const void *)mlp_fused_kernel<TRAIN, MF_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    static_assert(MODE < 2 || MF_NW == 8, "the backward's epilogue deals 64-row halves to eight waves");
+    static const hipError_t attr = hipFuncSetAttribute((const void *)mlp_fused_kernel<MODE, MF_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((mlp_fused_kernel<TRAIN, MF_NW>), dim3((p.M + Cfg::TM - 1) / Cfg::TM), dim3(64 * MF_NW), Cfg::LDS, s, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<MODE, MF_NW>), dim3((p.M + Cfg::TM - 1) / Cfg::TM), dim3(64 * MF_NW), Cfg::LDS, s, p);
     return hipGetLastError();
 }
 
