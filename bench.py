@@ -58,6 +58,7 @@ if ROOT not in sys.path:
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MEASURED_COPY_GBS = 5400.0   # what a device-to-device copy sustains on this part (`roofline.measured_copy_GBs`, 5.3-5.4 TB/s in every run)
 
 
 def parse():
@@ -569,10 +570,19 @@ def attention_leg(device, scenes):
     rasterizer.profile_enable(False)
     us = 1e3 * sum(ms for _, ms in rec) / 5
     flops = G * (2 * 8 * 256 * 256 * 2 + 2 * 4 * 800 * 512 + 2 * 2 * 8 * 4 * 16 * 16)
+    # What this formulation must move through HBM whatever its kernels do: the fp32 residual stream in and out, the bf16 conditioning
+    # rows, the K|V rows written by their projection and read back by the attention kernel.  (Fusing that projection into the per-group
+    # kernel -- VERDICT r5 #5 -- would take the 67 MB round trip away and the projection's weight reuse with it: a wave owns 16 conditioning
+    # rows and would stream the 0.8 MB weight matrix for them.)  At the copy rate this part sustains the step cannot be faster than
+    # `hbm_floor_us`, i.e. its ceiling against the matrix peak is `ceiling_frac`, not 1.
+    hbm_bytes = G * (2 * 8 * 256 * 4 + 4 * 800 * 2 + 2 * 4 * 512 * 2)
+    floor_us = hbm_bytes / (MEASURED_COPY_GBS * 1e3)
     return {"workload": f"GroupAttBlock attention step (LN, q/k/v/out projections, QK^T, softmax, AV), "
                         f"{scenes} scenes = {G} groups, forward, bf16 MFMA / fp32 accumulate",
             "us_per_layer": round(us, 1), "achieved": round(flops / us / 1e6, 1), "peak": 2500.0,
-            "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 2500.0, 4), "bound": "mfma"}
+            "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 2500.0, 4), "bound": "mfma",
+            "hbm_bytes": hbm_bytes, "hbm_floor_us": round(floor_us, 1), "copy_GBs_assumed": MEASURED_COPY_GBS,
+            "ceiling_frac": round(flops / floor_us / 1e6 / 2500.0, 4), "frac_of_ceiling": round(floor_us / us, 4)}
 
 
 def encoder_leg(device, scenes):

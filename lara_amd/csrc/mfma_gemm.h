@@ -880,6 +880,8 @@ static inline hipError_t launch_gemm_ring(const GemmP &p, hipStream_t s) {
     static const hipError_t attr = hipFuncSetAttribute((const void *)gemm_ring_kernel<AMODE, EPI>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, RING * RTILE);
     if (attr != hipSuccess) return attr;
+    // EPI 9's row sums need a tile that holds WHOLE rows of the LayerNorm, its saved statistics and its outputs
+    if (EPI == 9 && (p.N != RT || !p.lnx || !p.stats || !p.colsum || !p.C2 || !p.gamma)) return hipErrorInvalidValue;
     if (p.K % 128 == 0 && (!AMODE || p.Cin % 128 == 0)) {
         static const hipError_t attr2 = hipFuncSetAttribute((const void *)gemm_ring2_kernel<AMODE, EPI>,
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, RING * RTILE);

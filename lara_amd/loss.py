@@ -122,6 +122,7 @@ def _gauss_window(device, size=11, sigma=1.5):
         c = torch.arange(size, dtype=torch.float32) - size // 2
         g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
         _win_cache[key] = (g / g.sum()).to(device)
+        _win_cache[key]._lara_window = (size, sigma)
     return _win_cache[key]
 
 
@@ -130,9 +131,11 @@ _band_cache = {}
 
 def _band(win, n_in, n_out, device, dtype):
     """[n_in, n_out] matrix B with B[j + i, j] = win[i]: x @ B = the 'valid' correlation of x's last dimension with win."""
-    # keyed on the window TENSOR (no device value is read on a hit: `float(win[0])` here cost a host synchronisation per call,
-    # ~20 per step with MS-SSIM on both images); the entry keeps `win` alive, so its address cannot be reused by another window
-    key = (str(device), dtype, win.data_ptr(), win.numel(), n_in, n_out)
+    # keyed on what the window IS -- the (size, sigma) `_gauss_window` built it from -- not on its address: `ms_ssim` converts the
+    # window to the images' dtype, and for float64 (the finite-difference tests) that is a fresh tensor per call, i.e. a fresh entry
+    # per call that kept its window alive (ADVICE r5).  No device value is read on a hit either way (`float(win[0])` here cost a
+    # host synchronisation per call, ~20 per step with MS-SSIM on both images).  A window from elsewhere falls back to its address.
+    key = (str(device), dtype, getattr(win, "_lara_window", win.data_ptr()), win.numel(), n_in, n_out)
     if key not in _band_cache:
         k = win.numel()
         B = torch.zeros(n_in, n_out, dtype=dtype, device=device)
@@ -183,7 +186,10 @@ def ms_ssim(X, Y, data_range=1.0, win_size=11, win_sigma=1.5, weights=MS_SSIM_WE
         raise ValueError(f"ms_ssim: the smaller image side must exceed {(win_size - 1) * 2 ** 4} (four 2x downsamplings)")
     if X.dtype != torch.float64 or Y.dtype != torch.float64:       # (float64 stays float64: the tests' finite differences)
         X, Y = X.float(), Y.float()
-    win = _gauss_window(X.device, win_size, win_sigma).to(X.dtype)
+    base = _gauss_window(X.device, win_size, win_sigma)
+    win = base.to(X.dtype)
+    if win is not base:
+        win._lara_window = base._lara_window      # (the band cache's key: see `_band`)
     w = torch.tensor(weights, dtype=X.dtype, device=X.device)
     vals = []
     for i in range(len(weights)):

@@ -140,7 +140,7 @@ def explain_contrib_mismatches(ref, n_contrib_hip, W, tol_alpha=1e-3, tol_T=5e-3
             # every entry IN FRONT of the two answers whose alpha sits on the 1/255 threshold may have been blended by one side
             # only: each such flip moves all later T by a factor 1 - 1/255 (tol_T covers one; a 2 000-entry list of a 1024^2
             # frame can hold two)
-            flips_before = int((w["alpha"][:lo0] <= tol_alpha).sum())
+            flips_before = min(int((w["alpha"][:lo0] <= tol_alpha).sum()), 3)      # capped: at most two extra 1/255 allowances
             if ma <= tol_alpha:
                 out["by_alpha_flip"] += 1
                 out["worst_alpha_margin"] = max(out["worst_alpha_margin"], ma)
