@@ -101,7 +101,11 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
     unsigned short *xn = (unsigned short *)workspace;
     unsigned short *hid = xn + (size_t)M * 256;  // [M, 512]
     float2 *stats = (float2 *)((char *)workspace + (size_t)M * 256 * 2 * 4);
+#ifndef LARA_MLP_UNFUSED
+    char *zero_row = (char *)xn + (size_t)M * 512;      // row M of xn: written by the fused MLP kernel (the hidden tensor's old place)
+#else
     char *zero_row = (char *)workspace + (size_t)M * 256 * 2 * 4 + (size_t)M * 8;
+#endif
     // 2. MLP + norm3: ONE kernel per 128-row tile (mlp_fused.h); the hidden tensor never leaves the CU
 #ifndef LARA_MLP_UNFUSED
     (void)hid;
@@ -141,7 +145,9 @@ int lara_groupblock_forward(int32_t scenes, int32_t R, int32_t cond_dim, float *
     }
 #endif
     L2D_CHECK_LAUNCH();
+#ifdef LARA_MLP_UNFUSED
     if (hipMemsetAsync(zero_row, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+#endif      // (the fused kernel zero-fills the row behind xn's last: mlp_fused.h)
     {
         L2D_PROF("gb_conv3d", s);
         GemmP p{};

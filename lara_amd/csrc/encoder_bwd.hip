@@ -1301,7 +1301,9 @@ int block_forward_keep(int M, int cond_dim, const float *x_in, const unsigned sh
     hipLaunchKernelGGL(ln_cast_kernel, dim3(lnb), dim3(256), 0, s, x2, w->ln3_w, w->ln3_b, w->eps, xn3,
                        (float2 *)(save + L.stats), M);
 #endif
+#ifdef LARA_MLP_UNFUSED
     if (hipMemsetAsync(xn3 + (size_t)M * 256, 0, 512, s) != hipSuccess) return LARA2DGS_E_LAUNCH;
+#endif      // (the fused kernel zero-fills row M of xn3: mlp_fused.h)
     return hipGetLastError() == hipSuccess ? LARA2DGS_OK : LARA2DGS_E_LAUNCH;
 }
 

@@ -61,7 +61,8 @@ struct MlpP {
     float *x2;                        // [M, 256] fp32 out (may be x1: a workgroup reads its rows before it writes them)
     const float *ln2_w, *ln2_b, *b1, *b2, *ln3_w, *ln3_b;
     const unsigned short *w1, *w2;    // bf16 [512, 256], [256, 512]
-    unsigned short *xn3;              // [M, 256] bf16 out: norm3(x2)
+    unsigned short *xn3;              // [M + 1, 256] bf16 out: norm3(x2); row M is zero-filled (the convolution's padding voxels gather it:
+                                      // a 512-byte memset launch per layer until round 6)
     float2 *stats;                    // [M] out: (mean, rstd) of x2's rows
     unsigned short *xn2, *z, *h;      // TRAIN: bf16 [M, 256], [M, 512], [M, 512]
     float eps;
@@ -450,6 +451,7 @@ mlp_fused_kernel(const MlpP p) {
         }
         return;
     }
+    if (MODE < 2 && blockIdx.x == 0 && tid < 32) ((uint4 *)(p.xn3 + (size_t)M * 256))[tid] = make_uint4(0u, 0u, 0u, 0u);
     // ---- epilogue: x2 = acc2 + b2 + x1, norm3(x2).  Per wave 32 rows x 64 columns per trip through LDS (as ring_epilogue);
     //      a lane then holds four columns (c4) of rows 16 half + 4 q + lg; a row's 256 columns sit in the four waves of its wave row.
     // the residual rows this lane adds below (16 float4: the registers the fc1 operand held until the last chunk), requested in one
