@@ -206,7 +206,9 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
 int lara2dgs_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
                           const float *projmatrix, uint8_t *present, void *stream);
 
-/* Optional per-kernel timing (bench.py's roofline leg; not part of the reference surface).
+/* Optional per-kernel timing (bench.py's roofline leg; not part of the reference surface).  THE ONE process-wide switch of this
+ * library -- it changes no result, it is off by default, and tests/test_abi_cpu.py::test_library_exports_no_setters names it as the
+ * single exported symbol that reads like a switch.
  * When enabled (process-wide), every kernel the library launches is bracketed by HIP
  * events recorded on the launch stream.  lara2dgs_profile_collect synchronises those events,
  * writes up to `max_entries` records (kernel name -> `names`, NUL-separated, at most `names_len`
