@@ -71,6 +71,14 @@ typedef struct {
 
 int lara_take_rows(int32_t n, const int64_t *idx, int32_t count, const lara_rows_item *items, int32_t scatter, void *stream);
 
+/* The fine stage's volume-feature rows (network.py:509: every kept Gaussian reads the feature row of its voxel,
+ * `x.unsqueeze(1).expand(-1, K, -1)[mask.view(-1, K)]`).  `vox`: n ASCENDING int64 voxel indices on the device (mask indices / K:
+ * the rows of one voxel are consecutive).  width % 4 == 0; rows fp32, 16-byte aligned.
+ *   backward = 0:  dst[r][0..width) = src[vox[r]][0..width)                                       for r < n
+ *   backward = 1:  dst[v][0..width) = sum over the rows r with vox[r] == v of src[r][0..width)   (in row order, no atomics;
+ *                  voxels without a row are not written: the caller zero-fills dst) */
+int lara_voxel_rows(int32_t n, int32_t width, const int64_t *vox, const float *src, float *dst, int32_t backward, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,9 +244,51 @@ __global__ void __launch_bounds__(256) take_rows_kernel(const RowsP p) {
     else p.dst[k][near] = p.src[k][far];
 }
 
+// The fine stage's volume-feature rows (network.py:509: `x.unsqueeze(1).expand(-1, K, -1)[mask.view(-1, K)]`): row r of the subset
+// reads voxel vox[r]; vox is ascending (the indices of a mask, divided by K), so the rows of one voxel are a RUN of at most K.
+// Forward: a gather, one float4 per thread.  Backward: the first row of every run adds the run up (in row order: bit-reproducible,
+// no atomics) and writes the voxel's gradient; voxels without a row keep the caller's zeros.
+__global__ void __launch_bounds__(256) voxel_rows_fwd_kernel(const int n, const int c4, const long long *__restrict__ vox,
+                                                            const float4 *__restrict__ x, float4 *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * c4) return;
+    const int r = (int)(t / c4), c = (int)(t - (long long)r * c4);
+    out[t] = x[(size_t)vox[r] * c4 + c];
+}
+__global__ void __launch_bounds__(256) voxel_rows_bwd_kernel(const int n, const int c4, const long long *__restrict__ vox,
+                                                            const float4 *__restrict__ g, float4 *__restrict__ dx) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * c4) return;
+    const int r = (int)(t / c4), c = (int)(t - (long long)r * c4);
+    const long long v = vox[r];
+    if (r > 0 && vox[r - 1] == v) return;      // not the first row of its voxel's run
+    float4 a = g[t];
+    for (int q = r + 1; q < n && vox[q] == v; q++) {
+        const float4 b = g[(size_t)q * c4 + c];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    dx[(size_t)v * c4 + c] = a;
+}
+
 }  // namespace
 
 extern "C" {
+
+int lara_voxel_rows(int32_t n, int32_t width, const int64_t *vox, const float *src, float *dst, int32_t backward, void *stream) {
+    if (n < 0 || width <= 0 || (width & 3)) return LARA2DGS_E_INVALID;
+    if (n == 0) return LARA2DGS_OK;
+    if (!vox || !src || !dst) return LARA2DGS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int c4 = width / 4;
+    const unsigned blocks = (unsigned)(((long long)n * c4 + 255) / 256);
+    {
+        L2D_PROF(backward ? "voxel_rows_bwd" : "voxel_rows_fwd", s);
+        if (backward) hipLaunchKernelGGL(voxel_rows_bwd_kernel, dim3(blocks), dim3(256), 0, s, n, c4, (const long long *)vox, (const float4 *)src, (float4 *)dst);
+        else hipLaunchKernelGGL(voxel_rows_fwd_kernel, dim3(blocks), dim3(256), 0, s, n, c4, (const long long *)vox, (const float4 *)src, (float4 *)dst);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
 
 int64_t lara_point_feats_workspace_bytes(int32_t V, int32_t h, int32_t w) {
     if (V <= 0 || V > PF_MAX_VIEWS || h <= 0 || w <= 0 || (int64_t)V * h * w * 8 >= (1ll << 31)) return LARA2DGS_E_INVALID;  // 32-bit offsets into the stack

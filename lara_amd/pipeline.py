@@ -38,7 +38,7 @@ import torch
 from torch import nn
 
 from . import cameras, coarse
-from .fine import _tn_over_points, fold_fine_weights, forward_fine, sample_point_feats, take_rows, take_rows_multi
+from .fine import _tn_over_points, fold_fine_weights, forward_fine, sample_point_feats, take_rows, take_rows_multi, voxel_rows_scenes
 from .renderer import Renderer, _AssembleScenes, batch_map_buffers
 
 
@@ -282,6 +282,8 @@ class LaRaPipeline(nn.Module):
 
         sizes = [(int(batch["meta"]["tar_w"][i]), int(batch["meta"]["tar_h"][i])) for i in range(B)]
         cams_of = cameras.make_cameras_scenes(batch["tar_c2w"], sizes, scalars, device=batch["tar_c2w"].device)   # every MiniCam of the batch
+        # the views' background colours with their rows on 16-byte boundaries, once per batch (render_views would pad per call)
+        bg_rows = torch.nn.functional.pad(batch["bg_color"].float(), (0, 1))[..., :3]
         self._mark("start")
         g = make_gaussians()
         # the input images as [B, n_sel, 3, H, W] (network.py:437-438, :469): what the sampler reads as `img_ref`
@@ -303,18 +305,18 @@ class LaRaPipeline(nn.Module):
                 # made on the caller's stream, read (and saved for the backward) on the scene streams -- the batch's own tensors
                 # too: with a generator that frees the previous batch at the next iteration their safety would otherwise
                 # rest on the caller joining the streams before it drops the batch
-                hand_over((g, inps, cams_of, bufs, [batch[k] for k in ("tar_rays", "bg_color", "tar_w2c", "tar_ixt") if k in batch]), s)
+                hand_over((g, inps, cams_of, bufs, bg_rows, [batch[k] for k in ("tar_rays", "bg_color", "tar_w2c", "tar_ixt") if k in batch]), s)
 
         # per-scene tensors: one unbind per tensor (its backward is one stack; `x[i]` per use would cost a zero-filled
         # [B,P,C] buffer and an accumulation for every use)
-        sc = {k: g[k].unbind(0) for k in ("centers", "shs", "opacity", "scaling", "rotation", "vol")}
+        sc = {k: g[k].unbind(0) for k in ("centers", "shs", "opacity", "scaling", "rotation")}
         per_scene = [None] * B
         for i in range(B):                                                      # network.py:473-497
             s = sides[i % len(sides)]
             with on(s):
                 per_scene[i] = self.gs_render.render_views(
                     cams_of[i], batch["tar_rays"][i], sc["centers"][i], sc["shs"][i], sc["opacity"][i], sc["scaling"][i],
-                    sc["rotation"][i], dev, bg_colors=batch["bg_color"][i], concat=True,
+                    sc["rotation"][i], dev, bg_colors=bg_rows[i], concat=True,
                     into=None if bufs is None else {k: v[i] for k, v in bufs.items() if not k.endswith("_fine")})
                 self._mark("coarse views")
         if with_fine:
@@ -322,10 +324,14 @@ class LaRaPipeline(nn.Module):
             # (every scene's coarse views are already enqueued on the side streams)
             idx = [masks[i].nonzero().squeeze(-1) for i in range(B)]
             folded = fold_fine_weights(self.decoder)      # once per step, shared by the scenes (on the caller's stream)
+            # every scene's volume-feature rows (network.py:509) through ONE autograd node, on the caller's stream: its backward
+            # builds the gradient of `vol` in place instead of four dense per-scene gradients + their concatenation
+            vox = [torch.div(idx[i], self.K, rounding_mode="floor") for i in range(B)]
+            vol_rows = voxel_rows_scenes(g["vol"], vox)
             for s in sides:
                 if s is not None:
                     s.wait_stream(cur)
-                    hand_over((masks, folded), s)
+                    hand_over((masks, folded, vol_rows), s)
             for i in range(B):                                                  # network.py:502-525
                 s = sides[i % len(sides)]
                 hand_over(idx[i], s)
@@ -339,13 +345,12 @@ class LaRaPipeline(nn.Module):
                     # the sampler reads the first n_sel views of the side-by-side maps in place (network.py:499 stacks them)
                     pf = sample_point_feats(centers_f, batch["tar_w2c"][i, :n_sel], batch["tar_ixt"][i, :n_sel], inps[i],
                                             co["image"], co["acc_map"], co["depth"], row_views=V)
-                    vox = torch.div(idx[i], self.K, rounding_mode="floor")
-                    sh_res = forward_fine(self.decoder, _TakeVoxelRows.apply(sc["vol"][i], vox), torch.einsum("lcb->blc", pf), folded)
+                    sh_res = forward_fine(self.decoder, vol_rows[i], torch.einsum("lcb->blc", pf), folded)
                     shs_f = sh_res.view(-1, *g["shs"].shape[-2:]) + shs_sel
                     self._mark("sampler+forward_fine")
                     co.update(self.gs_render.render_views(
                         cams_of[i], batch["tar_rays"][i], centers_f, shs_f, opacity_f, scaling_f, rotation_f, dev,
-                        bg_colors=batch["bg_color"][i], prex="_fine", concat=True,
+                        bg_colors=bg_rows[i], prex="_fine", concat=True,
                         into=None if bufs is None else {k: v[i] for k, v in bufs.items() if k.endswith("_fine")}))
                     self._mark("fine views")
         outs = per_scene                                                        # network.py:527: already [H, V*W, C] per key

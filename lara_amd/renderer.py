@@ -330,8 +330,9 @@ class Renderer(nn.Module):
         written by one post-processing launch for all views -- into the caller's buffers when ``into`` ({key+prex: [H, n*W, C]})
         is given."""
         n = len(cams)
-        if torch.is_tensor(bg_colors) and bg_colors.dim() == 2:     # rows on 16-byte boundaries (see cameras.make_cameras)
-            bg_colors = torch.nn.functional.pad(bg_colors.float(), (0, 1))[:, :3]
+        if torch.is_tensor(bg_colors) and bg_colors.dim() == 2 and not (
+                bg_colors.dtype == torch.float32 and bg_colors.stride() == (4, 1) and bg_colors.data_ptr() % 16 == 0):
+            bg_colors = torch.nn.functional.pad(bg_colors.float(), (0, 1))[:, :3]     # rows on 16-byte boundaries (see cameras.make_cameras)
         bgs = [None] * n if bg_colors is None else list(bg_colors)
         settings = [self._settings(cam, device=device, bg=bg) for cam, bg in zip(cams, bgs)]
         opacity, scales, rotations = self._activated(opacity, scales, rotations)
