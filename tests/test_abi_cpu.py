@@ -178,3 +178,57 @@ def test_capacity_policy_follows_the_measured_pair_counts(monkeypatch):
     monkeypatch.setenv("LARA2DGS_DUP_FACTOR", "16")
     assert rz.binning_capacity(P) == 3 << 22
     rz.reset_capacity_history()
+
+
+def test_a_forward_that_does_not_fit_is_repeated_before_the_operator_returns(monkeypatch):
+    """Host logic of `_run_forward` (no GPU: the enqueue, the pinned words and the event are stand-ins): the forward goes out at
+    the capacity the class's history asks for; the counts the scan kernel would have stored are read; an overflow repeats the SAME
+    forward at twice the count it reported -- before anything is returned -- and every count lands in the history."""
+    import numpy as np
+    import torch
+    from lara_amd import rasterizer as rz
+    monkeypatch.delenv("LARA2DGS_DUP_FACTOR", raising=False)
+    rz.reset_capacity_history()
+
+    class FakeCounts:
+        def __init__(self, n):
+            self.np = np.zeros((max(n, 16), 4), dtype=np.uint32)
+            self.ptr = 0xABC0
+
+    class FakeEvent:
+        def record(self): pass
+        def query(self): return True
+
+    fake = FakeCounts(8)
+    monkeypatch.setattr(rz, "_counts", lambda n: fake)
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    bucket = (0, 557056, 512, 512)
+    D_per_view = [1_500_000, 7_000_000, 1_400_000]        # view 1 outgrows the 3 Mi pairs a new class starts from
+    calls = []
+
+    def enqueue(cap, counts_ptr):
+        assert counts_ptr == fake.ptr and not fake.np[:3, 3].any(), "the ready words are cleared before every launch"
+        calls.append(cap)
+        for i, D in enumerate(D_per_view):                 # what tile_scan stores
+            fake.np[i] = (D, int(D > cap), 4000, 1)
+        return "state%d" % len(calls), (lambda: None), ("sb", "qb")
+
+    reruns = rz._reruns
+    state, cap, extra, D = rz._run_forward(bucket, 3, enqueue)
+    assert calls == [3 << 20, 1 << 24] and cap == 1 << 24 and state == "state2" and extra == ("sb", "qb") and D == 7_000_000      # 2 x 7 M on the grid
+    assert rz._reruns == reruns + 1 and list(rz._hist[bucket]) == [7_000_000, 7_000_000]
+    # the next call of the class starts where this one ended: no repeat
+    calls.clear()
+    state, cap, _, _ = rz._run_forward(bucket, 3, enqueue)
+    assert calls == [1 << 24] and rz._reruns == reruns + 1
+    # beyond the 32-bit pair index there is nothing to repeat with: the one way a call can still fail, and it says so
+    D_per_view[1] = 0xFFFFFFF0
+
+    def enqueue_huge(cap, counts_ptr):
+        for i, D in enumerate(D_per_view):
+            fake.np[i] = (D, 1, 4000, 1)
+        return "s", (lambda: None), None
+    monkeypatch.setattr(rz, "_next_capacity", lambda b: 0xFFFFFFFF)
+    with pytest.raises(RuntimeError, match="32-bit pair index"):
+        rz._run_forward(bucket, 3, enqueue_huge)
+    rz.reset_capacity_history()

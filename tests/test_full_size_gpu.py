@@ -44,6 +44,17 @@ def test_multi_view_launch_at_benchmark_size_equals_the_per_view_operator_and_th
     ((color * dc).sum() + (allmap * da).sum()).backward()
     torch.cuda.synchronize()
 
+    # the same scene through the FORWARD-ONLY instantiation of every kernel (what evaluation.py / the mesh extractor get under
+    # no_grad): the multi-view call and one per-view call, bit-identical to the training-mode forward at full size
+    with torch.no_grad():
+        c_fo, r_fo, a_fo = rasterize_gaussians_views(settings, inp["means3D"], None, inp["opacities"], shs=inp["shs"],
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+        c1, r1, a1 = GaussianRasterizer(settings[6])(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
+                                                     scales=inp["scales"], rotations=inp["rotations"])
+    assert c_fo.grad_fn is None and torch.equal(c_fo, color.detach()) and torch.equal(a_fo, allmap.detach()) and torch.equal(r_fo, radii)
+    assert torch.equal(c1, color[6].detach()) and torch.equal(a1, allmap[6].detach()) and torch.equal(r1, radii[6])
+    del c_fo, r_fo, a_fo, c1, r1, a1
+
     want = None
     for i, rs in enumerate(settings):
         li = leaves()

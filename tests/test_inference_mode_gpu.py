@@ -68,6 +68,8 @@ def test_fifty_no_grad_multi_view_calls_leave_the_allocator_where_it_was(hip_lib
     forward-only call owns nothing once it has returned."""
     from lara_amd import cameras, synthetic, rasterize_gaussians_views, rasterizer
     from lara_amd import GaussianRasterizationSettings
+    if rasterizer._poison_mode():
+        pytest.skip("poison mode keeps every buffer it hands out until the guards are checked")
     sc = synthetic.make_scene(grid=32, K=2, seed=3, device=DEV)
     with torch.no_grad():
         opa, scl, rot = torch.sigmoid(sc["opacity"]), torch.exp(sc["scales"] + math.log(2.0)), F.normalize(sc["rotations"])
@@ -106,6 +108,8 @@ def test_the_pair_count_history_is_a_window(hip_lib):
     """A size class that once saw a large frame gives the memory back after `_HISTORY` ordinary calls (round 5 kept the
     high-water mark for the life of the process: 16 Mi-pair buffers after one `step_with_reference_lr`)."""
     from lara_amd import rasterizer
+    if rasterizer._poison_mode():
+        pytest.skip("poison mode keeps every buffer it hands out until the guards are checked (256 calls at the spike's capacity)")
     act, cams = small_scene(grid=16, size=128, seed=0)
     rs = raster_settings(cams[0], (1, 1, 1), device=DEV)
     t = _inputs(act, False)
