@@ -182,6 +182,33 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
                            float *out_color, float *out_allmap, int32_t *out_radii, void *state,
                            int64_t state_stride, void *scratch, int64_t scratch_stride, void *stream);
 
+/* The same call for a SUBSET of the surfels an earlier multi-view call has rendered, from the same cameras at the same image size and
+ * with the same geometry (means, scales, rotations, opacities: the subset's rows are copies of the earlier call's) -- LaRa's fine
+ * pass (lightning/network.py:502-525: `x[mask]` of the coarse pass's Gaussians with refined SH coefficients).  The subset's
+ * per-tile lists are then the earlier call's lists with the dropped surfels taken out and the ids renumbered -- the sort key is
+ * (depth bits, id) and the subset's numbering is monotone -- so this entry point FILTERS those lists (stable compaction per tile)
+ * instead of scattering and sorting again.  Everything it leaves in `state` -- records, point_list, ranges, the pair map -- equals
+ * lara2dgs_forward_views' on the same inputs bit for bit; so do the images.
+ *   coarse_state / coarse_state_stride / coarse_capacity / coarse_P / coarse_forward_only: the earlier call's state buffer (still
+ *       alive: a training step keeps it for the backward) and the arguments it was laid out with; a subset call that keeps state for a
+ *       backward (views[0].forward_only == 0) needs an earlier call that did too (the pair map is derived from its pair map);
+ *   inv: int32 [coarse_P] on the device: the subset's row of every earlier surfel, -1 for the dropped ones; rows ascending.
+ * views[i] must be the earlier call's view i (same cameras); P = the subset's surfel count. */
+typedef struct lara2dgs_subset {
+    const void *coarse_state;
+    int64_t coarse_state_stride;
+    int64_t coarse_capacity;
+    int32_t coarse_P;
+    int32_t coarse_forward_only;
+    const int32_t *inv;
+} lara2dgs_subset;
+int lara2dgs_forward_views_subset(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+                                  const float *shs, const float *colors_precomp, const float *opacities,
+                                  const float *scales, const float *rotations, const float *transmat_precomp,
+                                  float *out_color, float *out_allmap, int32_t *out_radii, void *state,
+                                  int64_t state_stride, void *scratch, int64_t scratch_stride,
+                                  const lara2dgs_subset *subset, void *stream);
+
 /* Offsets (in floats) of the gradient arrays inside one flat gradient buffer; -1 = absent. */
 typedef struct lara2dgs_grad_layout {
     int64_t means3D, means2D, shs, colors, opacities, scales, rotations, transmat, total;

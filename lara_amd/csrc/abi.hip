@@ -326,12 +326,21 @@ int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int3
 // L2D_MAX_VIEWS): the surfels' inputs come from HBM once for the n cameras, and one view's tail of long tile lists is filled by
 // the next view's workgroups.  (Rounds 2-4 also kept a per-view path dealt to side streams -- "lanes" -- with two process-wide
 // setters; it measured slower in every configuration once the kernels were batched and is gone: the library keeps no settings.)
-int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+static int forward_views_impl(int32_t n_views, const lara2dgs_view *views, const float *means3D,
                            const float *shs, const float *colors_precomp, const float *opacities,
                            const float *scales, const float *rotations, const float *transmat_precomp,
                            float *out_color, float *out_allmap, int32_t *out_radii, void *state,
-                           int64_t state_stride, void *scratch, int64_t scratch_stride, void *stream) {
+                           int64_t state_stride, void *scratch, int64_t scratch_stride, void *stream,
+                           const lara2dgs_subset *subset) {
     if (n_views <= 0 || !views || !state || !scratch) return LARA2DGS_E_INVALID;
+    if (subset) {
+        // the subset call's lists come out of the coarse call's: same cameras and image, a coarse state that holds what is read
+        if (!subset->coarse_state || !subset->inv || subset->coarse_P < views[0].P || subset->coarse_capacity < 0 ||
+            subset->coarse_capacity > 0xffffffffll || subset->coarse_state_stride % 256) return LARA2DGS_E_INVALID;
+        if (!views[0].forward_only && subset->coarse_forward_only) return LARA2DGS_E_INVALID;   // (the pair map is derived from the coarse one)
+        if (subset->coarse_state_stride < lara2dgs_state_bytes(subset->coarse_P, views[0].image_height, views[0].image_width,
+                                                                subset->coarse_capacity, subset->coarse_forward_only)) return LARA2DGS_E_INVALID;
+    }
     if (!views_agree(n_views, views)) return LARA2DGS_E_INVALID;
     const lara2dgs_view &v0 = views[0];
     if (!strides_ok(v0, state_stride, scratch_stride)) return LARA2DGS_E_INVALID;
@@ -370,12 +379,38 @@ int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const fl
         for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
         rc = launch_preprocess_fwd_views(vd[i0], vb.n, &vd[i0], means3D, shs, colors_precomp, opacities, scales, rotations,
                                          transmat_precomp, &st[i0], &sc[i0], &rad[i0], caller);
-        if (rc == LARA2DGS_OK) rc = launch_binning(vd[i0], st[i0], sc[i0], caller, &vb);
+        if (rc == LARA2DGS_OK && !subset) rc = launch_binning(vd[i0], st[i0], sc[i0], caller, &vb);
+        if (rc == LARA2DGS_OK && subset) {
+            ViewDev cv = vd[i0];      // the coarse call's view i0: its surfel count, capacity and mode decide its state's layout
+            cv.P = subset->coarse_P; cv.cap = (unsigned)subset->coarse_capacity; cv.fwd_only = subset->coarse_forward_only != 0;
+            const StateView cst = carve_state(cv, (char *)const_cast<void *>(subset->coarse_state) + (int64_t)i0 * subset->coarse_state_stride);
+            rc = launch_binning_subset(vd[i0], st[i0], sc[i0], caller, &vb, cst, subset->coarse_state_stride, subset->inv);
+        }
         if (rc == LARA2DGS_OK)
             rc = launch_composite_fwd(vd[i0], st[i0], sc[i0], out_color + (int64_t)i0 * 3 * HW, out_allmap + (int64_t)i0 * 7 * HW,
                                       caller, &vb);
     }
     return rc;
+}
+
+int lara2dgs_forward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+                           const float *shs, const float *colors_precomp, const float *opacities,
+                           const float *scales, const float *rotations, const float *transmat_precomp,
+                           float *out_color, float *out_allmap, int32_t *out_radii, void *state,
+                           int64_t state_stride, void *scratch, int64_t scratch_stride, void *stream) {
+    return forward_views_impl(n_views, views, means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp, out_color,
+                              out_allmap, out_radii, state, state_stride, scratch, scratch_stride, stream, nullptr);
+}
+
+int lara2dgs_forward_views_subset(int32_t n_views, const lara2dgs_view *views, const float *means3D,
+                                  const float *shs, const float *colors_precomp, const float *opacities,
+                                  const float *scales, const float *rotations, const float *transmat_precomp,
+                                  float *out_color, float *out_allmap, int32_t *out_radii, void *state,
+                                  int64_t state_stride, void *scratch, int64_t scratch_stride,
+                                  const lara2dgs_subset *subset, void *stream) {
+    if (!subset) return LARA2DGS_E_INVALID;
+    return forward_views_impl(n_views, views, means3D, shs, colors_precomp, opacities, scales, rotations, transmat_precomp, out_color,
+                              out_allmap, out_radii, state, state_stride, scratch, scratch_stride, stream, subset);
 }
 
 int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const float *means3D,

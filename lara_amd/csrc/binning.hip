@@ -699,7 +699,101 @@ tile_sort_kernel(ViewDev v, const uint2 *__restrict__ ranges, const uint32_t *__
     }
 }
 
+// ---- the fine pass's lists as a FILTER of the coarse pass's (lara2dgs_forward_views_subset) ------------------------------------
+// LaRa's fine pass (network.py:502-525) renders a subset of the surfels the coarse pass has just rendered, from the same cameras,
+// with the same geometry -- only the colours differ.  Its per-tile lists are therefore the coarse lists with the dropped surfels
+// taken out and the ids renumbered: the sort key is (depth bits, id), the subset's numbering is monotone in the coarse one, so a
+// STABLE filter of a coarse list IS the fine list, tie order included.  The subset's preprocess still runs (its colours, and with
+// them the records, are its own; its per-tile counts give tile_scan the ranges), scatter + sort do not: a per-surfel pass writes the
+// surfel-major pair numbering scatter would have written, a per-tile pass compacts.
+__global__ void __launch_bounds__(256)
+pair_base_kernel(ViewDev v, const uint4 *__restrict__ rect, const uint32_t *__restrict__ block_base, uint32_t *__restrict__ pair_base,
+                 const long long sst, const long long qst) {
+    rect = l2d_view_ptr(rect, qst); block_base = l2d_view_ptr(block_base, qst); pair_base = l2d_view_ptr(pair_base, sst);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= v.P) return;
+    const uint4 r = rect[idx];
+    const uint32_t pb = block_base[blockIdx.x] + r.w;
+    pair_base[idx] = pb;
+    if (idx == v.P - 1) {
+        const int rx0 = r.x & 0xffff, ry0 = r.x >> 16, rx1 = r.y & 0xffff, ry1 = r.y >> 16;
+        pair_base[v.P] = pb + (uint32_t)(rx1 - rx0) * (uint32_t)(ry1 - ry0);
+    }
+}
+
+// one workgroup per (tile, view): the coarse list in order, kept entries to the fine list at start + rank (ballot ranks inside a wave,
+// wave totals through LDS in wave order: the compaction is stable); a kept entry's pair index in the fine pass's surfel-major
+// numbering = its surfel's first pair there + the tile's offset inside the surfel's rectangle, which the coarse pair map knows
+__global__ void __launch_bounds__(256)
+subset_compact_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list,
+                      const uint32_t *__restrict__ pair_base, uint32_t *__restrict__ pair_pos, const long long sst,
+                      const uint2 *__restrict__ c_ranges, const uint32_t *__restrict__ c_point_list, const uint32_t *__restrict__ c_pair_base,
+                      const uint32_t *__restrict__ c_pair_pos, const long long csst, const int32_t *__restrict__ inv) {
+    header = l2d_view_ptr(header, sst); ranges = l2d_view_ptr(ranges, sst); point_list = l2d_view_ptr(point_list, sst);
+    pair_base = l2d_view_ptr(pair_base, sst); pair_pos = l2d_view_ptr(pair_pos, sst);
+    c_ranges = l2d_view_ptr(c_ranges, csst); c_point_list = l2d_view_ptr(c_point_list, csst);
+    c_pair_base = l2d_view_ptr(c_pair_base, csst); c_pair_pos = l2d_view_ptr(c_pair_pos, csst);
+    __shared__ uint32_t wtot[2][4];
+    if (header[1]) return;      // capacity overflow: the outputs get poisoned instead
+    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 cr = c_ranges[tile];
+    const uint32_t n = cr.y - cr.x;
+    uint32_t out = ranges[tile].x;
+    // (a trip's dependent chain -- id, its row in the subset, the two pair numbers -- is started one trip ahead: the kernel is a
+    // latency chain per tile, 6 trips of 256 entries at LaRa's list lengths; one barrier per trip, the wave totals double-buffered)
+    uint32_t id_n = tid < n ? c_point_list[cr.x + tid] : 0u;
+    int fid_n = tid < n ? inv[id_n] : -1;
+    int buf = 0;
+    for (uint32_t base = 0; base < n; base += 256, buf ^= 1) {      // (uniform trip count: the ballots need whole waves)
+        const uint32_t i = base + tid, id = id_n;
+        const int fid = fid_n;
+        uint32_t off = 0, pbf = 0;
+        if (fid >= 0 && !v.fwd_only) { off = c_pair_pos[cr.x + i] - c_pair_base[id]; pbf = pair_base[fid]; }
+        if (base + 256 < n) {
+            id_n = i + 256 < n ? c_point_list[cr.x + i + 256] : 0u;
+            fid_n = i + 256 < n ? inv[id_n] : -1;
+        }
+        const unsigned long long kept = __ballot(fid >= 0);
+        if (lane == 0) wtot[buf][wave] = (uint32_t)__builtin_popcountll(kept);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { before += w < wave ? wtot[buf][w] : 0u; all += wtot[buf][w]; }
+        if (fid >= 0) {
+            const uint32_t pos = out + before + (uint32_t)__builtin_popcountll(kept & ((1ull << lane) - 1ull));
+            point_list[pos] = (uint32_t)fid;
+            if (!v.fwd_only) pair_pos[pos] = pbf + off;
+        }
+        out += all;
+    }
+}
+
 }  // namespace
+
+int launch_binning_subset(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb, StateView cst,
+                          long long coarse_stride, const int32_t *inv) {
+    const unsigned nz = vb ? (unsigned)vb->n : 1u;
+    const long long sst = vb ? vb->state_stride : 0, qst = vb ? vb->scratch_stride : 0;
+    {
+        L2D_PROF("tile_scan", s);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(v.P > 0 ? 2 : 1, 1, nz), dim3(1024), 0, s, v, sc.tile_count, sc.sub_start,
+                           st.ranges, st.header, st.tile_order, sc.block_tot, st.seg_base, st.seg_cnt, st.bwd_order,
+                           st.bwd_items, sc.sort_parts, sc.sort_items, sst, qst);
+    }
+    L2D_CHECK_LAUNCH();
+    if (v.P == 0) return LARA2DGS_OK;
+    if (!v.fwd_only) {
+        L2D_PROF("subset_pair_base", s);
+        hipLaunchKernelGGL(pair_base_kernel, dim3((v.P + 255) / 256, 1, nz), dim3(256), 0, s, v, sc.rect, sc.block_tot, st.pair_base, sst, qst);
+    }
+    {
+        L2D_PROF("subset_compact", s);
+        hipLaunchKernelGGL(subset_compact_kernel, dim3(v.tiles, 1, nz), dim3(256), 0, s, v, st.header, st.ranges, st.point_list,
+                           st.pair_base, st.pair_pos, sst, cst.ranges, cst.point_list, cst.pair_base, cst.pair_pos, coarse_stride, inv);
+    }
+    L2D_CHECK_LAUNCH();
+    return LARA2DGS_OK;
+}
 
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb) {
     // vb != nullptr: the binning of ALL views of a multi-view call in three launches (blockIdx.z = view; st / sc are view 0's)

@@ -151,6 +151,9 @@ int launch_preprocess_fwd_views(const ViewDev &v, int n, const ViewDev *views, c
                                 const float *rotations, const float *transmat_precomp, const StateView *st,
                                 const ScratchView *sc, int32_t *const *radii, hipStream_t s);
 int launch_binning(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb = nullptr);
+// the lists of a subset of the surfels a coarse call has binned, by filtering its lists (binning.hip); cst = view 0 of the coarse state
+int launch_binning_subset(const ViewDev &v, StateView st, ScratchView sc, hipStream_t s, const ViewBatch *vb, StateView cst,
+                          long long coarse_stride, const int32_t *inv);
 int launch_composite_fwd(const ViewDev &v, StateView st, ScratchView sc, float *out_color, float *out_allmap,
                          hipStream_t s, const ViewBatch *vb = nullptr);
 // re-orders the backward's work items by what they cost the forward AND zero-fills [zero_base, zero_base + zero_bytes) (per view at

@@ -198,6 +198,7 @@ class LaRaPipeline(nn.Module):
         self._streams = []
         self.fused_coarse = True          # False: `decode_coarse` (torch operators) instead of lara_amd.coarse
         self.fine_mask = "reference"      # "reference": _check_mask as the reference applies it; "plain": opacity > 0.005 only
+        self.fine_reuses_coarse_lists = True    # the fine pass's per-tile lists as a filter of the coarse pass's (rasterize_gaussians_views: subset_of)
         self.stage_events = None          # set to a list to collect (stage, start event, end event) per call
         self.opacity_bias = None          # benchmarks only: a [1,P,1] logit bias (see `trained_like_opacity_bias`)
 
@@ -311,13 +312,15 @@ class LaRaPipeline(nn.Module):
         # [B,P,C] buffer and an accumulation for every use)
         sc = {k: g[k].unbind(0) for k in ("centers", "shs", "opacity", "scaling", "rotation")}
         per_scene = [None] * B
+        coarse_raster = [[] for _ in range(B)]       # the coarse calls' own outputs: the fine calls filter their lists (`subset_of`)
         for i in range(B):                                                      # network.py:473-497
             s = sides[i % len(sides)]
             with on(s):
                 per_scene[i] = self.gs_render.render_views(
                     cams_of[i], batch["tar_rays"][i], sc["centers"][i], sc["shs"][i], sc["opacity"][i], sc["scaling"][i],
                     sc["rotation"][i], dev, bg_colors=bg_rows[i], concat=True,
-                    into=None if bufs is None else {k: v[i] for k, v in bufs.items() if not k.endswith("_fine")})
+                    into=None if bufs is None else {k: v[i] for k, v in bufs.items() if not k.endswith("_fine")},
+                    raster_out=coarse_raster[i])
                 self._mark("coarse views")
         if with_fine:
             # the sizes of the masked subsets: host reads on the stream that holds only the encoder + decoder + masks
@@ -351,7 +354,8 @@ class LaRaPipeline(nn.Module):
                     co.update(self.gs_render.render_views(
                         cams_of[i], batch["tar_rays"][i], centers_f, shs_f, opacity_f, scaling_f, rotation_f, dev,
                         bg_colors=bg_rows[i], prex="_fine", concat=True,
-                        into=None if bufs is None else {k: v[i] for k, v in bufs.items() if k.endswith("_fine")}))
+                        into=None if bufs is None else {k: v[i] for k, v in bufs.items() if k.endswith("_fine")},
+                        subset_of=(coarse_raster[i][0][0], idx[i]) if self.fine_reuses_coarse_lists else None))
                     self._mark("fine views")
         outs = per_scene                                                        # network.py:527: already [H, V*W, C] per key
         for i, s in enumerate(sides):

@@ -50,6 +50,11 @@ class _View(ctypes.Structure):
     ]
 
 
+class _Subset(ctypes.Structure):        # struct lara2dgs_subset
+    _fields_ = [("coarse_state", ctypes.c_void_p), ("coarse_state_stride", ctypes.c_int64), ("coarse_capacity", ctypes.c_int64),
+                ("coarse_P", ctypes.c_int32), ("coarse_forward_only", ctypes.c_int32), ("inv", ctypes.c_void_p)]
+
+
 class GradLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "transmat", "total")]
@@ -92,6 +97,8 @@ def load_library():
     lib.lara2dgs_backward.argtypes = [ctypes.POINTER(_View)] + [vp] * 20
     lib.lara2dgs_forward_views.restype = ctypes.c_int
     lib.lara2dgs_forward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 11 + [i64, vp, i64, vp]
+    lib.lara2dgs_forward_views_subset.restype = ctypes.c_int
+    lib.lara2dgs_forward_views_subset.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 11 + [i64, vp, i64, ctypes.POINTER(_Subset), vp]
     lib.lara2dgs_backward_views.restype = ctypes.c_int
     lib.lara2dgs_backward_views.argtypes = [i32, ctypes.POINTER(_View)] + [vp] * 10 + [i64, vp, i64, vp, vp]
     lib.lara2dgs_get_grad_layout.restype = ctypes.c_int
@@ -557,8 +564,12 @@ def _views_array(settings, P, M, cap, device, prefiltered_bits=None):
     return arr, keep
 
 
-def _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, forward_only=False):
-    """The n views of a scene in one library call (see `_forward_impl`); `state` holds the n per-view states at stride `sb`."""
+def _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, forward_only=False,
+                        subset=None):
+    """The n views of a scene in one library call (see `_forward_impl`); `state` holds the n per-view states at stride `sb`.
+    `subset` = (state, state stride, capacity, surfel count of an earlier call with the same cameras, ascending row indices of this
+    call's surfels in that call's): the lists are filtered out of the earlier call's instead of scattered and sorted again
+    (`lara2dgs_forward_views_subset`)."""
     lib = load_library()
     rs0 = settings[0]
     n = len(settings)
@@ -576,6 +587,14 @@ def _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotation
         color = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
         allmap = torch.empty((n, 7, H, W), dtype=torch.float32, device=device)
         radii = torch.empty((n, P), dtype=torch.int32, device=device)
+        sub = None
+        if subset is not None and P > 0:
+            c_state, c_sb, c_cap, c_P, idx = subset
+            if idx.numel() != P or idx.device != device or c_P < P:
+                raise RuntimeError("lara_amd: `subset_of` needs one index per surfel of this call, on its device")
+            inv = torch.full((c_P,), -1, dtype=torch.int32, device=device)      # the subset's row of every earlier surfel
+            inv[idx] = torch.arange(P, dtype=torch.int32, device=device)
+            sub = _Subset(c_state.data_ptr(), c_sb, c_cap, c_P, 0, inv.data_ptr())
 
         def enqueue(cap, counts_ptr):
             for i in range(n):
@@ -586,10 +605,12 @@ def _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotation
             qb = (lib.lara2dgs_scratch_bytes(_sizing_P(P), H, W, cap, fo) + 255) // 256 * 256
             state = _alloc_bytes(n * sb, device)
             scratch = _get_scratch(device, n * qb)      # a scratch buffer per view: every kernel is one launch over the cameras
-            rc = lib.lara2dgs_forward_views(n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c),
-                                            _ptr(sc_c), _ptr(rot_c), _ptr(tm_c), color.data_ptr(), allmap.data_ptr(),
-                                            radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb,
-                                            torch.cuda.current_stream(device).cuda_stream)
+            args = (n, views, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(opa_c), _ptr(sc_c), _ptr(rot_c), _ptr(tm_c),
+                    color.data_ptr(), allmap.data_ptr(), radii.data_ptr(), state.data_ptr(), sb, scratch.data_ptr(), qb)
+            if sub is None:
+                rc = lib.lara2dgs_forward_views(*args, torch.cuda.current_stream(device).cuda_stream)
+            else:
+                rc = lib.lara2dgs_forward_views_subset(*args, ctypes.byref(sub), torch.cuda.current_stream(device).cuda_stream)
             _check(rc, "lara2dgs_forward_views")
             return state, (lambda: state.view(n, sb)[:, :64].contiguous().view(torch.int32)), (sb, qb)
 
@@ -604,10 +625,10 @@ class _RasterizeViews(torch.autograd.Function):
     launch over the cameras and the gradient comes back already summed over the views."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, subset=None):
         settings = tuple(settings)
         rs0 = settings[0]
-        r = _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings)
+        r = _forward_views_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings, subset=subset)
         color, radii, allmap, M, keep = r["color"], r["radii"], r["allmap"], r["M"], r["keep"]
         means3D_c, sh_c, col_c, sc_c, rot_c, tm_c = r["inputs"]
         ctx.state, ctx.cap, ctx.strides, ctx.D = r["state"], r["cap"], r["strides"], r["D"]
@@ -674,14 +695,20 @@ class _RasterizeViews(torch.autograd.Function):
         return (sec(G.means3D, 3, (P, 3)), sec(G.means2D, 3, (P, 3)) if ctx.needs_input_grad[1] else None, g_sh,
                 sec(G.colors, 3, (P, 3)) if has_col else None, g_opac,
                 sec(G.scales, 2, (P, 2)) if has_sr else None, sec(G.rotations, 4, (P, 4)) if has_sr else None,
-                sec(G.transmat, 9, (P, 9)) if has_tm else None, None)
+                sec(G.transmat, 9, (P, 9)) if has_tm else None, None, None)
 
 
 def rasterize_gaussians_views(settings, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
-                              rotations=None, cov3D_precomp=None):
+                              rotations=None, cov3D_precomp=None, subset_of=None):
     """All views of a scene in one call: ``settings`` is a sequence of GaussianRasterizationSettings (one per camera,
     same image size / sh_degree); returns ``(color [n,3,H,W], radii [n,P], allmap [n,7,H,W])``.  Same results per view
-    as ``GaussianRasterizer(settings[i])(...)``; the gradients are the sums over the views."""
+    as ``GaussianRasterizer(settings[i])(...)``; the gradients are the sums over the views.
+
+    ``subset_of = (color, idx)`` (opt-in; LaRa's fine pass, network.py:502-525): this call's surfels are rows ``idx`` (ascending,
+    int64) of the surfels an EARLIER grad-mode call of this function rendered from the same cameras -- ``color`` is that call's
+    colour output -- with the same means, scales, rotations and opacities.  The per-tile lists are then filtered out of the earlier
+    call's instead of scattered and sorted again; every output is the same bit for bit.  Ignored (the full path runs) when the
+    earlier call kept no state (``no_grad``) or this one keeps none."""
     if len(settings) == 0:
         raise RuntimeError("lara_amd: rasterize_gaussians_views needs at least one view")
     if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
@@ -695,8 +722,19 @@ def rasterize_gaussians_views(settings, means3D, means2D, opacities, shs=None, c
         # inference (evaluation.py:129 / tools/meshExtractor.py:85 run under no_grad): a forward-only call, no autograd node
         r = _forward_views_impl(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, tuple(settings), True)
         return r["color"], r["radii"], r["allmap"]
+    subset = None
+    if subset_of is not None:
+        coarse_color, idx = subset_of
+        node = getattr(coarse_color, "grad_fn", None)
+        if node is not None and hasattr(node, "strides") and hasattr(node, "state") and len(node.settings) == len(settings):
+            for a, b in zip(node.settings, settings):      # the same cameras and image (the background may differ: it never reaches the lists)
+                if (a.image_height, a.image_width, a.tanfovx, a.tanfovy, float(a.scale_modifier)) != \
+                        (b.image_height, b.image_width, b.tanfovx, b.tanfovy, float(b.scale_modifier)) or \
+                        a.viewmatrix.data_ptr() != b.viewmatrix.data_ptr() or a.projmatrix.data_ptr() != b.projmatrix.data_ptr():
+                    raise RuntimeError("lara_amd: `subset_of` names a call with other cameras")
+            subset = (node.state, node.strides[0], node.cap, node.saved_tensors[0].shape[0], idx.contiguous())
     return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                 tuple(settings))
+                                 tuple(settings), subset)
 
 
 def _as_f32(t):
@@ -784,6 +822,8 @@ def state_views(state: torch.Tensor, P: int, H: int, W: int, cap: int, forward_o
         return common
     return dict(
         common,
+        pair_base=sec(L.pair_base, (P + 1) * 4, torch.int32, (P + 1,)),
+        pair_pos=sec(L.pair_pos, cap * 4, torch.int32, (cap,)),
         final_T=sec(L.final_T, 10 * H * W * 4, torch.float32, (10, H, W)),
         n_contrib=sec(L.n_contrib, 2 * H * W * 4, torch.int32, (2, H, W)),
         seg_base=sec(L.seg_base, (tiles + 1) * 4, torch.int32, (tiles + 1,)),

@@ -319,7 +319,7 @@ class Renderer(nn.Module):
                 f"depth_normal{prex}": dnorm, f"rend_dist{prex}": rdist}
 
     def render_views(self, cams, rays, centers, shs, opacity, scales, rotations, device, bg_colors=None,
-                     cov3D_precomp=None, prex='', depth_ratio=0.0, concat=False, into=None):
+                     cov3D_precomp=None, prex='', depth_ratio=0.0, concat=False, into=None, raster_out=None, subset_of=None):
         """All views of a scene in ONE rasteriser call (one autograd node, per-camera state carved from one
         allocation, gradients summed over the views inside the library): what the reference's inner loop
         (lightning/network.py:486-497 coarse, :516-525 fine) does with one ``render_img`` per view.  ``cams`` is a
@@ -328,7 +328,9 @@ class Renderer(nn.Module):
         list of per-view dictionaries ``render_img`` would have returned; with ``concat=True`` ONE dictionary whose maps
         are the views' maps side by side, [H, n*W, C] -- what network.py:527 builds with ``torch.cat(..., dim=1)`` --
         written by one post-processing launch for all views -- into the caller's buffers when ``into`` ({key+prex: [H, n*W, C]})
-        is given."""
+        is given.  ``raster_out`` (a list) receives the rasteriser's own (color, radii, allmap); ``subset_of = (color, idx)`` names
+        an earlier call's colour output and this call's rows in it (`rasterize_gaussians_views`: the fine pass filters the coarse
+        pass's lists instead of binning again)."""
         n = len(cams)
         if torch.is_tensor(bg_colors) and bg_colors.dim() == 2 and not (
                 bg_colors.dtype == torch.float32 and bg_colors.stride() == (4, 1) and bg_colors.data_ptr() % 16 == 0):
@@ -337,7 +339,10 @@ class Renderer(nn.Module):
         settings = [self._settings(cam, device=device, bg=bg) for cam, bg in zip(cams, bgs)]
         opacity, scales, rotations = self._activated(opacity, scales, rotations)
         color, radii, allmap = rasterize_gaussians_views(settings, centers, self._zero_means2D(centers), opacity, shs=shs,
-                                                         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+                                                         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                                                         subset_of=subset_of)
+        if raster_out is not None:
+            raster_out.append((color, radii, allmap))
         if concat and rays is not None:
             rots = torch.stack([cam.world_view_transform[:3, :3] for cam in cams]).transpose(1, 2)       # renderer_2dgs.py:231
             rays_t = rays if torch.is_tensor(rays) else torch.stack(list(rays))

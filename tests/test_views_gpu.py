@@ -301,3 +301,75 @@ def test_state_and_scratch_contents_do_not_matter(monkeypatch):
     assert rasterizer.check_poison_guards() == []       # ... and none writes beyond either end of a buffer
     for x, y in zip(clean, poisoned):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("keep,scale_boost", [(0.5, 1.0), (0.93, 3.0), (0.02, 3.0)])
+def test_a_subset_call_filters_the_earlier_calls_lists_bit_for_bit(hip_lib, keep, scale_boost):
+    """LaRa's fine pass (network.py:502-525) renders `x[mask]` of the coarse pass's Gaussians from the same cameras with refined SH
+    coefficients.  `rasterize_gaussians_views(..., subset_of=(coarse colour, idx))` builds its per-tile lists by a stable filter
+    of the coarse call's (the sort key is (depth bits, id), the subset's numbering is monotone): images, radii, `point_list`,
+    `ranges`, the surfel-major pair map and every gradient must equal the full path's -- scatter + sort again -- BIT FOR BIT,
+    including lists several thousand entries deep (scale_boost 3) and a nearly empty subset."""
+    from lara_amd import rasterize_gaussians_views, rasterizer
+    act, cams = small_scene(grid=20, size=96, seed=11, scale_boost=scale_boost, opacity_boost=-1.0 if scale_boost > 1 else 0.0)
+    n, S = 4, 96
+    settings = [raster_settings(c, bg, device=DEV) for c, bg in zip(cams[:n], ((1, 1, 1), (0, 0, 0), (.5, .5, .5), (1, 1, 1)))]
+    P = act["means3D"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    idx = (torch.rand(P, generator=g) < keep).nonzero().squeeze(-1).to(DEV)
+    assert 0 < idx.numel() < P
+    coarse = {k: v.to(DEV).clone().requires_grad_(True) for k, v in act.items()}
+    c_color, c_radii, c_allmap = rasterize_gaussians_views(settings, coarse["means3D"], None, coarse["opacities"], shs=coarse["shs"],
+                                                           scales=coarse["scales"], rotations=coarse["rotations"])
+    dc = torch.randn(n, 3, S, S, generator=g).to(DEV)
+    da = (0.1 * torch.randn(n, 7, S, S, generator=g)).to(DEV)
+
+    def fine(subset_of):
+        t = {k: v.detach()[idx].clone().requires_grad_(True) for k, v in coarse.items()}
+        with torch.no_grad():
+            t["shs"].add_(0.05)                 # the refined coefficients: the only thing that differs from the coarse pass
+        color, radii, allmap = rasterize_gaussians_views(settings, t["means3D"], None, t["opacities"], shs=t["shs"], scales=t["scales"],
+                                                         rotations=t["rotations"], subset_of=subset_of)
+        node = color.grad_fn
+        v0 = rasterizer.state_views(node.state.view(n, node.strides[0])[2], idx.numel(), S, S, node.cap)
+        snap = {k: v0[k].clone() for k in ("header", "point_list", "ranges", "pair_pos", "pair_base", "geom", "tile_order", "seg_cnt")}
+        torch.autograd.backward([color, allmap], [dc, da])
+        return color.detach(), radii, allmap.detach(), {k: v.grad for k, v in t.items()}, snap, node.D
+
+    full = fine(None)
+    filt = fine((c_color, idx))
+    D = full[5]
+    assert filt[5] == D and D > 0
+    for a, b, name in zip(full[:3], filt[:3], ("color", "radii", "allmap")):
+        assert torch.equal(a, b), name
+    for k in full[3]:
+        assert torch.equal(full[3][k], filt[3][k]), f"grad {k}"
+    Dv = int(full[4]["header"][0])
+    for k in ("ranges", "geom", "seg_cnt", "pair_base"):
+        assert torch.equal(full[4][k], filt[4][k]), k
+    assert torch.equal(full[4]["point_list"][:Dv], filt[4]["point_list"][:Dv])
+    assert torch.equal(full[4]["pair_pos"][:Dv], filt[4]["pair_pos"][:Dv])
+    if scale_boost > 1 and keep > 0.9:
+        assert int(full[4]["header"][2]) > 2048, "the case must hold lists several rounds deep"
+    # the coarse call's own backward is untouched by having been read
+    torch.autograd.backward([c_color, c_allmap], [dc, da])
+    assert all(torch.isfinite(v.grad).all() for v in coarse.values())
+
+
+def test_a_subset_call_that_outgrows_its_buffers_is_repeated_like_any_other(hip_lib, monkeypatch):
+    from lara_amd import rasterize_gaussians_views, rasterizer
+    act, cams = small_scene(grid=16, size=128, seed=0, scale_boost=3.0)
+    settings = [raster_settings(c, (1, 1, 1), device=DEV) for c in cams[:2]]
+    P = act["means3D"].shape[0]
+    idx = torch.arange(0, P, 2, device=DEV)
+    coarse = {k: v.to(DEV).clone().requires_grad_(True) for k, v in act.items()}
+    c_color, _, _ = rasterize_gaussians_views(settings, coarse["means3D"], None, coarse["opacities"], shs=coarse["shs"],
+                                              scales=coarse["scales"], rotations=coarse["rotations"])
+    t = {k: v.detach()[idx].clone().requires_grad_(True) for k, v in coarse.items()}
+    kw = dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    want, _, _ = rasterize_gaussians_views(settings, t["means3D"], None, t["opacities"], **kw)
+    monkeypatch.setattr(rasterizer, "_next_capacity", lambda bucket: 4096)      # far too small: the subset call must come back repaired
+    before = rasterizer._reruns
+    got, _, _ = rasterize_gaussians_views(settings, t["means3D"], None, t["opacities"], subset_of=(c_color, idx), **kw)
+    assert rasterizer._reruns == before + 1 and torch.equal(got, want)
+    rasterizer.reset_capacity_history()
