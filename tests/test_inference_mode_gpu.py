@@ -181,3 +181,55 @@ def test_a_training_loop_through_a_pair_count_jump_never_sees_nan(hip_lib, monke
     reruns = rasterizer._reruns - reruns0
     assert 1 <= reruns <= 8, reruns       # the first call of the class and the views of the jump step, nothing else
     rasterizer.reset_capacity_history()
+
+
+@pytest.mark.parametrize("n_views,H,W", [(11, 80, 64), (1, 50, 70), (9, 48, 112)])
+def test_forward_only_and_subset_calls_beyond_one_launch_chunk_and_on_ragged_images(hip_lib, n_views, H, W):
+    """More cameras than one batched launch holds (8: the library issues chunks), image sides that are no multiples of the 16-pixel
+    tile, precomputed colours: the forward-only call and the subset call against the training-mode full path, bit for bit."""
+    from lara_amd import cameras, rasterize_gaussians_views
+    from lara_amd import GaussianRasterizationSettings
+    act, _ = small_scene(grid=12, size=64, seed=21, scale_boost=2.0)
+    cams = cameras.make_cameras(cameras.turntable_c2w(n_views), W, H, 0.75, 0.75, 1.906 - 0.8, 1.906 + 0.8, device=DEV)
+    settings = [GaussianRasterizationSettings(H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), torch.full((3,), 0.25 * (i % 4), device=DEV), 1.0,
+                                              c.world_view_transform.contiguous(), c.full_proj_transform.contiguous(), 1,
+                                              c.camera_center.contiguous(), False, False) for i, c in enumerate(cams)]
+    t = _inputs(act, True)
+    P = t["means3D"].shape[0]
+    cols = torch.rand(P, 3, device=DEV, requires_grad=True)
+    for kw in (dict(shs=t["shs"]), dict(colors_precomp=cols)):
+        args = (settings, t["means3D"], None, t["opacities"])
+        geo = dict(scales=t["scales"], rotations=t["rotations"])
+        c, r, a = rasterize_gaussians_views(*args, **kw, **geo)
+        with torch.no_grad():
+            c2, r2, a2 = rasterize_gaussians_views(*args, **kw, **geo)
+        assert c.grad_fn is not None and c2.grad_fn is None
+        assert torch.equal(c.detach(), c2) and torch.equal(r, r2) and torch.equal(a.detach(), a2)
+        # a subset of every third surfel, once through its own scatter + sort, once as a filter of the call above
+        idx = torch.arange(1, P, 3, device=DEV)
+        sub = {k: (v.detach()[idx].clone().requires_grad_(True)) for k, v in t.items()}
+        skw = dict(shs=sub["shs"]) if "shs" in kw else dict(colors_precomp=cols.detach()[idx].clone().requires_grad_(True))
+        sgeo = dict(scales=sub["scales"], rotations=sub["rotations"])
+        full = rasterize_gaussians_views(settings, sub["means3D"], None, sub["opacities"], **skw, **sgeo)
+        filt = rasterize_gaussians_views(settings, sub["means3D"], None, sub["opacities"], **skw, **sgeo, subset_of=(c, idx))
+        for x, y in zip(full, filt):
+            assert torch.equal(x.detach(), y.detach())
+        gf = torch.autograd.grad((full[0].sum() + full[2][:, :2].sum()), [sub["means3D"], sub["opacities"]])
+        gs = torch.autograd.grad((filt[0].sum() + filt[2][:, :2].sum()), [sub["means3D"], sub["opacities"]])
+        for x, y in zip(gf, gs):
+            assert torch.equal(x, y)
+
+
+def test_forward_only_call_without_surfels_is_the_background(hip_lib):
+    from lara_amd import GaussianRasterizer, rasterize_gaussians_views
+    _, cams = small_scene(grid=4, size=48, seed=0)
+    rs = [raster_settings(c, (0.25, 0.5, 0.75), device=DEV) for c in cams[:2]]
+    z = lambda *s: torch.zeros(s, device=DEV)
+    with torch.no_grad():
+        color, radii, allmap = GaussianRasterizer(rs[0])(means3D=z(0, 3), means2D=None, shs=z(0, 4, 3), opacities=z(0, 1), scales=z(0, 2),
+                                                         rotations=z(0, 4))
+        cv, rv, av = rasterize_gaussians_views(rs, z(0, 3), None, z(0, 1), shs=z(0, 4, 3), scales=z(0, 2), rotations=z(0, 4))
+    torch.cuda.synchronize()
+    want = torch.tensor([0.25, 0.5, 0.75], device=DEV)[:, None, None].expand(3, 48, 48)
+    assert radii.numel() == 0 and torch.equal(color, want) and float(allmap.abs().max()) == 0.0
+    assert torch.equal(cv[0], want) and torch.equal(cv[1], want) and float(av.abs().max()) == 0.0
