@@ -35,7 +35,7 @@
 namespace {
 
 #ifndef MF_TIMING
-#define MF_TIMING 0                        // timing-only builds (results invalid; tools/build_variant.sh -DMF_TIMING=n): 1 = no epilogue,
+#define MF_TIMING 0                        // timing-only builds (results invalid; tools/build_variant.sh -DMF_TIMING=n): 1 = no epilogue, 8 = no weight stream,
 #endif                                     // 2 = no products (weight stream + MFMAs), 4 = no phase 0
 // NW = waves per workgroup: 8 (128 token rows, one workgroup per CU) or 4 (64 rows, 69 KB of LDS: TWO workgroups per CU, whose
 // memory phases -- the tile's rows in, the results out -- run under the other one's products; the weights then travel L2 -> LDS twice
@@ -45,15 +45,26 @@ namespace {
 #endif
 constexpr int MF_SLOT = 16384;             // bytes per weight slot
 constexpr int MF_CONST = 5 * 1024;         // b1 (512) | b2 (256) | ln3 gamma (256) | ln3 beta (256) floats
-template <int NW> struct MfCfg {
+#ifndef MF_SLOTS0
+#define MF_SLOTS0 4        // ring slots of the inference instantiation
+#endif
+#ifndef MF_SLOTS1
+#define MF_SLOTS1 4        // ... of the training forward and the backward (z chunk resident)
+#endif
+template <int NW, int MODE = 1> struct MfCfg {
     static constexpr int TM = 16 * NW;                     // token rows per workgroup
-    static constexpr int SLOTS = NW == 8 ? 4 : 3;          // ring
+    // (Ring depth, measured on one box, inference / training forward + backward products: 4 slots 171.6 / 455 + 145 us, 5 and 3
+    // slots 179.5 / 460 + 153, 6 and 4: 182.8 / 458 + 147, 7 and 5: 183.4 / 456 + 148 -- more bytes in flight do not speed the
+    // weight stream up; -DMF_SLOTS0 / -DMF_SLOTS1 for A/B builds.)
+    static constexpr int SLOTS = NW == 8 ? (MODE == 0 ? MF_SLOTS0 : MF_SLOTS1) : 3;          // ring
     static constexpr int AHEAD = SLOTS - 2;                // slots in flight behind the one being multiplied (see the loop)
     static constexpr int PW = 16 / NW;                     // one-KB pieces of a slot per wave
     static constexpr int HC = TM * 256;                    // the hidden chunk: [4 panels of 32 units][TM tokens][64 B]
-    static constexpr int ZC = TM * 256;                    // the chunk's pre-activations z, same layout (training forward: out; backward: in)
-    static constexpr int LDS = HC + ZC + SLOTS * MF_SLOT + MF_CONST;   // 133 KB / 85 KB (phase 0's TM x 512 B of normalised rows and the
+    static constexpr int ZC = MODE == 0 ? 0 : TM * 256;    // the chunk's pre-activations z, same layout (training forward: out; backward: in)
+    static constexpr int LDS = HC + ZC + SLOTS * MF_SLOT + MF_CONST;   // (phase 0's TM x 512 B of normalised rows and the
                                                                        // epilogue's bounce tiles alias the chunk + ring region)
+    static_assert(HC + SLOTS * MF_SLOT >= TM * 512 && HC + SLOTS * MF_SLOT >= NW * 8704 + 2048, "phase 0 / the epilogue alias chunk + ring");
+    static_assert(LDS <= 163840, "one workgroup's LDS");
 };
 
 struct MlpP {
@@ -88,7 +99,7 @@ template <int MODE, int NW>
 __global__ void __launch_bounds__(64 * NW)
 mlp_fused_kernel(const MlpP p) {
     constexpr bool TRAIN = MODE == 1;
-    using Cfg = MfCfg<NW>;
+    using Cfg = MfCfg<NW, MODE>;
     constexpr int TM = Cfg::TM, PANEL = TM * 64, MF_SLOTS = Cfg::SLOTS, MF_AHEAD = Cfg::AHEAD, PW = Cfg::PW, MF_HC = Cfg::HC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *const hc = lds;                       // hidden chunk
@@ -104,6 +115,14 @@ mlp_fused_kernel(const MlpP p) {
     // fc2 wave tile: tokens wr * 64 .. + 64, outputs wc * 64 .. + 64
     const int wr = wave >> 2, wc = wave & 3;
 
+#ifdef MF_STAGGER
+    // Stagger: the workgroups of a round run their phases in lock-step -- every CU reads its rows at the same time, then every CU
+    // streams the weights from L2, then every CU writes -- so each shared resource is idle two thirds of the time.  Holding back every
+    // other workgroup of the FIRST round by about half a tile's time puts the two halves of the chip out of phase for the rest of the
+    // launch (a tile takes the same time everywhere, so the offset persists).
+    if (blockIdx.x < 256 && (blockIdx.x & 1))
+        for (int i = 0; i < MF_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+#endif
     // ---- the weight stream: slot n of a tile = (chunk c = n / 8, k = n % 8): k < 4: W1 rows c*128 .. +128, channels 64 k .. +64 as
     //      two 32-channel sub-tiles [2][128 rows][64 B]; k >= 4: W2 rows 0 .. 256, hidden units c*128 + 32 (k-4) .. +32 as [256 rows][64 B].
     //      A slot is 16 one-KB pieces (16 rows x 64 B, lane L -> row L / 4, physical chunk L & 3 = logical chunk ^ ((row >> 2) & 3));
@@ -129,6 +148,7 @@ mlp_fused_kernel(const MlpP p) {
 #define MF_DMA(base, voff, ldsaddr) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"((uint32_t)(ldsaddr)), "v"((uint32_t)(voff)), "s"(base) : "memory")
     auto issue = [&](const int n) {      // this wave's pieces of slot n (n < 32)
+        if (MF_TIMING & 8) return;       // (timing-only: no weight stream -- the products run on whatever the ring holds)
         const int c = n >> 3, k = n & 7;
         const uint32_t dst = ring_a + (n % MF_SLOTS) * MF_SLOT;
 #pragma unroll
@@ -231,14 +251,24 @@ mlp_fused_kernel(const MlpP p) {
             const int n = c * 8 + k;
             // (wait + barrier as ONE asm statement with a memory clobber: the barrier intrinsic alone does not order the compiler's
             // LDS accesses; lgkmcnt(0): this wave's chunk stores have landed before anybody is told to read them)
-            static_assert(PW * MF_AHEAD == 4, "the counted waits below are written for four younger pieces in flight");
-            if (n + MF_AHEAD < 32) {
-                issue(n + MF_AHEAD);
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            } else if (MF_AHEAD == 2 && n + 1 < 32) {
-                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // this wave's pieces of slot n have landed once at most PW * (slots issued behind it) are outstanding
+            if (n + MF_AHEAD < 32) issue(n + MF_AHEAD);
+            {
+                constexpr int kMaxYounger = PW * MF_AHEAD;
+                const int younger = PW * (n + MF_AHEAD < 32 ? MF_AHEAD : 31 - n);      // (n is a constant of the unrolled loop)
+                static_assert(kMaxYounger <= 12, "add cases below");
+                // (the backward's z pieces are requested at k == 0 behind that trip's slot and are needed at k == 3: with AHEAD <= 3 every
+                // piece the k == 3 wait leaves outstanding is younger than they are)
+                static_assert(MODE < 2 || MF_AHEAD <= 3, "the z chunk's pieces would be among the outstanding ones at k == 3");
+                switch (younger) {
+                case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                }
             }
             const unsigned char *slot = ring + (n % MF_SLOTS) * MF_SLOT;
             if (MODE >= 2 && k == 0) {
@@ -528,7 +558,7 @@ mlp_fused_kernel(const MlpP p) {
 
 template <int MODE>
 static inline hipError_t launch_mlp_fused(const MlpP &p, hipStream_t s) {
-    using Cfg = MfCfg<MF_NW>;
+    using Cfg = MfCfg<MF_NW, MODE>;
     static_assert(MODE < 2 || MF_NW == 8, "the backward's epilogue deals 64-row halves to eight waves");
     static const hipError_t attr = hipFuncSetAttribute((const void *)mlp_fused_kernel<MODE, MF_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (attr != hipSuccess) return attr;
