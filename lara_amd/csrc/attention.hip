@@ -52,11 +52,10 @@ int lara_groupattn_forward(int32_t G, int32_t cond_dim, const float *x, const ui
     {
         L2D_PROF("ga_fused", s);
         const int units = (G + 3) / 4;
-        // the two 256 x 256 weights in fragment order (2 x 128 KB at the start of the workspace): two launches of 32
+        // the two 256 x 256 weights in fragment order (2 x 128 KB at the start of the workspace): one launch of 64
         // workgroups in front of the step
         unsigned short *wqp = (unsigned short *)workspace, *wop = wqp + 65536;
-        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, wq, wqp);
-        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, wo, wop);
+        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(64), dim3(256), 0, s, wq, wqp, wo, wop);
         hipLaunchKernelGGL(group_attn_fused2_kernel<false>, dim3(units), dim3(64), 0, s, x, ln_weight, ln_bias, eps, wqp, kvf, wop, y, G,
                            (unsigned short *)nullptr, (unsigned short *)nullptr, (unsigned short *)nullptr);
     }

@@ -1273,8 +1273,7 @@ int block_forward_keep(int M, int cond_dim, const float *x_in, const unsigned sh
     }
     {
         unsigned short *wqp = (unsigned short *)(save + L.wpack), *wop = wqp + 65536;
-        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, w->wq, wqp);
-        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(32), dim3(256), 0, s, w->wo, wop);
+        hipLaunchKernelGGL(pack_weight_frag_kernel, dim3(64), dim3(256), 0, s, w->wq, wqp, w->wo, wop);
         hipLaunchKernelGGL(group_attn_fused2_kernel<true>, dim3((G + 3) / 4), dim3(64), 0, s, x_in, w->ln1_w, w->ln1_b, w->eps, wqp, kv, wop,
                            x1, G, xn1, q, o);
     }

@@ -59,8 +59,13 @@ __device__ __forceinline__ float wave_total(float x) {
 // the row-major matrix a fragment instruction touches 32 rows x 32 bytes -- 64 separate L1 accesses, 23.6 k per wave and unit,
 // and the kernel sat on the L1's access rate (TCP_TOTAL_CACHE_ACCESSES 96.6 M per launch = 180 us of 222); packed, the same
 // instruction reads 1 KB of consecutive bytes.
-__global__ void __launch_bounds__(256) pack_weight_frag_kernel(const unsigned short *__restrict__ W, unsigned short *__restrict__ out) {
-    const int t = blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk per thread: 8192 chunks
+// (both weights of the step in ONE launch of 64 workgroups -- 32 per matrix; round 6: two launches per layer until then)
+__global__ void __launch_bounds__(256) pack_weight_frag_kernel(const unsigned short *__restrict__ W0, unsigned short *__restrict__ out0,
+                                                               const unsigned short *__restrict__ W1, unsigned short *__restrict__ out1) {
+    const bool second = blockIdx.x >= 32;
+    const unsigned short *W = second ? W1 : W0;
+    unsigned short *out = second ? out1 : out0;
+    const int t = (blockIdx.x & 31) * 256 + threadIdx.x;   // one 16-byte chunk per thread: 8192 chunks per matrix
     const int lane = t & 63, ks = (t >> 6) & 15, nt = t >> 10;
     *(uint4 *)(out + (size_t)t * 8) = *(const uint4 *)(W + (size_t)(nt * 32 + (lane & 31)) * 256 + ks * 16 + 8 * (lane >> 5));
 }
