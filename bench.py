@@ -79,6 +79,9 @@ def parse():
                     help="pipeline step: `reference` applies Network._check_mask as a training step does (a mask keeping > 50 %% of the "
                          "Gaussians is thinned to about half at random, network.py:381-388); `plain` keeps every Gaussian above the "
                          "opacity threshold (what an eval step renders)")
+    ap.add_argument("--dense-map-grads", action="store_true",
+                    help="A/B only: a pass whose maps take no gradient hands the rasteriser seven planes of zeros (the behaviour up to "
+                         "round 5) instead of None = the colour-only composite_bwd")
     ap.add_argument("--fine-rebins", action="store_true",
                     help="pipeline step: the fine pass scatters and sorts its own lists (rounds 1-5) instead of filtering the coarse pass's "
                          "(`rasterize_gaussians_views(..., subset_of=...)`, round 6); same results bit for bit")
@@ -1224,7 +1227,15 @@ def make_pipeline_step(args, device, rank, world, plumbing):
     enc = VolTransformer(256, 800, [args.grid // 4], args.grid // 2, args.grid, 80, args.encoder_layers, 16)
     pipe = LaRaPipeline(enc, CoarseFineDecoder(), grid_reso=args.grid // 2, n_streams=args.streams).to(device)
     pipe.fine_mask = args.fine_mask
-    pipe.fine_reuses_coarse_lists = not args.fine_rebins
+    pipe.fine_reuses_coarse_lists = not getattr(args, "fine_rebins", False)
+    if getattr(args, "dense_map_grads", False):
+        from lara_amd import renderer
+        plain = renderer._SurfaceMapsViews.backward
+
+        def dense(ctx, *gs):
+            out = plain(ctx, *gs)
+            return out if out[1] is not None else (out[0], torch.zeros_like(ctx.saved_tensors[1])) + tuple(out[2:])
+        renderer._SurfaceMapsViews.backward = staticmethod(dense)
     pipe._streams = _streams      # one pair of scene streams for every leg of this process: the device has 4 hardware queues, and a
                                   # second pair (the side legs' `step`) would alias onto them and serialise (93.5 vs 82.3 ms)
     pipe.train()

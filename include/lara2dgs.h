@@ -155,6 +155,8 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
 /* Replaces `_C.rasterize_gaussians_backward(...)`.  `state` is the buffer a forward with forward_only = 0 filled (a view
  * with forward_only = 1 is LARA2DGS_E_INVALID here); the backward WRITES to it (it
  * re-orders the work-item list `bwd_items` in place and sets header[22]): one backward at a time per state buffer.
+ * dL_dallmap may be NULL = no gradient on any of the seven maps (LaRa's fine pass, lightning/loss.py:35-47: the loss reads its
+ * image only): the compositing backward then runs its colour-only form -- same gradients as seven planes of zeros, to rounding.
  * Gradient outputs (any may be NULL when the corresponding input was NULL):
  *   dL_dmeans3D [P,3], dL_dmeans2D [P,3], dL_dshs [P,M,3], dL_dcolors [P,3], dL_dopacities [P],
  *   dL_dscales [P,2], dL_drotations [P,4], dL_dtransmat [P,9].  They are fully overwritten. */
@@ -216,7 +218,7 @@ typedef struct lara2dgs_grad_layout {
 int lara2dgs_get_grad_layout(int32_t P, int32_t sh_coeffs, int32_t has_shs, int32_t has_colors,
                              int32_t has_scale_rot, int32_t has_transmat, lara2dgs_grad_layout *out);
 
-/* Backward of lara2dgs_forward_views: dL_dcolor [n,3,H,W], dL_dallmap [n,7,H,W], radii [n,P].  grad_out
+/* Backward of lara2dgs_forward_views: dL_dcolor [n,3,H,W], dL_dallmap [n,7,H,W] or NULL (= zero, as above), radii [n,P].  grad_out
  * ([layout.total] floats; every gradient array in it is fully overwritten) receives the gradients summed over the
  * views in view order -- the sum over a scene's views that autograd otherwise forms with n-1 accumulation kernels per
  * input, and bit-reproducible: each view's per-pair gradient rows stay in its own scratch buffer and ONE per-surfel launch

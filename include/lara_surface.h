@@ -58,7 +58,8 @@ int lara_activate_gaussians_backward(int64_t P, const float *opacity_act, const 
  * (lightning/network.py:527: `torch.cat([view[k] ...], dim=1)`): color [n,3,H,W], allmap [n,7,H,W], rays [n,H,W,6],
  * rots [n,9]; every output (and, in the backward, every output gradient) is ONE [H, n*W, C] map in which view v owns the
  * columns [v*W, (v+1)*W).  d_color [n,3,H,W] and d_allmap [n,7,H,W] are fully overwritten.  With n = 1 these are the
- * single-view entry points above. */
+ * single-view entry points above.  d_allmap may be NULL when the five map gradients (everything but g_image) are NULL: the
+ * seven planes would be zeros, and lara2dgs_backward* takes NULL for exactly that. */
 int lara_surface_maps_forward_views(int32_t n_views, int32_t H, int32_t W, const float *color, const float *allmap,
                                     const float *rays, const float *rots, float depth_ratio, float *image, float *depth,
                                     float *acc_map, float *rend_normal, float *depth_normal, float *rend_dist, void *stream);

@@ -196,7 +196,7 @@ int lara2dgs_backward(const lara2dgs_view *view, const float *means3D, const flo
                       float *dL_dtransmat, void *stream) {
     ViewDev v;
     if (!make_view(view, v)) return LARA2DGS_E_INVALID;
-    if (!dL_dcolor || !dL_dallmap || !state || !scratch) return LARA2DGS_E_INVALID;
+    if (!dL_dcolor || !state || !scratch) return LARA2DGS_E_INVALID;      // (dL_dallmap NULL = zero: the colour-only backward)
     if (v.fwd_only) return LARA2DGS_E_INVALID;      // a forward-only call kept nothing for a backward
     if (v.P == 0) return LARA2DGS_OK;
     if (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacities) return LARA2DGS_E_INVALID;
@@ -424,7 +424,7 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
     const lara2dgs_view &v0 = views[0];
     if (v0.forward_only) return LARA2DGS_E_INVALID;      // a forward-only call kept nothing for a backward
     if (!strides_ok(v0, state_stride, scratch_stride)) return LARA2DGS_E_INVALID;
-    if (!dL_dcolor || !dL_dallmap) return LARA2DGS_E_INVALID;
+    if (!dL_dcolor) return LARA2DGS_E_INVALID;      // (dL_dallmap NULL = zero: the colour-only backward)
     const bool has_sh = shs != nullptr, has_col = colors_precomp != nullptr, has_sr = scales && rotations,
                has_tm = transmat_precomp != nullptr;
     lara2dgs_grad_layout G;
@@ -457,7 +457,7 @@ int lara2dgs_backward_views(int32_t n_views, const lara2dgs_view *views, const f
         for (int k = 0; k < vb.n; k++) vb.bg[k] = vd[i0 + k].bg;
         rc = launch_bwd_order(vd[i0], st[i0], sc[i0], caller, &vb, sc[i0].pair_valid, SL[i0].total - SL[i0].pair_valid);
         if (rc == LARA2DGS_OK)
-            rc = launch_composite_bwd(vd[i0], st[i0], sc[i0], dL_dcolor + (int64_t)i0 * 3 * HW, dL_dallmap + (int64_t)i0 * 7 * HW, caller, &vb);
+            rc = launch_composite_bwd(vd[i0], st[i0], sc[i0], dL_dcolor + (int64_t)i0 * 3 * HW, dL_dallmap ? dL_dallmap + (int64_t)i0 * 7 * HW : nullptr, caller, &vb);
         if (rc == LARA2DGS_OK)
             rc = launch_preprocess_bwd_views(vd[i0], vb.n, &vd[i0], i0 > 0, means3D, shs, colors_precomp, scales, rotations,
                                              transmat_precomp, &rad[i0], &st[i0], &sc[i0], at(grad_out, G.means3D),

@@ -547,6 +547,10 @@ __device__ __forceinline__ void quad_reduce_scatter(const float dp[3], const flo
         const float send = k.b1 * t + (k.b2 * d + k.b3 * tq);
         r[c] = mine + dpp_full<0x4E>(send);              // quad_perm [2,3,0,1]
     }
+    // (A DPP instruction's bank_mask cannot replace the selects: a "bank" is four CONSECUTIVE lanes of a row -- a whole quad --, not a
+    // lane position inside the quad.  Tried in round 6 with the masks read as lane positions: 374 -> 366 us and wrong sums.  With the
+    // block's four pixels at lane stride 4 the masks would fit, but the full exchanges of rows 0-2 then need two masked DPP adds
+    // each where one quad_perm does today: 16 + 12 DPP adds against 17 + 14 selects, 13 issue clocks of 600 per trip.)
     float v1[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) {
@@ -561,6 +565,32 @@ __device__ __forceinline__ void quad_reduce_scatter(const float dp[3], const flo
         r[3 + i] = mine + dpp_full<0x4E>(send);
     }
     r[5] = v1[4] + dpp_full<0x4E>(v1[4]);
+}
+// the 16-sum form of the colour-only backward: rows 0-2 as above, r[3] = sum h[lane & 3]
+__device__ __forceinline__ void quad_reduce_scatter16(const float dp[3], const float q[3], const float h[4], const QuadCoef &k,
+                                                      float r[4], const int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float d = dp[c], qq = q[c];
+        asm volatile("" : "+v"(d));
+        asm volatile("" : "+v"(qq));     // (q is a product here: left alone it is fused into the sum -- v_mov_dpp + v_fmac, another rounding)
+        const float t = d + dpp_full<0xB1>(d);
+        const float tq = qq + dpp_full<0xB1>(qq);
+        const float mine = k.a1 * t + (k.a2 * d + k.a3 * tq);
+        const float send = k.b1 * t + (k.b2 * d + k.b3 * tq);
+        r[c] = mine + dpp_full<0x4E>(send);
+    }
+    float v1[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float mine = b0 ? h[2 * i + 1] : h[2 * i];
+        const float send = b0 ? h[2 * i] : h[2 * i + 1];
+        v1[i] = mine + dpp_full<0xB1>(send);
+    }
+    const float mine = b1 ? v1[1] : v1[0];
+    const float send = b1 ? v1[0] : v1[1];
+    r[3] = mine + dpp_full<0x4E>(send);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -591,7 +621,16 @@ constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
 #endif
 constexpr int SLAB_POOL = L2D_SLAB_POOL;    // (entry, 2x2 block) slots per round (tools/build_variant.sh -DL2D_SLAB_POOL=n for A/B runs)
 constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padded to 96 bytes (48 KB in all)
+// MAPS = false: the call has a gradient on the COLOUR image only (dL_dallmap is NULL = zero: LaRa's fine pass always, its coarse pass
+// for the first 1000 iterations -- lightning/loss.py:35-60 puts the distortion and normal terms on the coarse maps alone).  Then
+// dL/ddepth of every pair is zero and with it the depth / distortion / median / normal chains of the walk; an (entry, block) slot
+// carries 16 sums instead of 22 (64 bytes, written by ONE ds_write_b128 per lane), the pool holds 576 slots instead of 384.  Every
+// term that is left is computed as in the full kernel; the two agree to the rounding of a product that is now not fused with a
+// zero (tests/test_raster_parity_gpu.py).
+constexpr int SLAB_F_COLOR = 16;
+constexpr int SLAB_POOL_COLOR = SLAB_POOL * SLAB_F / SLAB_F_COLOR;
 
+template <bool MAPS>
 #ifdef L2D_BWD_WAVES       // waves per SIMD the register allocation aims at (tools/build_variant.sh -DL2D_BWD_WAVES=n for A/B runs)
 __global__ void __launch_bounds__(256, L2D_BWD_WAVES)
 #else
@@ -621,8 +660,9 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         if (vb.n) v.bg = vb.bg[blockIdx.z];
     }
     constexpr int WIN = SLAB_WIN;
+    constexpr int POOL = MAPS ? SLAB_POOL : SLAB_POOL_COLOR, SF = MAPS ? SLAB_F : SLAB_F_COLOR;
     __shared__ float4 rec[REC4 * WIN];
-    __shared__ __attribute__((aligned(16))) float pool[(SLAB_POOL + 1) * SLAB_F];    // (+ one slot that stays zero, for phase S2)
+    __shared__ __attribute__((aligned(16))) float pool[(POOL + 1) * SF];    // (+ one slot that stays zero, for phase S2)
     __shared__ uint32_t s_base[SLAB_CHUNK];  // first pool slot of each entry of the round
     __shared__ unsigned long long s_live[SLAB_CHUNK];  // an entry's candidate blocks whose quad still walks it
     __shared__ uint32_t s_ql[64];            // per 2x2 block: last contributor over its four pixels
@@ -676,19 +716,21 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
     const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
-    const uint32_t median_contributor = inside ? n_contrib[pix + HW] : 0u;
+    const uint32_t median_contributor = (MAPS && inside) ? n_contrib[pix + HW] : 0u;
     float dpix[3] = {0.f, 0.f, 0.f}, dnrm[3] = {0.f, 0.f, 0.f};
     float dL_ddepth = 0.f, dL_daccum = 0.f, dL_dmedian = 0.f, dL_dreg = 0.f;
     float final_D = 0.f, final_D2 = 0.f;
     if (inside) {
         for (int ch = 0; ch < 3; ch++) dpix[ch] = dL_dcolor[ch * HW + pix];
-        dL_ddepth = dL_dallmap[0 * HW + pix];
-        dL_daccum = dL_dallmap[1 * HW + pix];
-        for (int ch = 0; ch < 3; ch++) dnrm[ch] = dL_dallmap[(2 + ch) * HW + pix];
-        dL_dmedian = dL_dallmap[5 * HW + pix];
-        dL_dreg = dL_dallmap[6 * HW + pix];
-        final_D = final_T[pix + HW];
-        final_D2 = final_T[pix + 2 * HW];
+        if constexpr (MAPS) {
+            dL_ddepth = dL_dallmap[0 * HW + pix];
+            dL_daccum = dL_dallmap[1 * HW + pix];
+            for (int ch = 0; ch < 3; ch++) dnrm[ch] = dL_dallmap[(2 + ch) * HW + pix];
+            dL_dmedian = dL_dallmap[5 * HW + pix];
+            dL_dreg = dL_dallmap[6 * HW + pix];
+            final_D = final_T[pix + HW];
+            final_D2 = final_T[pix + 2 * HW];
+        }
     }
     const float final_A = 1.0f - T_final;
     const float bg_dot_dpixel = v.bg[0] * dpix[0] + v.bg[1] * dpix[1] + v.bg[2] * dpix[2];
@@ -705,7 +747,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0xB1, 0xf, 0xf, false));
     quad_last = max(quad_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)quad_last, 0x4E, 0xf, 0xf, false));
     if ((lane & 3) == 0) s_ql[my_blk] = quad_last;  // read by wave 0 after the first window's barrier
-    if (tid < SLAB_F) pool[SLAB_POOL * SLAB_F + tid] = 0.f;
+    if (tid < SF) pool[POOL * SF + tid] = 0.f;
 
     // A pixel whose walk began above this segment resumes from the forward's checkpoint at seg_hi:
     // with F the running sum of f_k * w_k over entries < seg_hi and T_b the transmittance there,
@@ -715,13 +757,20 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         const float Tb = ck[0], inv_Tb = 1.0f / Tb;
         T = Tb;
         const float s_alpha = (Tb - T_final) * inv_Tb;
-        const float s_m1 = (final_D - ck[1 * 256]) * inv_Tb, s_m2 = (final_D2 - ck[2 * 256]) * inv_Tb;
-        float sg = (Tb - T_final) * dL_daccum + (final_T[pix + 6 * HW] - ck[6 * 256]) * dL_ddepth;
-        for (int ch = 0; ch < 3; ch++)
-            sg += (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * dpix[ch] +
-                  (final_T[pix + (7 + ch) * HW] - ck[(7 + ch) * 256]) * dnrm[ch];
-        accum_g = sg * inv_Tb;
-        last_dL_dT = (final_D2 * s_alpha + final_A * s_m2 - 2.0f * final_D * s_m1) * dL_dreg;
+        if constexpr (MAPS) {
+            const float s_m1 = (final_D - ck[1 * 256]) * inv_Tb, s_m2 = (final_D2 - ck[2 * 256]) * inv_Tb;
+            float sg = (Tb - T_final) * dL_daccum + (final_T[pix + 6 * HW] - ck[6 * 256]) * dL_ddepth;
+            for (int ch = 0; ch < 3; ch++)
+                sg += (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * dpix[ch] +
+                      (final_T[pix + (7 + ch) * HW] - ck[(7 + ch) * 256]) * dnrm[ch];
+            accum_g = sg * inv_Tb;
+            last_dL_dT = (final_D2 * s_alpha + final_A * s_m2 - 2.0f * final_D * s_m1) * dL_dreg;
+        } else {
+            (void)s_alpha;
+            float sg = 0.f;
+            for (int ch = 0; ch < 3; ch++) sg += (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * dpix[ch];
+            accum_g = sg * inv_Tb;
+        }
     }
 
     // Windows of WIN entries, back to front; window slot e <-> list position whi - 1 - e.  Surfel
@@ -730,7 +779,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     uint32_t id2 = total - WIN - 1 - tid >= lo ? point_list[range.x + total - WIN - 1 - tid] : 0u;
     uint2 mk1 = total - 1 - tid >= lo ? pair_mask[range.x + total - 1 - tid] : make_uint2(0u, 0u);
     uint2 mk2 = total - WIN - 1 - tid >= lo ? pair_mask[range.x + total - WIN - 1 - tid] : make_uint2(0u, 0u);
-    int dirty = SLAB_POOL;  // pool slots that may hold data (all of them before the first round)
+    int dirty = POOL;  // pool slots that may hold data (all of them before the first round)
     for (int whi = total; whi > lo; whi -= WIN) {
         const int wcnt = min(WIN, whi - lo);
         const uint32_t id0 = id1;
@@ -798,8 +847,8 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     if (lane >= d) incl += y;
                 }
                 const uint32_t b0 = incl - c[0] - c[1], b1 = incl - c[1];
-                const unsigned long long f0 = __ballot(s0 + 2 * lane < wcnt && b1 <= (uint32_t)SLAB_POOL);
-                const unsigned long long f1 = __ballot(s0 + 2 * lane + 1 < wcnt && incl <= (uint32_t)SLAB_POOL);
+                const unsigned long long f0 = __ballot(s0 + 2 * lane < wcnt && b1 <= (uint32_t)POOL);
+                const unsigned long long f1 = __ballot(s0 + 2 * lane + 1 < wcnt && incl <= (uint32_t)POOL);
                 // entries that fit form a prefix; at least one fits (a slab has at most 64 slots)
                 const int L = f1 == ~0ull ? 64 : __builtin_ctzll(~f1);
                 if (lane == 0) s_nfit = L == 64 ? 128 : 2 * L + (int)((f0 >> L) & 1ull);
@@ -809,12 +858,12 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             } else {  // the other three waves clear what the previous round used of the pool: a block no
                       // quad visits must read as zeros
                 float4 *pw = (float4 *)pool;
-                for (int i = tid - 64; i < dirty * (SLAB_F / 4); i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = tid - 64; i < dirty * (SF / 4); i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __syncthreads();
             DBG_PHASE(2);
             const int nfit = s_nfit;
-            dirty = nfit < SLAB_CHUNK ? (int)s_base[nfit] : min((int)s_total, SLAB_POOL);
+            dirty = nfit < SLAB_CHUNK ? (int)s_base[nfit] : min((int)s_total, POOL);
             dbg_entries += (uint32_t)nfit; dbg_slots += (uint32_t)dirty;
 
             // ---- phase P: every quad walks its own candidates over the whole round, last list position
@@ -852,7 +901,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 // clear-lowest-bit: a third of the instructions of the 64-bit pair-of-words bookkeeping)
                 uint32_t mm = (uint32_t)m0, q1 = (uint32_t)(m0 >> 32), q2 = (uint32_t)m1, q3 = (uint32_t)(m1 >> 32);
                 int jb = 0;
-                while (__ballot((mm | q1 | q2 | q3) != 0u) != 0ull) {
+                auto trip = [&]() __attribute__((always_inline)) {
                     dbg_trips++;
                     while (mm == 0u && (q1 | q2 | q3) != 0u) { mm = q1; q1 = q2; q2 = q3; q3 = 0u; jb += 32; }
                     const bool has = mm != 0u;
@@ -870,6 +919,43 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     // lanes keep their state and contribute exact zeros.
                     const float4 r4 = rec[4 * WIN + ws], r5 = rec[5 * WIN + ws];
                     const float nrm[3] = {r4.x, r4.y, r4.z}, rgb[3] = {r4.w, r5.x, r5.y};
+                    if constexpr (!MAPS) {
+                        // Colour gradient only: no depth, distortion, median or normal chain (dL/dz = 0 for every pair); what is
+                        // left is the code below, term for term.  16 sums per (entry, block): rows 0-2 as in the full kernel with
+                        // (G da, qG2 ddx, qG2 ddy) in the place of the three dL/dz sums, row 3 = the colour products and the weight.
+                        (void)nrm;
+                        const float alpha = active ? h.alpha : 0.f;
+                        const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                        const float T_new = T * inv_1ma;
+                        const float w = alpha * T_new;
+                        const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2];
+                        const float accum_new = mul_legacy(last_alpha, last_g) + (1.f - last_alpha) * accum_g;
+                        float dL_dalpha = gval - accum_new;
+                        dL_dalpha *= T_new;
+                        dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                        T = T_new;
+                        accum_g = accum_new;
+                        last_g = gval;
+                        last_alpha = alpha;
+                        const float da = active ? dL_dalpha : 0.f;
+                        const float sx = h.sx, sy = h.sy;
+                        const float rz3 = (active && h.use3d) ? h.rz : 0.f;
+                        const float qG = opa * da * h.G;
+                        const float dL_dsx = -mul_legacy(qG, sx), dL_dsy = -mul_legacy(qG, sy);
+                        const float dpx = dL_dsx * rz3, dpy = dL_dsy * rz3;
+                        const float dpv[3] = {dpx, dpy, -(mul_legacy(dpx, sx) + mul_legacy(dpy, sy))};
+                        const float qG2 = h.use3d ? 0.f : -FILTER_INV_SQUARE * qG;
+                        const float q3[3] = {h.G * da, qG2 * h.ddx, qG2 * h.ddy};
+                        const float h4[4] = {w * dpix[0], w * dpix[1], w * dpix[2], w};
+                        float r[4];
+                        quad_reduce_scatter16(dpv, q3, h4, qcoef, r, lane);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) asm volatile("" : "+v"(r[i]));
+                        const unsigned long long lv = s_live[has ? j : 0];
+                        const int rank = __builtin_popcount((uint32_t)lv & below_lo) + __builtin_popcount((uint32_t)(lv >> 32) & below_hi);
+                        float4 *ps = (float4 *)(pool + ((int)s_base[has ? j : 0] + rank) * SF) + (lane & 3);
+                        if (has) *ps = make_float4(r[0], r[1], r[2], r[3]);     // slot float 4 (lane & 3) + i = r[i]
+                    } else {
                     // An inactive lane runs the recurrences with alpha = 0, which leaves its state where the next active
                     // entry would have put it anyway: T / (1 - 0) = T; the collapsed "what lies behind" recurrence
                     // becomes (accum_new, *, 0) and the next step's 0 * last_g + 1 * accum_new reproduces accum_new
@@ -941,6 +1027,15 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                         ps[0] = r[0]; ps[4] = r[1]; ps[8] = r[2]; ps[12] = r[3]; ps[16] = r[4];
                         if (!(lane & 2)) ps[20] = r[5];
                     }
+                    }   // MAPS
+                };
+                // (two trips per loop iteration: the five state registers alternate instead of being copied at the loop's top)
+                while (__ballot((mm | q1 | q2 | q3) != 0u) != 0ull) {
+                    trip();
+#ifndef L2D_WALK_NO_UNROLL
+                    if (__ballot((mm | q1 | q2 | q3) != 0u) == 0ull) break;
+                    trip();
+#endif
                 }
             }
             __syncthreads();
@@ -961,30 +1056,37 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 }
                 // the lane's first slot is LOADED (a lane without one reads the pool's extra, always-zero slot): no 24 zero moves and
                 // no adds for the first slot
-                float g[22];
-                const float4 *ps = (const float4 *)(pool + (int)s_base[e] * SLAB_F);
+                constexpr int NG = MAPS ? 22 : 16;
+                float g[NG];
+                const float4 *ps = (const float4 *)(pool + (int)s_base[e] * SF);
                 {
-                    const float4 *p0 = part < cnt ? ps + part * (SLAB_F / 4) : (const float4 *)(pool + SLAB_POOL * SLAB_F);
+                    const float4 *p0 = part < cnt ? ps + part * (SF / 4) : (const float4 *)(pool + POOL * SF);
 #pragma unroll
-                    for (int q = 0; q < 5; q++) {
+                    for (int q = 0; q < NG / 4; q++) {
                         const float4 t = p0[q];
                         g[4 * q] = t.x; g[4 * q + 1] = t.y; g[4 * q + 2] = t.z; g[4 * q + 3] = t.w;
                     }
-                    const float2 t2 = *(const float2 *)(p0 + 5);
-                    g[20] = t2.x; g[21] = t2.y;
+                    if constexpr (MAPS) {
+                        const float2 t2 = *(const float2 *)(p0 + 5);
+                        g[20] = t2.x; g[21] = t2.y;
+                    }
                 }
                 for (int i = part + 2; i < cnt; i += 2) {
 #pragma unroll
-                    for (int q = 0; q < 5; q++) {
-                        const float4 t = ps[i * (SLAB_F / 4) + q];
+                    for (int q = 0; q < NG / 4; q++) {
+                        const float4 t = ps[i * (SF / 4) + q];
                         g[4 * q] += t.x; g[4 * q + 1] += t.y; g[4 * q + 2] += t.z; g[4 * q + 3] += t.w;
                     }
-                    const float2 t2 = *(const float2 *)(ps + i * (SLAB_F / 4) + 5);
-                    g[20] += t2.x; g[21] += t2.y;
+                    if constexpr (MAPS) {
+                        const float2 t2 = *(const float2 *)(ps + i * (SF / 4) + 5);
+                        g[20] += t2.x; g[21] += t2.y;
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < 22; k++) g[k] += dpp_full<0xB1>(g[k]);  // the entry's two lanes
-                const bool touched = g[21] > 0.f;
+                for (int k = 0; k < NG; k++) g[k] += dpp_full<0xB1>(g[k]);  // the entry's two lanes
+                // (colour-only slots: float 4 l + i = lane l's r[i] -- rows 0-2 transposed, (G da, qG2 ddx, qG2 ddy) where the full
+                //  kernel has the dL/dz sums, the colour products and the weight in every lane's last float)
+                const bool touched = (MAPS ? g[21] : g[15]) > 0.f;
                 if (part == 0 && touched) {
                     const uint32_t p = range.x + (uint32_t)(whi - 1 - ws);
                     const float4 g0 = gq0, g1 = gq1, g2 = gq2;
@@ -992,8 +1094,10 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     const float k0[3] = {X0 * Tw[0] - Tu[0], X0 * Tw[1] - Tu[1], X0 * Tw[2] - Tu[2]};
                     const float l0[3] = {Y0 * Tw[0] - Tv[0], Y0 * Tw[1] - Tv[1], Y0 * Tw[2] - Tv[2]};
                     // slot rows 0-2 = per component of dL/dp: (sum, sum lx, sum ly, q) -- see quad_reduce_scatter
-                    const float a[3] = {g[0], g[4], g[8]}, b[3] = {g[1], g[5], g[9]}, cc[3] = {g[2], g[6], g[10]};
-                    const float qd[3] = {g[3], g[7], g[11]};       // sums of dz sx, dz sy, dz
+                    const float a[3] = {g[0], MAPS ? g[4] : g[1], MAPS ? g[8] : g[2]};
+                    const float b[3] = {MAPS ? g[1] : g[4], g[5], MAPS ? g[9] : g[6]};
+                    const float cc[3] = {MAPS ? g[2] : g[8], MAPS ? g[6] : g[9], g[10]};
+                    const float qd[3] = {MAPS ? g[3] : 0.f, MAPS ? g[7] : 0.f, MAPS ? g[11] : 0.f};       // sums of dz sx, dz sy, dz
                     // A = k0 x l0, B = Tw x l0, C = k0 x Tw ; for y = u x v: dL/du = v x dL/dy, dL/dv = dL/dy x u
                     float t1[3], t2[3], dk0[3], dl0[3], dTw[3];
                     cross3(l0, a, t1); cross3(Tw, cc, t2);
@@ -1001,7 +1105,10 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     cross3(a, k0, t1); cross3(b, Tw, t2);
                     for (int i = 0; i < 3; i++) dl0[i] = t1[i] + t2[i];
                     cross3(l0, b, t1); cross3(cc, k0, t2);
-                    for (int i = 0; i < 3; i++) dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i] + qd[i];
+                    for (int i = 0; i < 3; i++) {
+                        dTw[i] = t1[i] + t2[i] + X0 * dk0[i] + Y0 * dl0[i];
+                        if constexpr (MAPS) dTw[i] += qd[i];
+                    }
                     // one 80-byte gradient row per touched (tile, surfel) pair, written exactly once, at the pair's
                     // SURFEL-MAJOR index (pair_pos[p], recorded by the sort): a surfel's rows are contiguous and
                     // preprocess_bwd streams them; a byte per pair marks the rows that exist
@@ -1009,9 +1116,15 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     float4 *row = pair_grad + (size_t)q * (GRAD_F / 4);
                     row[0] = make_float4(-dk0[0], -dk0[1], -dk0[2], -dl0[0]);
                     row[1] = make_float4(-dl0[1], -dl0[2], dTw[0], dTw[1]);
-                    row[2] = make_float4(dTw[2], g[12], g[13], g[14]);
-                    row[3] = make_float4(g[15], g[16], g[17], g[18]);
-                    row[4] = make_float4(g[19], g[20], 0.f, 0.f);
+                    if constexpr (MAPS) {
+                        row[2] = make_float4(dTw[2], g[12], g[13], g[14]);
+                        row[3] = make_float4(g[15], g[16], g[17], g[18]);
+                        row[4] = make_float4(g[19], g[20], 0.f, 0.f);
+                    } else {
+                        row[2] = make_float4(dTw[2], g[13], g[14], 0.f);
+                        row[3] = make_float4(0.f, 0.f, g[12], g[3]);
+                        row[4] = make_float4(g[7], g[11], 0.f, 0.f);
+                    }
                     pair_valid[q] = 1;
                     dbg_rows++;
                 }
@@ -1165,11 +1278,13 @@ int launch_composite_bwd(const ViewDev &v, StateView st, ScratchView sc, const f
     ViewBatch vb{};
     if (vbp) vb = *vbp;
     {
-        L2D_PROF("composite_bwd", s);
+        L2D_PROF(dL_dallmap ? "composite_bwd" : "composite_bwd_color", s);
         // one workgroup per (tile, segment); the count lives on the device (header[3]), so launch
         // the upper bound -- surplus workgroups exit on their first instruction
         const unsigned grid = (unsigned)v.tiles + v.cap / L2D_SEG;
-        hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid, 1, vbp ? (unsigned)vb.n : 1u), dim3(256), 0, s, v, st.header, st.ranges,
+        // dL_dallmap == NULL: the gradient on the seven maps is zero -> the colour-only kernel
+        auto kern = dL_dallmap ? composite_bwd_kernel<true> : composite_bwd_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3(grid, 1, vbp ? (unsigned)vb.n : 1u), dim3(256), 0, s, v, st.header, st.ranges,
                            st.point_list, (const float4 *)st.geom, st.tile_order,
                            (const float4 *)st.cullbox, st.final_T, st.n_contrib, st.seg_base, st.seg_cnt, st.bwd_order,
                            st.bwd_items, st.ckpt, st.pair_mask, st.tile_maxc, dL_dcolor, dL_dallmap, st.pair_pos, sc.pair_grad,

@@ -121,12 +121,13 @@ surface_bwd_kernel(const SurfP p0, const float *__restrict__ g_image, const floa
     const int y = (int)(pix / p.W), x = (int)(pix - (size_t)y * p.W);
     const size_t o = out_pix(p, vw, y, x);
     d_color += (size_t)vw * 3 * HW;
-    d_allmap += (size_t)vw * 7 * HW;
 #pragma unroll
     for (int c = 0; c < 3; c++) {  // clamp passes the gradient inside [0, 1] (bounds included, as torch does)
         const float v = p.color[c * HW + pix];
         d_color[c * HW + pix] = (g_image && v >= 0.f && v <= 1.f) ? g_image[o * 3 + c] : 0.f;
     }
+    if (!d_allmap) return;      // no gradient on any of the five maps: the seven planes would be zeros (the caller passes NULL on)
+    d_allmap += (size_t)vw * 7 * HW;
     // gradient of the surface depth: direct + through the points of the four neighbouring normals
     float gs = g_depth ? g_depth[o] : 0.f;
     if (g_dn) {
@@ -254,7 +255,8 @@ int lara_surface_maps_backward_views(int32_t n_views, int32_t H, int32_t W, cons
                                      const float *g_rend_dist, float *d_color, float *d_allmap, void *stream) {
     if (n_views < 0 || H < 0 || W < 0 || n_views > 65535) return LARA2DGS_E_INVALID;
     if (n_views == 0 || H == 0 || W == 0) return LARA2DGS_OK;
-    if (!color || !allmap || !rays || !rots || !d_color || !d_allmap) return LARA2DGS_E_INVALID;
+    if (!color || !allmap || !rays || !rots || !d_color) return LARA2DGS_E_INVALID;
+    if (!d_allmap && (g_depth || g_acc_map || g_rend_normal || g_depth_normal || g_rend_dist)) return LARA2DGS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     SurfP p{H, W, color, allmap, rays, rots, depth_ratio, n_views};
     const size_t HW = (size_t)H * W;

@@ -516,10 +516,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(device):
             if grad_color is None:
                 grad_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
-            if grad_allmap is None:
-                grad_allmap = torch.zeros((7, H, W), dtype=torch.float32, device=device)
             grad_color = _prep(grad_color, "grad_color", device)
-            grad_allmap = _prep(grad_allmap, "grad_allmap", device)
+            if grad_allmap is not None:       # (None = no gradient on the maps: the library's colour-only backward)
+                grad_allmap = _prep(grad_allmap, "grad_allmap", device)
             view = _View(P, int(rs.sh_degree), ctx.M, H, W, float(rs.tanfovx), float(rs.tanfovy),
                          float(rs.scale_modifier), ctx.prefiltered_bits, int(bool(rs.debug)), 0,
                          cap, bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), None)
@@ -538,7 +537,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ctypes.byref(view), _ptr(means3D), _ptr(sh if has_sh else None),
                 _ptr(col if has_col else None), _ptr(sc if has_sr else None),
                 _ptr(rot if has_sr else None), _ptr(tm if has_tm else None), radii.data_ptr(),
-                grad_color.data_ptr(), grad_allmap.data_ptr(), state.data_ptr(), scratch.data_ptr(),
+                grad_color.data_ptr(), _ptr(grad_allmap), state.data_ptr(), scratch.data_ptr(),
                 g_means3D.data_ptr(), g_means2D.data_ptr(), _ptr(g_sh), _ptr(g_col),
                 g_opac.data_ptr(), _ptr(g_sc), _ptr(g_rot), _ptr(g_tm), stream)
             _check(rc, "lara2dgs_backward")
@@ -664,10 +663,9 @@ class _RasterizeViews(torch.autograd.Function):
         with torch.cuda.device(device):
             if grad_color is None:
                 grad_color = torch.zeros((n, 3, H, W), dtype=torch.float32, device=device)
-            if grad_allmap is None:
-                grad_allmap = torch.zeros((n, 7, H, W), dtype=torch.float32, device=device)
             grad_color = _prep(grad_color, "grad_color", device)
-            grad_allmap = _prep(grad_allmap, "grad_allmap", device)
+            if grad_allmap is not None:       # (None = no gradient on the maps: the library's colour-only backward)
+                grad_allmap = _prep(grad_allmap, "grad_allmap", device)
             views = (_View * n)()
             for i, rs in enumerate(settings):
                 bg, vm, pm, cp = cams[4 * i:4 * i + 4]
@@ -682,7 +680,7 @@ class _RasterizeViews(torch.autograd.Function):
             rc = lib.lara2dgs_backward_views(
                 n, views, _ptr(means3D), _ptr(sh if has_sh else None), _ptr(col if has_col else None),
                 _ptr(sc if has_sr else None), _ptr(rot if has_sr else None), _ptr(tm if has_tm else None),
-                radii.data_ptr(), grad_color.data_ptr(), grad_allmap.data_ptr(), state.data_ptr(), sb,
+                radii.data_ptr(), grad_color.data_ptr(), _ptr(grad_allmap), state.data_ptr(), sb,
                 scratch.data_ptr(), qb, out.data_ptr(), stream)
             _check(rc, "lara2dgs_backward_views")
 

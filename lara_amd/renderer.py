@@ -82,11 +82,12 @@ class _SurfaceMaps(torch.autograd.Function):
         color, allmap, rays, rot = ctx.saved_tensors
         H, W = color.shape[1], color.shape[2]
         gs = [None if g is None else g.float().contiguous() for g in (g_image, g_depth, g_acc, g_rnorm, g_dnorm, g_rdist)]
-        d_color, d_allmap = torch.empty_like(color), torch.empty_like(allmap)
+        d_color = torch.empty_like(color)
+        d_allmap = None if all(g is None for g in gs[1:]) else torch.empty_like(allmap)     # (see _SurfaceMapsViews.backward)
         with torch.cuda.device(color.device):
             _check(_lib().lara_surface_maps_backward(H, W, color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), rot.data_ptr(),
                                                      ctx.depth_ratio, *[None if g is None else g.data_ptr() for g in gs],
-                                                     d_color.data_ptr(), d_allmap.data_ptr(),
+                                                     d_color.data_ptr(), None if d_allmap is None else d_allmap.data_ptr(),
                                                      torch.cuda.current_stream(color.device).cuda_stream),
                    "lara_surface_maps_backward")
         return d_color, d_allmap, None, None, None
@@ -175,11 +176,14 @@ class _SurfaceMapsViews(torch.autograd.Function):
         color, allmap, rays, rots = ctx.saved_tensors
         n, H, W = color.shape[0], color.shape[2], color.shape[3]
         gs = [None if g is None else g.float().contiguous() for g in (g_image, g_depth, g_acc, g_rnorm, g_dnorm, g_rdist)]
-        d_color, d_allmap = torch.empty_like(color), torch.empty_like(allmap)
+        # no gradient on any of the five maps (LaRa's fine pass: the loss reads its image only, lightning/loss.py:35-47): the
+        # seven planes of d_allmap would be zeros -- None instead, which the rasteriser's backward takes as "colour only"
+        d_color = torch.empty_like(color)
+        d_allmap = None if all(g is None for g in gs[1:]) else torch.empty_like(allmap)
         with torch.cuda.device(color.device):
             _check(_lib().lara_surface_maps_backward_views(n, H, W, color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), rots.data_ptr(),
                                                            ctx.depth_ratio, *[None if g is None else g.data_ptr() for g in gs],
-                                                           d_color.data_ptr(), d_allmap.data_ptr(),
+                                                           d_color.data_ptr(), None if d_allmap is None else d_allmap.data_ptr(),
                                                            torch.cuda.current_stream(color.device).cuda_stream),
                    "lara_surface_maps_backward_views")
         return d_color, d_allmap, None, None, None, None

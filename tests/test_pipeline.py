@@ -218,6 +218,38 @@ def test_pipeline_equals_the_operators_called_one_by_one(hip_lib, with_fine, n_s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("it,with_fine", [(2000, True), (500, True), (500, False), (2000, False)])
+def test_passes_whose_maps_take_no_gradient_run_the_colour_only_backward(hip_lib, it, with_fine):
+    """lightning/loss.py:35-60: the fine pass contributes its image only; the coarse pass its distortion and normal maps from
+    iteration 1000 on, and -- whenever there is a fine pass -- its image, depth and alpha maps through the fine decoder's
+    sampler (network.py:499-504).  A pass without a gradient on its maps hands `None` down to the rasteriser (no seven planes of
+    zeros written and read) and the library runs composite_bwd's colour-only form for it."""
+    from lara_amd import rasterizer
+    from lara_amd.pipeline import lara_loss
+    dev = torch.device("cuda:0")
+    pipe, batch, feat_vol = _small_problem(dev)
+    out = pipe(batch, feat_vol, with_fine=with_fine)
+    loss, _ = lara_loss(batch, out, it, ms_ssim=False)
+    pipe.join_streams()
+    torch.cuda.synchronize()
+    rasterizer.profile_enable(True)
+    try:
+        rasterizer.profile_collect()
+        loss.backward()
+        pipe.join_streams()
+        torch.cuda.synchronize()
+        names = [n for n, _ in rasterizer.profile_collect()]
+    finally:
+        rasterizer.profile_enable(False)
+    scenes = batch["tar_rgb"].shape[0]
+    coarse_full = with_fine or it > 1000
+    assert names.count("composite_bwd") == (scenes if coarse_full else 0), names
+    assert names.count("composite_bwd_color") == (scenes if with_fine else 0) + (0 if coarse_full else scenes), names
+    used = [p for n, p in pipe.named_parameters() if p.requires_grad and (with_fine or not n.startswith(("decoder.norm", "decoder.cross_att", "decoder.mlp_fine")))]
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in used)
+
+
+@pytest.mark.gpu
 def test_pipeline_reference_mask_thins_dense_masks_in_training(hip_lib):
     """`fine_mask = "reference"` applies `_check_mask` (network.py:381-388): with > 50 % of the Gaussians above the
     opacity threshold a training step renders about half of them in the fine pass, an eval step all of them."""

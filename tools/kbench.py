@@ -11,6 +11,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--grid", type=int, default=64)
 ap.add_argument("--regimes", default="init,trained")
+ap.add_argument("--color-only", action="store_true", help="no gradient on the seven maps (LaRa's fine pass): composite_bwd's colour-only form")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 rasterizer.load_library()
@@ -32,7 +33,8 @@ for regime in args.regimes.split(","):
             color, radii, allmap = GaussianRasterizer(rs)(means3D=act["means3D"], means2D=torch.zeros_like(act["means3D"]),
                                                           shs=act["shs"], opacities=act["opacities"],
                                                           scales=act["scales"], rotations=act["rotations"])
-            outs += [color, allmap]; grads += [gc, ga]
+            outs += [color] if args.color_only else [color, allmap]
+            grads += [gc] if args.color_only else [gc, ga]
         torch.autograd.backward(outs, grads)
         torch.cuda.synchronize()
     for name, ms in rasterizer.profile_collect():
