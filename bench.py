@@ -193,18 +193,18 @@ def step(scenes, settings, gc, ga, n_streams=1, fine_idx=None, after=None, api="
         color, radii, allmap = GaussianRasterizer(rs)(
             means3D=centers, means2D=means2D, shs=shs, opacities=torch.sigmoid(opacity), scales=torch.exp(scales),
             rotations=torch.nn.functional.normalize(rotations), cov3D_precomp=None)
-        outs.extend((color, allmap))
-        grads.extend((gc, ga))
+        outs.extend((color, allmap) if ga is not None else (color,))
+        grads.extend((gc, ga) if ga is not None else (gc,))
 
     nv = len(settings)
-    gcs, gas = gc.expand(nv, *gc.shape), ga.expand(nv, *ga.shape)
+    gcs, gas = gc.expand(nv, *gc.shape), (ga.expand(nv, *ga.shape) if ga is not None else None)      # (ga None: no gradient on the maps)
 
     def render_views(centers, shs, opacity, scales, rotations):
         color, radii, allmap = rasterize_gaussians_views(
             settings, centers, torch.zeros_like(centers), torch.sigmoid(opacity), shs=shs, scales=torch.exp(scales),
             rotations=torch.nn.functional.normalize(rotations))
-        outs.extend((color, allmap))
-        grads.extend((gcs, gas))
+        outs.extend((color, allmap) if gas is not None else (color,))
+        grads.extend((gcs, gas) if gas is not None else (gcs,))
 
     for i, sc in enumerate(scenes):
         side = _streams[i % n_streams] if n_streams > 1 else None
@@ -381,6 +381,11 @@ def measure_roofline(scenes, settings, gc, ga, args):
     step(scenes, settings, gc, ga)
     torch.cuda.synchronize()
     rec = rasterizer.profile_collect()
+    # the same step without a gradient on the seven maps (LaRa's fine pass: lightning/loss.py reads its image only): the
+    # compositing backward's colour-only form
+    step(scenes, settings, gc, None)
+    torch.cuda.synchronize()
+    rec_color = [ms for name, ms in rasterizer.profile_collect() if name == "composite_bwd_color"]
     rasterizer.profile_enable(False)
     by_name = {}
     for name, ms in rec:
@@ -465,6 +470,10 @@ def measure_roofline(scenes, settings, gc, ga, args):
             "valu_useful_frac": None, "valu_insts_per_launch": insts, "valu_insts_source": insts_src,
             "avg_launch_us": round(t["avg_us"], 2), "host_stalls_left_out": stalls, "alg_bytes_per_launch": t["alg_bytes"],
             "pairs_per_frame_D": D, "measured_copy_GBs": round(copy_GBs, 1),
+            "color_only_backward": (None if not rec_color else {
+                "avg_launch_us": round(1e3 * sorted(rec_color)[len(rec_color) // 2], 2),
+                "what": "composite_bwd when the seven maps take no gradient (dL_dallmap = NULL: every fine pass of the headline step): "
+                        "median launch of the same frames; 16 sums per (entry, block) instead of 22, no depth / distortion / normal chain"}),
             "whole_frame": {"alg_bytes": frame_bytes, "kernel_us": round(frame_us, 1),
                             "achieved": round(frame_bytes / frame_us / 1e3, 1),
                             "frac": round(frame_bytes / frame_us / 1e3 / HBM_PEAK_GBS, 5)}}
