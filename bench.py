@@ -1712,6 +1712,7 @@ def main():
             torch.cuda.synchronize()
             from lara_amd import rasterizer as _rz5
             reruns0 = _rz5.capacity_report()["reruns"]
+            ms0 = torch.cuda.memory_stats()
             per = []
             for _ in range(args.steps):
                 t1 = time.perf_counter()
@@ -1723,6 +1724,13 @@ def main():
             out["step_with_reference_lr"] = {"value": round(frames_per_step * args.steps / d1, 3), "unit": "frames/s",
                                              "ms_per_step": round(1e3 * d1 / args.steps, 3), "lr": 4e-4,
                                              "ms_first_step": round(1e3 * per[0], 2), "ms_last_step": round(1e3 * per[-1], 2),
+                                             "ms_steps": [round(1e3 * x, 1) for x in per],
+                                             # (a step that grows a size class allocates its states afresh; one that makes the caching
+                                             #  allocator give its cached blocks back first shows here as a retry and a long step)
+                                             "allocator": {"retries": torch.cuda.memory_stats().get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
+                                                           "reserved_GiB_before": round(ms0.get("reserved_bytes.all.current", 0) / 2 ** 30, 2),
+                                                           "reserved_GiB_after": round(torch.cuda.memory_reserved() / 2 ** 30, 2),
+                                                           "peak_allocated_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
                                              "surfels_before": before, "surfels_after": surfel_stats(),
                                              "binning_capacity": {
                                                  "calls_repeated_at_a_larger_capacity": cap_rep.pop("reruns") - reruns0,
