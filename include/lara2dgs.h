@@ -156,7 +156,7 @@ int lara2dgs_forward(const lara2dgs_view *view, const float *means3D, const floa
  * with forward_only = 1 is LARA2DGS_E_INVALID here); the backward WRITES to it (it
  * re-orders the work-item list `bwd_items` in place and sets header[22]): one backward at a time per state buffer.
  * dL_dallmap may be NULL = no gradient on any of the seven maps (LaRa's fine pass, lightning/loss.py:35-47: the loss reads its
- * image only): the compositing backward then runs its colour-only form -- same gradients as seven planes of zeros, to rounding.
+ * image only): the compositing backward then runs its colour-only form -- same gradients as seven planes of zeros, bit for bit.
  * Gradient outputs (any may be NULL when the corresponding input was NULL):
  *   dL_dmeans3D [P,3], dL_dmeans2D [P,3], dL_dshs [P,M,3], dL_dcolors [P,3], dL_dopacities [P],
  *   dL_dscales [P,2], dL_drotations [P,4], dL_dtransmat [P,9].  They are fully overwritten. */

@@ -625,8 +625,8 @@ constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padd
 // for the first 1000 iterations -- lightning/loss.py:35-60 puts the distortion and normal terms on the coarse maps alone).  Then
 // dL/ddepth of every pair is zero and with it the depth / distortion / median / normal chains of the walk; an (entry, block) slot
 // carries 16 sums instead of 22 (64 bytes, written by ONE ds_write_b128 per lane), the pool holds 576 slots instead of 384.  Every
-// term that is left is computed as in the full kernel; the two agree to the rounding of a product that is now not fused with a
-// zero (tests/test_raster_parity_gpu.py).
+// term that is left is computed as in the full kernel, contraction for contraction: the two give the same bits for seven planes of
+// zeros (tests/test_raster_parity_gpu.py, tools/color_only_check.py).
 constexpr int SLAB_F_COLOR = 16;
 constexpr int SLAB_POOL_COLOR = SLAB_POOL * SLAB_F / SLAB_F_COLOR;
 
@@ -767,8 +767,14 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
             last_dL_dT = (final_D2 * s_alpha + final_A * s_m2 - 2.0f * final_D * s_m1) * dL_dreg;
         } else {
             (void)s_alpha;
+            // (each colour product rounded before it is added, as in the full kernel, where it is fused with its -- zero -- normal
+            //  product first: the two kernels then resume a segment from the same bits)
             float sg = 0.f;
-            for (int ch = 0; ch < 3; ch++) sg += (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * dpix[ch];
+            for (int ch = 0; ch < 3; ch++) {
+                float p = (final_T[pix + (3 + ch) * HW] - ck[(3 + ch) * 256]) * dpix[ch];
+                asm volatile("" : "+v"(p));
+                sg += p;
+            }
             accum_g = sg * inv_Tb;
         }
     }
@@ -928,11 +934,13 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                         const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                         const float T_new = T * inv_1ma;
                         const float w = alpha * T_new;
-                        const float gval = rgb[0] * dpix[0] + rgb[1] * dpix[1] + rgb[2] * dpix[2];
+                        // (the contractions written out the way the compiler fuses the full kernel's longer expressions, so that the
+                        //  two kernels round alike: the green product alone, red and blue fused onto it; the background term as a
+                        //  rounded product under the fused T_new * dL/dalpha)
+                        const float gval = __builtin_fmaf(rgb[2], dpix[2], __builtin_fmaf(rgb[0], dpix[0], rgb[1] * dpix[1]));
                         const float accum_new = mul_legacy(last_alpha, last_g) + (1.f - last_alpha) * accum_g;
                         float dL_dalpha = gval - accum_new;
-                        dL_dalpha *= T_new;
-                        dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
+                        dL_dalpha = __builtin_fmaf(T_new, dL_dalpha, -((T_final * inv_1ma) * bg_dot_dpixel));
                         T = T_new;
                         accum_g = accum_new;
                         last_g = gval;
