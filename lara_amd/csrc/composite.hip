@@ -628,11 +628,18 @@ constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padd
 // term that is left is computed as in the full kernel, contraction for contraction: the two give the same bits for seven planes of
 // zeros (tests/test_raster_parity_gpu.py, tools/color_only_check.py).
 constexpr int SLAB_F_COLOR = 16;
+#ifdef L2D_COLOR_OCC4      // A/B: the colour-only form at four workgroups per CU (384 slots = 24 KB, 128 VGPRs, 20 bytes of scratch): measured
+                           // 285 -> 270 us per view at init statistics, 77 -> 87 us trained-like (same box, two pairs) -- not shipped
+constexpr int SLAB_POOL_COLOR = SLAB_POOL;
+#else
 constexpr int SLAB_POOL_COLOR = SLAB_POOL * SLAB_F / SLAB_F_COLOR;
+#endif
 
 template <bool MAPS>
 #ifdef L2D_BWD_WAVES       // waves per SIMD the register allocation aims at (tools/build_variant.sh -DL2D_BWD_WAVES=n for A/B runs)
 __global__ void __launch_bounds__(256, L2D_BWD_WAVES)
+#elif defined(L2D_COLOR_OCC4)
+__global__ void __launch_bounds__(256, MAPS ? 1 : 4)
 #else
 __global__ void __launch_bounds__(256)
 #endif
