@@ -617,7 +617,7 @@ __device__ __forceinline__ void quad_reduce_scatter16(const float dp[3], const f
 constexpr int SLAB_WIN = 128;     // list entries staged per window (one per thread)
 constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
 #ifndef L2D_SLAB_POOL
-#define L2D_SLAB_POOL 384
+#define L2D_SLAB_POOL 374
 #endif
 constexpr int SLAB_POOL = L2D_SLAB_POOL;    // (entry, 2x2 block) slots per round (tools/build_variant.sh -DL2D_SLAB_POOL=n for A/B runs)
 constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padded to 96 bytes (48 KB in all)
@@ -670,12 +670,16 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     constexpr int POOL = MAPS ? SLAB_POOL : SLAB_POOL_COLOR, SF = MAPS ? SLAB_F : SLAB_F_COLOR;
     __shared__ float4 rec[REC4 * WIN];
     __shared__ __attribute__((aligned(16))) float pool[(POOL + 1) * SF];    // (+ one slot that stays zero, for phase S2)
-    __shared__ uint32_t s_base[SLAB_CHUNK];  // first pool slot of each entry of the round
-    __shared__ unsigned long long s_live[SLAB_CHUNK];  // an entry's candidate blocks whose quad still walks it
+    // The round's slot table (first pool slot and live-block mask per entry, number of entries that fit) and the window's surfel ids
+    // exist twice: while two lanes per entry add up round r's slots (phase S2), the waves that phase leaves idle stage the next
+    // window's records and size round r + 1 -- see the loop below.
+    __shared__ uint16_t s_base_[2][SLAB_CHUNK];  // first pool slot of each entry of the round
+    __shared__ unsigned long long s_live_[2][SLAB_CHUNK];  // an entry's candidate blocks whose quad still walks it
     __shared__ uint32_t s_ql[64];            // per 2x2 block: last contributor over its four pixels
-    __shared__ uint32_t s_id[WIN];
-    __shared__ int s_nfit;
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_id_[2][WIN];
+    __shared__ uint2 s_mask[WIN];            // the NEXT window's candidate masks (its first round is sized before it is staged)
+    __shared__ int s_nfit_[2];
+    __shared__ uint32_t s_total_[2];
     if (header[1]) return;
     const unsigned long long dbg_t0 = (v.dbg & 32u) ? wall_clock64() : 0ull;
     int dbg_rounds = 0;
@@ -786,49 +790,36 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
         }
     }
 
-    // Windows of WIN entries, back to front; window slot e <-> list position whi - 1 - e.  Surfel
-    // ids and the forward's candidate masks are fetched two windows ahead.
-    uint32_t id1 = total - 1 - tid >= lo ? point_list[range.x + total - 1 - tid] : 0u;
-    uint32_t id2 = total - WIN - 1 - tid >= lo ? point_list[range.x + total - WIN - 1 - tid] : 0u;
-    uint2 mk1 = total - 1 - tid >= lo ? pair_mask[range.x + total - 1 - tid] : make_uint2(0u, 0u);
-    uint2 mk2 = total - WIN - 1 - tid >= lo ? pair_mask[range.x + total - WIN - 1 - tid] : make_uint2(0u, 0u);
-    int dirty = POOL;  // pool slots that may hold data (all of them before the first round)
-    for (int whi = total; whi > lo; whi -= WIN) {
-        const int wcnt = min(WIN, whi - lo);
-        const uint32_t id0 = id1;
-        const uint2 mk0 = mk1;
-        id1 = id2;
-        mk1 = mk2;
-        id2 = whi - 2 * WIN - 1 - tid >= lo ? point_list[range.x + whi - 2 * WIN - 1 - tid] : 0u;
-        mk2 = whi - 2 * WIN - 1 - tid >= lo ? pair_mask[range.x + whi - 2 * WIN - 1 - tid] : make_uint2(0u, 0u);
-        __syncthreads();  // the previous window's last round is done with rec / s_id
-        DBG_PHASE(whi == total ? 0 : 4);
-        dbg_windows++;
-        if (tid < WIN) stage_entry_masked<WIN>(geom, id0, mk0, tid < wcnt, X0, Y0, rec, s_id, tid);
-        unsigned long long wm0 = 0ull, wm1 = 0ull;      // this quad's candidate bits over the window's 128 slots (set in the first round)
-
-        // Slab rounds over the window.  An entry's slab has four slots (the 2x2 pixels) per candidate
-        // block of its mask, in mask-bit order: slot = base + 4 * rank(block) + pixel-in-block with
-        // rank = popcount(mask below the block).  A round takes as many entries as fit the pool, at
-        // most 128.
-        for (int s0 = 0; s0 < wcnt;) {
-            dbg_rounds++;
-            __syncthreads();  // window staged / previous round's phase S2 done with pool, s_base
-            DBG_PHASE(s0 == 0 ? 1 : 4);
-            if (wave == 0) {  // lane l sizes entries 2l and 2l+1, one 64-lane scan covers the 128
+    // Windows of WIN entries, back to front; window slot e <-> list position whi - 1 - e.  A window is cut into rounds of as many
+    // entries as fit the slot pool.  Per round: the walk (all four waves), a barrier, then -- side by side -- phase S2 on the waves
+    // that own the round's entries (two lanes per entry: waves 0, 1 for the usual <= 64 entries) and, on waves 2 and 3, everything
+    // the NEXT round needs: its slot table (wave 3) and, when it opens a new window, that window's staged records (64 entries per
+    // wave); a second barrier.  Up to round 5 the slot table and the staging had phases of their own in front of the walk (14 % of
+    // the workgroup's time, one wave busy out of four) and a third barrier per round.  (The pool is not cleared between rounds:
+    // every slot a round allots is written by its quad -- an entry's slab has a slot for exactly the blocks whose quads walk it.)
+    // Surfel ids and the forward's candidate masks are fetched two windows ahead by the staging waves (entry tid - 128).
+    const int se = tid - 128;
+    const bool stager = se >= 0;
+    uint32_t id1 = 0u, id2 = 0u;            // the next window's ids / masks, and the one behind it
+    uint2 mk1 = make_uint2(0u, 0u), mk2 = mk1;
+    // sizes round `s0_` of the window that ends at list position `whi_` (`wcnt_` entries) into table `buf`; `side`: the window is
+    // not staged yet, its masks come from s_mask.  One wave: lane l sizes entries 2l and 2l+1, one 64-lane scan covers the 128.
+    auto size_round = [&](const int whi_, const int wcnt_, const int s0_, const int buf, const bool side) {
+        unsigned long long *const live_ = s_live_[buf];
+        uint16_t *const base_ = s_base_[buf];
                 // A block needs a slot in an entry's slab only while its quad still walks that entry
                 // (list position below the quad's last contributor): block b is live from round entry
                 // jmin_b = whi - s0 - quad_last_b on.  Lane b drops its bit at jmin_b, an OR-scan over
                 // the entries turns that into each entry's live mask.  Where pixels saturate early
                 // (opaque surfaces) the deep entries shrink to a few slots and rounds stay full.
-                const int jm = max(whi - s0 - (int)s_ql[lane], 0);
+                const int jm = max(whi_ - s0_ - (int)s_ql[lane], 0);
                 unsigned long long la = ~0ull, lb = ~0ull;
                 if (__ballot(jm > 0) != 0ull) {  // (usually every block is live for the whole round: skip)
                     // (volatile: the words are modified by OTHER lanes' atomics between this lane's store and load)
-                    volatile unsigned long long *vlive = s_live;
+                    volatile unsigned long long *vlive = live_;
                     vlive[2 * lane] = 0ull;
                     vlive[2 * lane + 1] = 0ull;
-                    if (jm < SLAB_CHUNK) atomicOr(&s_live[jm], 1ull << lane);
+                    if (jm < SLAB_CHUNK) atomicOr(&live_[jm], 1ull << lane);
                     __builtin_amdgcn_wave_barrier();
                     la = vlive[2 * lane];
                     lb = la | vlive[2 * lane + 1];
@@ -845,12 +836,13 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                 uint32_t c[2];
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
-                    const int slot = s0 + 2 * lane + q;
+                    const int slot = s0_ + 2 * lane + q;
                     unsigned long long mk = 0ull;
-                    if (slot < wcnt)
-                        mk = (((unsigned long long)__float_as_uint(rec[5 * WIN + slot].z) << 32) | __float_as_uint(rec[3 * WIN + slot].w)) &
-                             (q ? lb : la);
-                    s_live[2 * lane + q] = mk;
+                    if (slot < wcnt_) {
+                        const uint2 mw = side ? s_mask[slot] : make_uint2(__float_as_uint(rec[3 * WIN + slot].w), __float_as_uint(rec[5 * WIN + slot].z));
+                        mk = (((unsigned long long)mw.y << 32) | mw.x) & (q ? lb : la);
+                    }
+                    live_[2 * lane + q] = mk;
                     c[q] = (uint32_t)__builtin_popcountll(mk);
                 }
                 uint32_t incl = c[0] + c[1];
@@ -860,24 +852,49 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     if (lane >= d) incl += y;
                 }
                 const uint32_t b0 = incl - c[0] - c[1], b1 = incl - c[1];
-                const unsigned long long f0 = __ballot(s0 + 2 * lane < wcnt && b1 <= (uint32_t)POOL);
-                const unsigned long long f1 = __ballot(s0 + 2 * lane + 1 < wcnt && incl <= (uint32_t)POOL);
+                const unsigned long long f0 = __ballot(s0_ + 2 * lane < wcnt_ && b1 <= (uint32_t)POOL);
+                const unsigned long long f1 = __ballot(s0_ + 2 * lane + 1 < wcnt_ && incl <= (uint32_t)POOL);
                 // entries that fit form a prefix; at least one fits (a slab has at most 64 slots)
                 const int L = f1 == ~0ull ? 64 : __builtin_ctzll(~f1);
-                if (lane == 0) s_nfit = L == 64 ? 128 : 2 * L + (int)((f0 >> L) & 1ull);
-                s_base[2 * lane] = b0;
-                s_base[2 * lane + 1] = b1;
-                if (lane == 63) s_total = incl;
-            } else {  // the other three waves clear what the previous round used of the pool: a block no
-                      // quad visits must read as zeros
-                float4 *pw = (float4 *)pool;
-                for (int i = tid - 64; i < dirty * (SF / 4); i += 192) pw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            __syncthreads();
-            DBG_PHASE(2);
-            const int nfit = s_nfit;
-            dirty = nfit < SLAB_CHUNK ? (int)s_base[nfit] : min((int)s_total, POOL);
-            dbg_entries += (uint32_t)nfit; dbg_slots += (uint32_t)dirty;
+                if (lane == 0) s_nfit_[buf] = L == 64 ? 128 : 2 * L + (int)((f0 >> L) & 1ull);
+                base_[2 * lane] = (uint16_t)b0;
+                base_[2 * lane + 1] = (uint16_t)b1;
+                if (lane == 63) s_total_[buf] = incl;
+    };
+    {
+        const int wcnt = min(WIN, total - lo);
+        if (stager) {
+            const uint32_t id0 = total - 1 - se >= lo ? point_list[range.x + total - 1 - se] : 0u;
+            const uint2 mk0 = total - 1 - se >= lo ? pair_mask[range.x + total - 1 - se] : make_uint2(0u, 0u);
+            id1 = total - WIN - 1 - se >= lo ? point_list[range.x + total - WIN - 1 - se] : 0u;
+            mk1 = total - WIN - 1 - se >= lo ? pair_mask[range.x + total - WIN - 1 - se] : make_uint2(0u, 0u);
+            id2 = total - 2 * WIN - 1 - se >= lo ? point_list[range.x + total - 2 * WIN - 1 - se] : 0u;
+            mk2 = total - 2 * WIN - 1 - se >= lo ? pair_mask[range.x + total - 2 * WIN - 1 - se] : make_uint2(0u, 0u);
+            stage_entry_masked<WIN>(geom, id0, mk0, se < wcnt, X0, Y0, rec, s_id_[0], se);
+        }
+        __syncthreads();
+        if (wave == 3) size_round(total, wcnt, 0, 0, false);
+        __syncthreads();
+        DBG_PHASE(0);
+    }
+    int cur = 0, wb = 0;        // the slot table / the id list in use
+    for (int whi = total; whi > lo; whi -= WIN) {
+        const int wcnt = min(WIN, whi - lo);
+        const bool more_windows = whi - WIN > lo;
+        dbg_windows++;
+        if (stager) s_mask[se] = mk1;       // (read by wave 3 in this window's last round, barriers away)
+        unsigned long long wm0 = 0ull, wm1 = 0ull;      // this quad's candidate bits over the window's 128 slots (set in the first round)
+
+        // Slab rounds over the window.  An entry's slab has one slot per candidate block of its mask whose quad still walks the
+        // entry, in mask-bit order: slot = base + rank(block) with rank = popcount(live mask below the block).  A round takes as
+        // many entries as fit the pool, at most 128.
+        for (int s0 = 0; s0 < wcnt;) {
+            dbg_rounds++;
+            const unsigned long long *const s_live = s_live_[cur];
+            const uint16_t *const s_base = s_base_[cur];
+            const uint32_t *const s_id = s_id_[wb];
+            const int nfit = s_nfit_[cur];
+            if (v.dbg & 512u) { dbg_entries += (uint32_t)nfit; dbg_slots += nfit < SLAB_CHUNK ? (uint32_t)s_base[nfit] : min(s_total_[cur], (uint32_t)POOL); }
 
             // ---- phase P: every quad walks its own candidates over the whole round, last list position
             //      first (window slots ascend as list positions descend)
@@ -1053,7 +1070,7 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
 #endif
                 }
             }
-            __syncthreads();
+            __syncthreads();        // the round's slots are written
             DBG_PHASE(3);
 
             // ---- phase S2: two lanes per entry add up the entry's block slots (no geometry any more); a wave whose 32 entries lie
@@ -1144,8 +1161,26 @@ composite_bwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
                     dbg_rows++;
                 }
             }
+            // ---- beside phase S2, on waves 2 and 3: the next window's records (when this was the window's last round), the next
+            //      round's slot table
+            const bool last_round = s0 + nfit >= wcnt;
+            if (stager && last_round && more_windows) {
+                stage_entry_masked<WIN>(geom, id1, mk1, se < min(WIN, whi - WIN - lo), X0, Y0, rec, s_id_[wb ^ 1], se);
+                id1 = id2;
+                mk1 = mk2;
+                id2 = whi - 3 * WIN - 1 - se >= lo ? point_list[range.x + whi - 3 * WIN - 1 - se] : 0u;
+                mk2 = whi - 3 * WIN - 1 - se >= lo ? pair_mask[range.x + whi - 3 * WIN - 1 - se] : make_uint2(0u, 0u);
+            }
+            if (wave == 3) {
+                if (!last_round) size_round(whi, wcnt, s0 + nfit, cur ^ 1, false);
+                else if (more_windows) size_round(whi - WIN, min(WIN, whi - WIN - lo), 0, cur ^ 1, true);
+            }
+            __syncthreads();        // round r's slots are summed, round r + 1 is sized (and staged)
+            DBG_PHASE(4);
             s0 += nfit;
+            cur ^= 1;
         }
+        wb ^= 1;
     }
     if ((v.dbg & 64u) && tid == 0) {
         DBG_PHASE(4);
