@@ -1735,7 +1735,7 @@ def main():
                                              "binning_capacity": {
                                                  "calls_repeated_at_a_larger_capacity": cap_rep.pop("reruns") - reruns0,
                                                  "per_size_class": [{"surfels_sized_for": b[1], "image": [b[2], b[3]], "D_max": r_["D_max"],
-                                                                     "capacity_next_call": r_["capacity"],
+                                                                     "capacity_next_call": r_["capacity"], "longest_list": r_.get("longest_list"),
                                                                      "D_over_capacity": round(r_["D_max"] / r_["capacity"], 3)}
                                                                     for b, r_ in sorted(cap_rep.items())],
                                                  "what": "the pair capacity follows the measured pair counts (2 x the maximum of the size class's last "

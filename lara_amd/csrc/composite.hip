@@ -608,23 +608,25 @@ __device__ __forceinline__ void quad_reduce_scatter16(const float dp[3], const f
 //            the LDS slot of its (entry, block): plain ds_write, one writer per slot.  An entry's
 //            slab has one slot per candidate block of its mask (slot = base + popcount(mask below
 //            the block)); a 64-lane scan over the round hands out the bases, and a round takes as
-//            many entries as fit the 384-slot pool.
+//            many entries as fit the 374-slot pool.
 //   phase S2 (two lanes per entry) adds the entry's block slots, maps the sums back through
-//            A = k0 x l0, B = Tw x l0, C = k0 x Tw and writes the 80-byte gradient row.
+//            A = k0 x l0, B = Tw x l0, C = k0 x Tw and writes the 80-byte gradient row.  Beside it, on
+//            the waves it leaves idle: the next round's slot table and the next window's staging.
 // Versus reducing per entry across the wave inside the traversal (one candidate stream per wave, a
 // 55-instruction butterfly and a 64-lane gradient evaluation for 11 useful lanes) this needs half
 // the wave instructions, and it keeps the backward free of floating-point atomics.
-constexpr int SLAB_WIN = 128;     // list entries staged per window (one per thread)
+constexpr int SLAB_WIN = 128;     // list entries staged per window (one per thread of the two staging waves)
 constexpr int SLAB_CHUNK = 128;   // entries per slab round (two ballot words)
 #ifndef L2D_SLAB_POOL
 #define L2D_SLAB_POOL 374
 #endif
-constexpr int SLAB_POOL = L2D_SLAB_POOL;    // (entry, 2x2 block) slots per round (tools/build_variant.sh -DL2D_SLAB_POOL=n for A/B runs)
-constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padded to 96 bytes (48 KB in all)
+constexpr int SLAB_POOL = L2D_SLAB_POOL;    // (entry, 2x2 block) slots per round (tools/build_variant.sh -DL2D_SLAB_POOL=n for A/B runs); 374: the
+                                            // kernel's LDS must stay below 53 248 bytes for three workgroups per CU (384 slots: two, 460 us)
+constexpr int SLAB_F = 24;        // floats per slot: 22 quad-reduced sums, padded to 96 bytes (36 KB in all)
 // MAPS = false: the call has a gradient on the COLOUR image only (dL_dallmap is NULL = zero: LaRa's fine pass always, its coarse pass
 // for the first 1000 iterations -- lightning/loss.py:35-60 puts the distortion and normal terms on the coarse maps alone).  Then
 // dL/ddepth of every pair is zero and with it the depth / distortion / median / normal chains of the walk; an (entry, block) slot
-// carries 16 sums instead of 22 (64 bytes, written by ONE ds_write_b128 per lane), the pool holds 576 slots instead of 384.  Every
+// carries 16 sums instead of 22 (64 bytes, written by ONE ds_write_b128 per lane), the pool holds 561 slots instead of 374.  Every
 // term that is left is computed as in the full kernel, contraction for contraction: the two give the same bits for seven planes of
 // zeros (tests/test_raster_parity_gpu.py, tools/color_only_check.py).
 constexpr int SLAB_F_COLOR = 16;

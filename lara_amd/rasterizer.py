@@ -224,10 +224,14 @@ def binning_capacity(P: int, H: int = 0, W: int = 0, device: Optional[torch.devi
     return _next_capacity(_bucket(device, P, H, W))
 
 
+_longest = {}                 # size class -> the longest per-tile list any of its calls reported (diagnostic)
+
+
 def capacity_report() -> dict:
-    """{(device, sized surfels, H, W): {"D_max": the window's maximum, "calls": its length, "capacity": next call's}} +
-    "reruns": forwards repeated."""
-    rep = {b: {"D_max": max(h), "calls": len(h), "capacity": _cap_grid(max(b[1] * _dup_factor(), 2 * max(h)))}
+    """{(device, sized surfels, H, W): {"D_max": the window's maximum, "calls": its length, "capacity": next call's,
+    "longest_list": the longest per-tile list a call of the class has reported}} + "reruns": forwards repeated."""
+    rep = {b: {"D_max": max(h), "calls": len(h), "capacity": _cap_grid(max(b[1] * _dup_factor(), 2 * max(h))),
+               "longest_list": _longest.get(b, 0)}
            for b, h in _hist.items() if h}
     rep["reruns"] = _reruns
     return rep
@@ -236,6 +240,7 @@ def capacity_report() -> dict:
 def reset_capacity_history():
     """Forget the measured pair counts (tests)."""
     _hist.clear()
+    _longest.clear()
 
 
 # ---- the pair counts, read while the forward runs --------------------------------------------------------------------------
@@ -293,6 +298,8 @@ def _run_forward(bucket, n, enqueue, debug=False):
         done.record()
         D, overflow = _wait_counts(c, n, done, headers)
         note_pair_count(bucket, D)
+        if bool(c.np[:n, 3].all()):     # (the pinned words arrived: the longest list is among them)
+            _longest[bucket] = max(_longest.get(bucket, 0), int(c.np[:n, 2].max()))
         if not overflow:
             break
         new_cap = _cap_grid(max(2 * D, bucket[1] * _dup_factor()))

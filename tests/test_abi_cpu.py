@@ -169,7 +169,7 @@ def test_capacity_policy_follows_the_measured_pair_counts(monkeypatch):
     assert rz.binning_capacity(P, H, W, dev) == 3 << 22
     assert rz.binning_capacity(P, 1024, 1024, dev) == 3 << 20      # another size class: its own history
     rep = rz.capacity_report()
-    assert rep[b] == {"D_max": 4_600_000, "calls": 2, "capacity": 3 << 22} and "reruns" in rep
+    assert rep[b] == {"D_max": 4_600_000, "calls": 2, "capacity": 3 << 22, "longest_list": 0} and "reruns" in rep
     for _ in range(rz._HISTORY - 1):                                # the spike is still inside the window ...
         rz.note_pair_count(b, 1_545_000)
     assert rz.binning_capacity(P, H, W, dev) == 3 << 22
