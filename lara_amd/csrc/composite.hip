@@ -293,8 +293,12 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     static_assert(L2D_SEG % FWD_CHUNK == 0, "segment boundaries must fall on round boundaries");
     __shared__ float4 rec[REC4 * CHUNK];
     __shared__ unsigned long long qmask[4][16][CHUNK / 64];  // per wave, per quad: candidate words of the round
-    __shared__ uint32_t s_tmax;                               // largest last contributor over the tile's pixels
-    __shared__ uint32_t s_cost;                               // wave-trips of the current round, summed over the four waves
+    // Two words that live in the staged records' one unused field (plane 5's .w, staged as 0.f = 0u every round): with words of
+    // their own the kernel's LDS is 53 256 bytes + padding, and three workgroups only fit a CU up to 53 248 (measured on
+    // composite_bwd in round 6: 54 128 bytes ran at two).
+    uint32_t &s_cost = *(uint32_t *)&rec[5 * CHUNK + 0].w;   // wave-trips of the current round, summed over the four waves
+    uint32_t &s_tmax = *(uint32_t *)&rec[5 * CHUNK + 1].w;   // largest last contributor over the tile's pixels (used after the last round)
+    uint32_t &s_ndone = *(uint32_t *)&rec[5 * CHUNK + 2].w;  // waves whose 64 pixels are all finished (__syncthreads_count costs 256 bytes of LDS)
     const int tile = (v.dbg & 8u) ? (int)blockIdx.x : (int)tile_order[blockIdx.x];
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -354,8 +358,16 @@ composite_fwd_kernel(ViewDev v, const uint32_t *__restrict__ header, const uint2
     }
 #pragma unroll
     for (int q = 0; q < SPT; q++) cb1[q] = lo + q * 256 + tid < hi ? cullbox[id1[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 3) *(uint32_t *)&rec[5 * CHUNK + threadIdx.x].w = 0u;
+    __syncthreads();
     for (int base = lo; base < hi; base += CHUNK) {
-        if (__syncthreads_count(px.done) == 256) break;
+        {   // every pixel of the tile finished?  (the word is cleared by the staging below -- 0.f = 0u -- once everybody has read it or
+            // reads the cleared word: both say "go on")
+            const bool wave_done = __ballot(px.done) == ~0ull;
+            if (wave_done && lane == 0) atomicAdd(&s_ndone, 1u);
+            __syncthreads();
+            if (s_ndone == 4u) break;
+        }
         if (KEEP && tid == 0) {     // (between this barrier and the staging barrier no wave is in its walk)
             if (cost_round >= 0) { if ((uint32_t)cost_round < cost_nb) cost_full[cost_round] = s_cost; else *cost_last += s_cost; }
             s_cost = 0u;
