@@ -79,7 +79,13 @@ group_attn_fused2_kernel(const float *x /* may alias y: the block runs in place 
                         const float *__restrict__ beta, const float eps, const unsigned short *__restrict__ Wq /* packed */,
                         const unsigned short *__restrict__ KV, const unsigned short *__restrict__ Wo /* packed */, float *y, const int G,
                         unsigned short *__restrict__ xn_out, unsigned short *__restrict__ q_out, unsigned short *__restrict__ o_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[24576];
+#ifndef GA_LDS_BYTES
+#define GA_LDS_BYTES 24576
+#endif
+    // (tools/build_variant.sh -DGA_LDS_BYTES=n: occupancy experiments.  Round 6, inference instantiation, one box: 24 KB = six waves per
+    //  CU 137.0 us, 32 KB = five 159.0, 40 KB = four 146.7 -- an uneven number of waves per SIMD costs more than two waves buy; eight
+    //  (20 KB: K|V a quarter of the heads at a time) would be worth about what four -> six was, 7 %: not built.)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[GA_LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int unit = blockIdx.x, g0 = unit * 4;
     if (g0 >= G) return;
