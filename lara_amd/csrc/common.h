@@ -15,7 +15,10 @@
 #define L2D_SLICES 16            // per-tile counters are split 16 ways to shorten same-address atomic chains
 #define L2D_LDS_HIST_TILES 8192  // per-workgroup LDS tile histogram up to this many tiles (32 KB)
 #define GRAD_F 20          // floats per surfel in the backward accumulator (18 used)
-#define L2D_SEG 512       // backward work unit: a tile's list is cut into segments of this many entries
+#ifndef L2D_SEG
+#define L2D_SEG 512
+#endif                    // backward work unit: a tile's list is cut into segments of this many entries (1024, round 6: the per-view
+                          // backward 351 -> 403 us, trained-like 90 -> 150 us -- the launch's tail --, the 8-view step unchanged)
 #define L2D_CKPT_F 10      // floats per pixel in a segment-boundary checkpoint / in the per-pixel finals
 #define L2D_MAX_VIEWS 8    // cameras of one batched preprocess launch (a multi-view call with more views issues several)
 
